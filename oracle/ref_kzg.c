@@ -1,0 +1,777 @@
+/*
+ * oracle/ref_kzg.c -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * CPU restatement of the lambdaworks_kzg blob-commitment hot path. Every function
+ * cites the reference file:line it follows. Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may call this; the product never does.
+ *
+ * Two semantics:
+ *   mode 0 = "R": what /root/reference computes  (big-endian scalars = monomial
+ *                 coefficients, monomial SRS, big-endian Fiat-Shamir digest);
+ *   mode 1 = "C": what the c-kzg-4844 YAML vectors under /root/reference/tests encode
+ *                 (little-endian canonical scalars = evaluations on the bit-reversed
+ *                 4096th roots of unity; LE digest).  Mode C = bit-reversal + inverse
+ *                 NTT + mode R's monomial pipeline.
+ *
+ * Pinning (what this file has been checked against; see tests/test_oracle_*.py):
+ *   - /root/reference/tests/lib_test.rs:19-87, 89-167, 262-291 behaviours (mode R)
+ *   - /root/reference/src/compression.rs:155-221 unit KATs
+ *   - all c-kzg-4844 YAML vectors of blob_to_kzg_commitment / compute_kzg_proof /
+ *     compute_blob_kzg_proof (mode C), via tests/golden/ckzg_vectors.json
+ *   - the tau = 1337 closed form  sum s_i P_i = [sum s_i tau^i] G  
+ * For a generic blob in mode R the reference's own tests pin no number; parity there
+ * rests on the output being the canonical encoding of a mathematically defined point.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include "ref_field.h"
+
+#define N_BLOB 4096
+#define RET_OK 0
+#define RET_BADARGS 1
+#define RET_ERROR 2
+#define RET_MALLOC 3
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ SHA-256 (FIPS 180-4) */
+/* used by compute_challenge, /root/reference/src/utils.rs:148-154 (sha256::digest) */
+
+static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+static void sha256_block(uint32_t h[8], const uint8_t *b) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + SHA_K[i] + w[i];
+        uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        uint32_t mj = (a & bb) ^ (a & c) ^ (bb & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+EXPORT void orc_sha256(uint8_t out[32], const uint8_t *msg, size_t len) {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) sha256_block(h, msg + i);
+    uint8_t tail[128];
+    size_t rem = len - i;
+    memset(tail, 0, sizeof tail);
+    memcpy(tail, msg + i, rem);
+    tail[rem] = 0x80;
+    size_t tl = (rem + 9 <= 64) ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha256_block(h, tail);
+    if (tl == 128) sha256_block(h, tail + 64);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(h[k] >> 24);
+        out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(h[k] >> 8);
+        out[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
+/* ------------------------------------------------------------------ compression */
+
+/* check_point_is_in_subgroup, /root/reference/src/compression.rs:22-27: [r]P == O */
+static int g1_in_subgroup(const g1_t *p) {
+    g1_t t;
+    g1_mul_raw(&t, p, fr_MOD, 4);
+    return g1_is_neutral(&t);
+}
+
+/* compress_g1_point, /root/reference/src/compression.rs:33-60 */
+static void g1_compress(uint8_t out[48], const g1_t *p) {
+    if (g1_is_neutral(p)) {
+        memset(out, 0, 48);
+        out[0] |= 1 << 7;
+        out[0] |= 1 << 6;
+        return;
+    }
+    fp_t x, y, yn;
+    g1_to_affine(&x, &y, p);
+    fp_to_be(out, &x);
+    out[0] |= 1 << 7;
+    fp_neg(&yn, &y);
+    uint64_t ry[6], ryn[6];
+    fp_to_raw(ry, &y);
+    fp_to_raw(ryn, &yn);
+    /* y_neg.representative() < y.representative() */
+    if (!fp_raw_geq(ryn, ry)) out[0] |= 1 << 5;
+}
+
+/* decompress_g1_point, /root/reference/src/compression.rs:62-103.
+ * Returns 0 on success. The input is not modified (the shim copies first, lib.rs:367). */
+static int g1_decompress(g1_t *o, const uint8_t in[48]) {
+    uint8_t b[48];
+    memcpy(b, in, 48);
+    uint8_t prefix = b[0] >> 5;
+    if (((prefix & 4) >> 2) != 1) return 1; /* not compressed */
+    if (((prefix & 2) >> 1) == 1) {         /* infinity; remaining bits are not inspected */
+        g1_set_neutral(o);
+        return 0;
+    }
+    uint8_t third = prefix & 1;
+    b[0] = (uint8_t)((uint8_t)(b[0] << 3) >> 3);
+    fp_t x, y2, four, y, yn;
+    fp_from_be(&x, b); /* x >= p is reduced, not rejected (upstream from_bytes_be; unverified) */
+    fp_sqr(&y2, &x);
+    fp_mul(&y2, &y2, &x);
+    fp_set_u64(&four, 4);
+    fp_add(&y2, &y2, &four);
+    /* sqrt: p = 3 mod 4 -> y = y2^((p+1)/4), check */
+    static const uint64_t E[6] = {0xee7fbfffffffeaabull, 0x07aaffffac54ffffull, 0xd9cc34a83dac3d89ull,
+                                  0xd91dd2e13ce144afull, 0x92c6e9ed90d2eb35ull, 0x0680447a8e5ff9a6ull};
+    fp_pow(&y, &y2, E, 6);
+    fp_t chk;
+    fp_sqr(&chk, &y);
+    if (!fp_eq(&chk, &y2)) return 1;
+    fp_neg(&yn, &y);
+    /* select_sqrt_value_from_third_bit: the greater root iff the bit is 1 */
+    uint64_t ry[6], ryn[6];
+    fp_to_raw(ry, &y);
+    fp_to_raw(ryn, &yn);
+    int y_is_greater = fp_raw_geq(ry, ryn); /* equal only when y = 0, impossible on this curve */
+    fp_t ysel = (third == 1) ? (y_is_greater ? y : yn) : (y_is_greater ? yn : y);
+    g1_from_affine(o, &x, &ysel);
+    if (!g1_in_subgroup(o)) return 1;
+    return 0;
+}
+
+EXPORT int orc_g1_decompress_affine(uint8_t xy_be[96], int *is_inf, const uint8_t in[48]) {
+    g1_t p;
+    if (g1_decompress(&p, in)) return RET_ERROR;
+    *is_inf = g1_is_neutral(&p);
+    memset(xy_be, 0, 96);
+    if (!*is_inf) {
+        fp_t x, y;
+        g1_to_affine(&x, &y, &p);
+        fp_to_be(xy_be, &x);
+        fp_to_be(xy_be + 48, &y);
+    }
+    return RET_OK;
+}
+
+static int g1_from_affine_be(g1_t *o, const uint8_t xy_be[96]) {
+    fp_t x, y;
+    fp_from_be(&x, xy_be);
+    fp_from_be(&y, xy_be + 48);
+    if (!g1_on_curve_affine(&x, &y)) return 1;
+    g1_from_affine(o, &x, &y);
+    return 0;
+}
+
+EXPORT int orc_g1_compress_affine(uint8_t out[48], const uint8_t xy_be[96], int is_inf) {
+    g1_t p;
+    if (is_inf) {
+        g1_set_neutral(&p);
+    } else if (g1_from_affine_be(&p, xy_be)) {
+        return RET_ERROR;
+    }
+    g1_compress(out, &p);
+    return RET_OK;
+}
+
+/* ------------------------------------------------------------------ trusted setup */
+
+typedef struct {
+    int n1, n2;
+    g1_t *g1;          /* n1 monomial points [tau^i]G */
+    uint8_t *g1_comp;  /* n1 * 48 compressed bytes as read */
+    uint8_t *g2_comp;  /* n2 * 96 compressed bytes as read (G2 is out of the hot path) */
+} orc_settings;
+
+static int hexval(int c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+
+/* hex::decode_to_slice on one line: exact length required */
+static int hex_line(uint8_t *out, size_t nbytes, const char *s, size_t len) {
+    if (len != 2 * nbytes) return 1;
+    for (size_t i = 0; i < nbytes; i++) {
+        int h = hexval(s[2 * i]), l = hexval(s[2 * i + 1]);
+        if (h < 0 || l < 0) return 1;
+        out[i] = (uint8_t)(h * 16 + l);
+    }
+    return 0;
+}
+
+EXPORT void orc_free_settings(orc_settings *s) {
+    if (!s) return;
+    free(s->g1);
+    free(s->g1_comp);
+    free(s->g2_comp);
+    free(s);
+}
+
+/* load_trusted_setup_file_to_g1_points_and_g2_points, /root/reference/src/srs.rs:25-82:
+ * strictly line based (str::lines: '\n' or "\r\n"), line 1 = n1, line 2 = n2, then one
+ * hex point per line; each G1 line is decompressed and subgroup-checked (srs.rs:62).
+ * `check_subgroup` = 0 skips the 4096 [r]P checks (test speed knob only). */
+EXPORT int orc_load_trusted_setup_text(orc_settings **out, const char *text, size_t len, int check_subgroup) {
+    orc_settings *s = calloc(1, sizeof *s);
+    if (!s) return RET_MALLOC;
+    size_t pos = 0;
+    long hdr[2] = {-1, -1};
+    int lineno = 0;
+    int rc = RET_ERROR;
+    while (pos <= len) {
+        if (pos == len) break;
+        size_t e = pos;
+        while (e < len && text[e] != '\n') e++;
+        size_t ll = e - pos;
+        if (ll > 0 && text[pos + ll - 1] == '\r') ll--;
+        const char *line = text + pos;
+        if (lineno < 2) {
+            /* usize::from_str: decimal digits only (an optional leading '+' is accepted by Rust) */
+            size_t k = 0;
+            long v = 0;
+            if (ll > 0 && line[0] == '+') k = 1;
+            if (k == ll) goto fail;
+            for (; k < ll; k++) {
+                if (line[k] < '0' || line[k] > '9') goto fail;
+                v = v * 10 + (line[k] - '0');
+                if (v > (1 << 24)) goto fail;
+            }
+            hdr[lineno] = v;
+            if (lineno == 1) {
+                s->n1 = (int)hdr[0];
+                s->n2 = (int)hdr[1];
+                s->g1 = calloc((size_t)s->n1 + 1, sizeof(g1_t));
+                s->g1_comp = calloc((size_t)s->n1 + 1, 48);
+                s->g2_comp = calloc((size_t)s->n2 + 1, 96);
+                if (!s->g1 || !s->g1_comp || !s->g2_comp) { rc = RET_MALLOC; goto fail; }
+            }
+        } else {
+            int idx = lineno - 2;
+            if (idx < s->n1) {
+                uint8_t *b = s->g1_comp + 48 * (size_t)idx;
+                if (hex_line(b, 48, line, ll)) goto fail;
+                if (check_subgroup) {
+                    if (g1_decompress(&s->g1[idx], b)) goto fail;
+                } else {
+                    /* same as g1_decompress minus the [r]P check */
+                    uint8_t prefix = b[0] >> 5;
+                    if (!(prefix & 4)) goto fail;
+                    if (prefix & 2) {
+                        g1_set_neutral(&s->g1[idx]);
+                    } else {
+                        uint8_t t[48];
+                        memcpy(t, b, 48);
+                        t[0] &= 0x1f;
+                        fp_t x, y2, four, y, yn, chk;
+                        fp_from_be(&x, t);
+                        fp_sqr(&y2, &x);
+                        fp_mul(&y2, &y2, &x);
+                        fp_set_u64(&four, 4);
+                        fp_add(&y2, &y2, &four);
+                        static const uint64_t E[6] = {0xee7fbfffffffeaabull, 0x07aaffffac54ffffull, 0xd9cc34a83dac3d89ull,
+                                                      0xd91dd2e13ce144afull, 0x92c6e9ed90d2eb35ull, 0x0680447a8e5ff9a6ull};
+                        fp_pow(&y, &y2, E, 6);
+                        fp_sqr(&chk, &y);
+                        if (!fp_eq(&chk, &y2)) goto fail;
+                        fp_neg(&yn, &y);
+                        uint64_t ry[6], ryn[6];
+                        fp_to_raw(ry, &y);
+                        fp_to_raw(ryn, &yn);
+                        int yg = fp_raw_geq(ry, ryn);
+                        fp_t ys = (prefix & 1) ? (yg ? y : yn) : (yg ? yn : y);
+                        g1_from_affine(&s->g1[idx], &x, &ys);
+                    }
+                }
+            } else if (idx < s->n1 + s->n2) {
+                if (hex_line(s->g2_comp + 96 * (size_t)(idx - s->n1), 96, line, ll)) goto fail;
+            } else {
+                break;
+            }
+        }
+        lineno++;
+        pos = e + 1;
+    }
+    if (hdr[1] < 0) goto fail;
+    /* fewer point lines than announced: the reference returns shorter Vecs and later reads
+     * 4096 entries regardless (UB); the oracle reports an error. */
+    if (lineno - 2 < s->n1 + s->n2) goto fail;
+    *out = s;
+    return RET_OK;
+fail:
+    orc_free_settings(s);
+    return rc;
+}
+
+EXPORT int orc_settings_n1(const orc_settings *s) { return s->n1; }
+EXPORT int orc_settings_n2(const orc_settings *s) { return s->n2; }
+EXPORT const uint8_t *orc_settings_g1_compressed(const orc_settings *s) { return s->g1_comp; }
+EXPORT const uint8_t *orc_settings_g2_compressed(const orc_settings *s) { return s->g2_comp; }
+
+/* g1_point_to_blst_p1, /root/reference/src/srs.rs:131-153: canonical (non-Montgomery)
+ * integers, limbs most-significant first, z = 1 for affine input; neutral = (0,0,[0..0,1]).
+ * Writes n1 * 18 u64 (x[6], y[6], z[6]) -- the exact bytes of the reference's blst_p1[]. */
+EXPORT void orc_settings_g1_blst(const orc_settings *s, uint64_t *out) {
+    for (int i = 0; i < s->n1; i++) {
+        uint64_t *o = out + 18 * (size_t)i;
+        memset(o, 0, 18 * 8);
+        if (g1_is_neutral(&s->g1[i])) {
+            o[17] = 1;
+            continue;
+        }
+        uint64_t rx[6], ry[6], rz[6];
+        fp_to_raw(rx, &s->g1[i].x);
+        fp_to_raw(ry, &s->g1[i].y);
+        fp_to_raw(rz, &s->g1[i].z);
+        for (int k = 0; k < 6; k++) {
+            o[k] = rx[5 - k];
+            o[6 + k] = ry[5 - k];
+            o[12 + k] = rz[5 - k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ MSM */
+
+/* lambdaworks_math::msm::pippenger::msm (un-vendored; call sites
+ * /root/reference/src/lib.rs:28,242 and inside KZG::commit, lib.rs:270). Restated from
+ * window w = ilog2(n)*4/5 clamped to [2,32]; num_windows =
+ * (256-1)/w + 1; 2^w - 1 buckets reused; digit = (k >> (i*w)) & (2^w-1), zero digits
+ * skipped; per-window descending running-sum reduction; windows folded MSB->LSB with
+ * 2^w doublings.  scalars: raw canonical little-endian limbs, 4 per scalar. */
+static int ilog2_u(unsigned n) {
+    int l = 0;
+    while (n >>= 1) l++;
+    return l;
+}
+
+static void msm_pippenger(g1_t *out, const uint64_t *scalars, const g1_t *points, int n) {
+    if (n == 0) {
+        g1_set_neutral(out);
+        return;
+    }
+    int w = n >= 2 ? ilog2_u((unsigned)n) * 4 / 5 : 2;
+    if (w < 2) w = 2;
+    if (w > 32) w = 32;
+    int nwin = (256 - 1) / w + 1;
+    size_t nb = ((size_t)1 << w) - 1;
+    g1_t *buckets = malloc(nb * sizeof(g1_t));
+    g1_t acc;
+    g1_set_neutral(&acc);
+    for (int wi = nwin - 1; wi >= 0; wi--) {
+        for (int d = 0; d < w; d++) g1_double(&acc, &acc);
+        for (size_t b = 0; b < nb; b++) g1_set_neutral(&buckets[b]);
+        int bit = wi * w;
+        for (int i = 0; i < n; i++) {
+            const uint64_t *k = scalars + 4 * (size_t)i;
+            int limb = bit / 64, sh = bit % 64;
+            uint64_t v = k[limb] >> sh;
+            if (sh + w > 64 && limb + 1 < 4) v |= k[limb + 1] << (64 - sh);
+            uint64_t digit = v & (((uint64_t)1 << w) - 1);
+            if (digit) g1_add(&buckets[digit - 1], &buckets[digit - 1], &points[i]);
+        }
+        g1_t run, sum;
+        g1_set_neutral(&run);
+        g1_set_neutral(&sum);
+        for (size_t b = nb; b-- > 0;) {
+            g1_add(&run, &run, &buckets[b]);
+            g1_add(&sum, &sum, &run);
+        }
+        g1_add(&acc, &acc, &sum);
+    }
+    free(buckets);
+    *out = acc;
+}
+
+/* naive double-and-add MSM: independent of the bucket code, used to pin msm_pippenger */
+static void msm_naive(g1_t *out, const uint64_t *scalars, const g1_t *points, int n) {
+    g1_t acc, t;
+    g1_set_neutral(&acc);
+    for (int i = 0; i < n; i++) {
+        g1_mul_raw(&t, &points[i], scalars + 4 * (size_t)i, 4);
+        g1_add(&acc, &acc, &t);
+    }
+    *out = acc;
+}
+
+/* generic-points MSM for kernel tests: affine big-endian points (96 B each, must be on
+ * the curve, no infinity), big-endian 32-byte scalars reduced mod r. algo 0 = pippenger,
+ * 1 = naive. Output: compressed 48 bytes. */
+EXPORT int orc_msm_affine(uint8_t out[48], const uint8_t *points_xy_be, const uint8_t *scalars_be, int n, int algo) {
+    g1_t *pts = malloc(((size_t)n + 1) * sizeof(g1_t));
+    uint64_t *sc = malloc(((size_t)n + 1) * 32);
+    if (!pts || !sc) { free(pts); free(sc); return RET_MALLOC; }
+    for (int i = 0; i < n; i++) {
+        if (g1_from_affine_be(&pts[i], points_xy_be + 96 * (size_t)i)) { free(pts); free(sc); return RET_ERROR; }
+        fr_t f;
+        fr_from_be(&f, scalars_be + 32 * (size_t)i);
+        fr_to_raw(sc + 4 * (size_t)i, &f);
+    }
+    g1_t r;
+    if (algo == 0) msm_pippenger(&r, sc, pts, n); else msm_naive(&r, sc, pts, n);
+    g1_compress(out, &r);
+    free(pts);
+    free(sc);
+    return RET_OK;
+}
+
+/* [k]G compressed, k big-endian 32 bytes (reduced mod r): the tau closed-form helper */
+EXPORT void orc_g1_generator_mul(uint8_t out[48], const uint8_t k_be[32]) {
+    fr_t f;
+    uint64_t raw[4];
+    fr_from_be(&f, k_be);
+    fr_to_raw(raw, &f);
+    g1_t g, r;
+    g1_generator(&g);
+    g1_mul_raw(&r, &g, raw, 4);
+    g1_compress(out, &r);
+}
+
+/* ------------------------------------------------------------------ Fr helpers / NTT */
+
+static void fr_from_le(fr_t *o, const uint8_t *b) {
+    uint8_t be[32];
+    for (int i = 0; i < 32; i++) be[i] = b[31 - i];
+    fr_from_be(o, be);
+}
+static void fr_to_le(uint8_t *b, const fr_t *a) {
+    uint8_t be[32];
+    fr_to_be(be, a);
+    for (int i = 0; i < 32; i++) b[i] = be[31 - i];
+}
+static int fr_bytes_canonical(const uint8_t *b, int little_endian) {
+    uint8_t be[32];
+    uint64_t raw[4];
+    for (int i = 0; i < 32; i++) be[i] = little_endian ? b[31 - i] : b[i];
+    fr_raw_from_be(raw, be);
+    return !fr_raw_geq(raw, fr_MOD);
+}
+
+static unsigned bitrev12(unsigned i) {
+    unsigned r = 0;
+    for (int k = 0; k < 12; k++) r |= ((i >> k) & 1) << (11 - k);
+    return r;
+}
+
+/* omega_4096 = 7^((r-1)/4096); canonical raw limbs */
+static const uint64_t OMEGA_4096[4] = {0xe206da11a5d36306ull, 0x0ad1347b378fbf96ull, 0xfc3e8acfe0f8245full,
+                                       0x564c0a11a0f704f4ull};
+
+/* In-place radix-2 decimation-in-time NTT over Fr, n = 4096, natural order in/out.
+ * (a15: absent from the reference, required by the north star and by mode C.)
+ * inverse != 0: uses omega^-1 and scales by 4096^-1. */
+static void fr_ntt4096(fr_t *a, int inverse) {
+    const int n = N_BLOB;
+    fr_t w;
+    fr_from_raw(&w, OMEGA_4096);
+    if (inverse) fr_inv(&w, &w);
+    for (unsigned i = 0; i < (unsigned)n; i++) {
+        unsigned j = bitrev12(i);
+        if (i < j) { fr_t t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    static fr_t tw[N_BLOB / 2];
+    fr_set_one(&tw[0]);
+    for (int i = 1; i < n / 2; i++) fr_mul(&tw[i], &tw[i - 1], &w);
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len / 2, step = n / len;
+        for (int s = 0; s < n; s += len)
+            for (int k = 0; k < half; k++) {
+                fr_t u = a[s + k], v;
+                fr_mul(&v, &a[s + k + half], &tw[k * step]);
+                fr_add(&a[s + k], &u, &v);
+                fr_sub(&a[s + k + half], &u, &v);
+            }
+    }
+    if (inverse) {
+        fr_t ninv;
+        fr_set_u64(&ninv, (uint64_t)n);
+        fr_inv(&ninv, &ninv);
+        for (int i = 0; i < n; i++) fr_mul(&a[i], &a[i], &ninv);
+    }
+}
+
+/* test hook: 4096 big-endian Fr in, out = NTT / INTT (natural order both sides) */
+EXPORT void orc_fr_ntt4096(uint8_t *out_be, const uint8_t *in_be, int inverse) {
+    static fr_t a[N_BLOB];
+    for (int i = 0; i < N_BLOB; i++) fr_from_be(&a[i], in_be + 32 * i);
+    fr_ntt4096(a, inverse);
+    for (int i = 0; i < N_BLOB; i++) fr_to_be(out_be + 32 * i, &a[i]);
+}
+
+/* ------------------------------------------------------------------ blob -> polynomial */
+
+/* mode R: blob_to_polynomial, /root/reference/src/utils.rs:27-41 -- 4096 x from_bytes_be
+ *         (values >= r reduced, upstream behaviour unverified), monomial coefficients.
+ * mode C: c-kzg-4844 blob_to_polynomial -- LE, each element must be canonical else BADARGS;
+ *         blob[i] = p(omega^bitrev(i)); coefficients = INTT(bit-reversal(blob)).
+ * Returns coefficients in coef[0..4096). */
+static int blob_to_coefficients(fr_t *coef, const uint8_t *blob, int mode) {
+    if (mode == 0) {
+        for (int i = 0; i < N_BLOB; i++) fr_from_be(&coef[i], blob + 32 * i);
+        return RET_OK;
+    }
+    for (int i = 0; i < N_BLOB; i++)
+        if (!fr_bytes_canonical(blob + 32 * i, 1)) return RET_BADARGS;
+    for (unsigned i = 0; i < N_BLOB; i++) fr_from_le(&coef[bitrev12(i)], blob + 32 * i);
+    fr_ntt4096(coef, 1);
+    return RET_OK;
+}
+
+/* Polynomial::new trims trailing zero coefficients */
+static int poly_len(const fr_t *coef) {
+    int n = N_BLOB;
+    while (n > 0 && fr_is_zero(&coef[n - 1])) n--;
+    return n;
+}
+
+/* KZG::commit(p) = msm(p.coefficients.map(representative), srs.powers_main_group[..len])
+ * (un-vendored lambdaworks-crypto; call site /root/reference/src/lib.rs:270) */
+static int commit_coefficients(g1_t *out, const fr_t *coef, int len, const orc_settings *s, int algo) {
+    if (s->n1 < len) return RET_ERROR;
+    uint64_t *sc = malloc(((size_t)len + 1) * 32);
+    if (!sc) return RET_MALLOC;
+    for (int i = 0; i < len; i++) fr_to_raw(sc + 4 * (size_t)i, &coef[i]);
+    if (algo == 0) msm_pippenger(out, sc, s->g1, len); else msm_naive(out, sc, s->g1, len);
+    free(sc);
+    return RET_OK;
+}
+
+/* Polynomial::evaluate: Horner from the top coefficient (call sites lib.rs:320,389) */
+static void poly_eval(fr_t *y, const fr_t *coef, int len, const fr_t *z) {
+    fr_t acc;
+    fr_set_zero(&acc);
+    for (int i = len - 1; i >= 0; i--) {
+        fr_mul(&acc, &acc, z);
+        fr_add(&acc, &acc, &coef[i]);
+    }
+    *y = acc;
+}
+
+/* KZG::open(z, y, p) = commit((p - y).ruffini_division(z)) (call sites lib.rs:329,394).
+ * q has len-1 coefficients: q[len-2] = c[len-1]; q[i-1] = c[i] + z q[i]. */
+static int open_coefficients(g1_t *proof, const fr_t *coef, int len, const fr_t *z, const fr_t *y,
+                             const orc_settings *s, int algo) {
+    static fr_t q[N_BLOB];
+    (void)y; /* the remainder of (p - y)/(x - z) is p(z) - y = 0; y only shifts c[0], which Ruffini discards */
+    int qlen = len > 0 ? len - 1 : 0;
+    if (qlen > 0) {
+        q[qlen - 1] = coef[len - 1];
+        for (int i = len - 2; i >= 1; i--) {
+            fr_t t;
+            fr_mul(&t, &q[i], z);
+            fr_add(&q[i - 1], &coef[i], &t);
+        }
+    }
+    int ql = qlen;
+    while (ql > 0 && fr_is_zero(&q[ql - 1])) ql--;
+    return commit_coefficients(proof, q, ql, s, algo);
+}
+
+/* ------------------------------------------------------------------ the C-ABI functions, restated */
+
+/* blob_to_kzg_commitment, /root/reference/src/lib.rs:253-283 */
+EXPORT int orc_blob_to_kzg_commitment(uint8_t out[48], const uint8_t *blob, const orc_settings *s, int mode, int algo) {
+    static fr_t coef[N_BLOB];
+    int rc = blob_to_coefficients(coef, blob, mode);
+    if (rc) return rc;
+    g1_t c;
+    rc = commit_coefficients(&c, coef, poly_len(coef), s, algo);
+    if (rc) return rc;
+    g1_compress(out, &c);
+    return RET_OK;
+}
+
+/* compute_kzg_proof, /root/reference/src/lib.rs:300-344. z, y big-endian in mode R
+ * (lib.rs:316,321), little-endian + canonical-z check in mode C. */
+EXPORT int orc_compute_kzg_proof(uint8_t proof_out[48], uint8_t y_out[32], const uint8_t *blob, const uint8_t z_bytes[32],
+                                 const orc_settings *s, int mode, int algo) {
+    static fr_t coef[N_BLOB];
+    int rc = blob_to_coefficients(coef, blob, mode);
+    if (rc) return rc;
+    fr_t z, y;
+    if (mode == 0) {
+        fr_from_be(&z, z_bytes);
+    } else {
+        if (!fr_bytes_canonical(z_bytes, 1)) return RET_BADARGS;
+        fr_from_le(&z, z_bytes);
+    }
+    int len = poly_len(coef);
+    poly_eval(&y, coef, len, &z);
+    g1_t pr;
+    rc = open_coefficients(&pr, coef, len, &z, &y, s, algo);
+    if (rc) return rc;
+    g1_compress(proof_out, &pr);
+    if (mode == 0) fr_to_be(y_out, &y); else fr_to_le(y_out, &y);
+    return RET_OK;
+}
+
+/* compute_challenge, /root/reference/src/utils.rs:120-144 + hash_field_unsafe :148-154.
+ * input = "FSBLOBVERIFY_V1_" | usize(4096) LE (8) | u64(0) LE (8) | blob | compress(C);
+ * digest read big-endian in mode R (utils.rs:153), little-endian in mode C; reduced mod r. */
+static void compute_challenge(fr_t *z, const uint8_t *blob, const uint8_t comm48[48], int mode) {
+    static uint8_t buf[16 + 16 + N_BLOB * 32 + 48];
+    memcpy(buf, "FSBLOBVERIFY_V1_", 16);
+    memset(buf + 16, 0, 16);
+    buf[16] = 0x00;
+    buf[17] = 0x10; /* 4096 little-endian */
+    memcpy(buf + 32, blob, N_BLOB * 32);
+    memcpy(buf + 32 + N_BLOB * 32, comm48, 48);
+    uint8_t dg[32];
+    orc_sha256(dg, buf, sizeof buf);
+    if (mode == 0) fr_from_be(z, dg); else fr_from_le(z, dg);
+}
+
+EXPORT int orc_compute_challenge(uint8_t z_out[32], const uint8_t *blob, const uint8_t comm48[48], int mode) {
+    g1_t c;
+    if (g1_decompress(&c, comm48)) return mode == 0 ? RET_ERROR : RET_BADARGS;
+    uint8_t cc[48];
+    g1_compress(cc, &c);
+    fr_t z;
+    compute_challenge(&z, blob, cc, mode);
+    if (mode == 0) fr_to_be(z_out, &z); else fr_to_le(z_out, &z);
+    return RET_OK;
+}
+
+/* compute_blob_kzg_proof, /root/reference/src/lib.rs:361-404: decompress the commitment
+ * first (fail fast, :372-375), then parse, challenge, evaluate, open, compress. */
+EXPORT int orc_compute_blob_kzg_proof(uint8_t out[48], const uint8_t *blob, const uint8_t comm48[48],
+                                      const orc_settings *s, int mode, int algo) {
+    static fr_t coef[N_BLOB];
+    g1_t c;
+    if (mode == 0) {
+        if (g1_decompress(&c, comm48)) return RET_ERROR;
+        int rc = blob_to_coefficients(coef, blob, mode);
+        if (rc) return rc;
+    } else {
+        /* c-kzg order: blob first, then commitment; both BADARGS */
+        int rc = blob_to_coefficients(coef, blob, mode);
+        if (rc) return rc;
+        if (g1_decompress(&c, comm48)) return RET_BADARGS;
+    }
+    uint8_t cc[48];
+    g1_compress(cc, &c); /* utils.rs:138 re-compresses the decompressed point */
+    fr_t z, y;
+    compute_challenge(&z, blob, cc, mode);
+    int len = poly_len(coef);
+    poly_eval(&y, coef, len, &z);
+    g1_t pr;
+    int rc = open_coefficients(&pr, coef, len, &z, &y, s, algo);
+    if (rc) return rc;
+    g1_compress(out, &pr);
+    return RET_OK;
+}
+
+/* ------------------------------------------------------------------ verify side, closed form */
+
+/* verify_kzg_proof (/root/reference/src/lib.rs:407-453) decides
+ *     e(C - [y]G, G2) == e(pi, [tau]G2 - [z]G2).
+ * The oracle does NOT implement a pairing. For a setup whose secret is known
+ * (tests/trusted_setup.txt: tau = 1337) and subgroup points, that equation
+ * holds iff  C - [y]G == [tau - z] pi  in G1, which is what this function checks.
+ * Valid ONLY for such a setup; the caller passes tau. */
+EXPORT int orc_verify_kzg_proof_known_tau(int *ok, const uint8_t comm48[48], const uint8_t z_bytes[32],
+                                          const uint8_t y_bytes[32], const uint8_t proof48[48], uint64_t tau, int mode) {
+    *ok = 0;
+    g1_t c, pi, g, t, lhs, rhs;
+    int bad = mode == 0 ? RET_ERROR : RET_BADARGS;
+    if (g1_decompress(&c, comm48)) return bad;
+    fr_t z, y, tf, d;
+    if (mode == 0) {
+        fr_from_be(&z, z_bytes);
+        fr_from_be(&y, y_bytes);
+    } else {
+        if (!fr_bytes_canonical(z_bytes, 1) || !fr_bytes_canonical(y_bytes, 1)) return RET_BADARGS;
+        fr_from_le(&z, z_bytes);
+        fr_from_le(&y, y_bytes);
+    }
+    if (g1_decompress(&pi, proof48)) return bad;
+    uint64_t raw[4];
+    g1_generator(&g);
+    fr_to_raw(raw, &y);
+    g1_mul_raw(&t, &g, raw, 4);
+    g1_neg(&t, &t);
+    g1_add(&lhs, &c, &t);
+    fr_set_u64(&tf, tau);
+    fr_sub(&d, &tf, &z);
+    fr_to_raw(raw, &d);
+    g1_mul_raw(&rhs, &pi, raw, 4);
+    *ok = g1_eq(&lhs, &rhs);
+    return RET_OK;
+}
+
+/* ------------------------------------------------------------------ primitive hooks for kernel-level parity tests */
+
+EXPORT void orc_fp_mul_be(uint8_t out[48], const uint8_t a[48], const uint8_t b[48]) {
+    fp_t x, y;
+    fp_from_be(&x, a);
+    fp_from_be(&y, b);
+    fp_mul(&x, &x, &y);
+    fp_to_be(out, &x);
+}
+EXPORT void orc_fp_inv_be(uint8_t out[48], const uint8_t a[48]) {
+    fp_t x;
+    fp_from_be(&x, a);
+    fp_inv(&x, &x);
+    fp_to_be(out, &x);
+}
+EXPORT void orc_fr_mul_be(uint8_t out[32], const uint8_t a[32], const uint8_t b[32]) {
+    fr_t x, y;
+    fr_from_be(&x, a);
+    fr_from_be(&y, b);
+    fr_mul(&x, &x, &y);
+    fr_to_be(out, &x);
+}
+/* affine + affine (either may be infinity: flag) -> affine; exercises every branch of g1_add */
+EXPORT int orc_g1_add_affine(uint8_t out_xy[96], int *out_inf, const uint8_t a_xy[96], int a_inf, const uint8_t b_xy[96], int b_inf) {
+    g1_t a, b, r;
+    if (a_inf) g1_set_neutral(&a); else if (g1_from_affine_be(&a, a_xy)) return RET_ERROR;
+    if (b_inf) g1_set_neutral(&b); else if (g1_from_affine_be(&b, b_xy)) return RET_ERROR;
+    g1_add(&r, &a, &b);
+    *out_inf = g1_is_neutral(&r);
+    memset(out_xy, 0, 96);
+    if (!*out_inf) {
+        fp_t x, y;
+        g1_to_affine(&x, &y, &r);
+        fp_to_be(out_xy, &x);
+        fp_to_be(out_xy + 48, &y);
+    }
+    return RET_OK;
+}
+/* [k]P for affine P, k big-endian 32 bytes (NOT reduced: raw 256-bit integer) -> affine */
+EXPORT int orc_g1_mul_affine(uint8_t out_xy[96], int *out_inf, const uint8_t p_xy[96], const uint8_t k_be[32]) {
+    g1_t p, r;
+    if (g1_from_affine_be(&p, p_xy)) return RET_ERROR;
+    uint64_t raw[4];
+    fr_raw_from_be(raw, k_be);
+    g1_mul_raw(&r, &p, raw, 4);
+    *out_inf = g1_is_neutral(&r);
+    memset(out_xy, 0, 96);
+    if (!*out_inf) {
+        fp_t x, y;
+        g1_to_affine(&x, &y, &r);
+        fp_to_be(out_xy, &x);
+        fp_to_be(out_xy + 48, &y);
+    }
+    return RET_OK;
+}
