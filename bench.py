@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- blob_to_kzg_commitment throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (blob bytes -> 48-byte commitments: parse, digit sort, bucket
+accumulate, bucket reduce, compress) over one batch of synthetic 4096-element blobs that is already
+resident in HBM. Each GPU works on its own shard (weak scaling: 1024 blobs per GPU per step); the only
+collective is the one broadcast of the prepared trusted setup before the timed region.
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (k_bucket_accumulate) against HBM as
+the north star mandates AND gives the integer-multiply picture, because the kernel is integer-ALU bound
+(DESIGN.md section 5). `cpu_baseline` times the CPU oracle (a restatement of the reference's algorithm,
+NOT the reference binary, which cannot be built here) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+BLOBS_PER_GPU = 1024
+ALGO_BYTES_PER_MSM = 131072 + 393216 + 48   # scalars + affine points + output = 524,336 B
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
+
+
+def _cpu_worker(args):
+    lib_path, first, count = args
+    from oracle import oracle as O
+    l = O.lib(lib_path)
+    s = O.Settings.from_file(SETUP, check_subgroup=False, _lib=l)
+    import blobs as B
+    data = [B.synthetic_blob(first + i) for i in range(count)]
+    t0 = time.perf_counter()
+    outs = []
+    for b in data:
+        rc, cm = O.blob_to_kzg_commitment(b, s, O.MODE_R)
+        assert rc == 0
+        outs.append(cm)
+    return time.perf_counter() - t0, outs
+
+
+def cpu_baseline(gpu_outputs):
+    """Time the oracle on the host: all cores, one blob stream per process. Bounded sample."""
+    import multiprocessing as mp
+    import tempfile
+    from oracle import oracle as O
+    try:
+        lib_path = O.build(native=True, out_dir=tempfile.mkdtemp(prefix="lwkzg_oracle_"))
+    except Exception:
+        lib_path = os.path.join(ROOT, "oracle", "liboracle_kzg.so")
+        if not os.path.exists(lib_path):
+            lib_path = O.build()
+    cores = len(os.sched_getaffinity(0))
+    # one thread first: calibrates the per-blob cost and is itself the reference's configuration
+    t1, o1 = _cpu_worker((lib_path, 0, 4))
+    per_blob = t1 / 4
+    per_proc = max(2, min(64, int(12.0 / per_blob)))    # about 12 s of work per core
+    per_proc = min(per_proc, max(2, BLOBS_PER_GPU // cores))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(lib_path, i * per_proc, per_proc) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    total = cores * per_proc
+    busy = max(r[0] for r in res)
+    verified = True
+    flat = [o for r in res for o in r[1]]
+    for i, cm in enumerate(flat[:len(gpu_outputs)]):
+        if gpu_outputs[i] != cm:
+            verified = False
+    return {
+        "value": total / busy,
+        "unit": "blob_to_kzg_commitment ops/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d synthetic blobs (%d per core x %d cores, one process per core), %.1f s busy, %.1f s wall incl. "
+                  "process start; single-thread rate %.2f ops/s; CPU restatement of lambdaworks_kzg's algorithm "
+                  "(Pippenger w=9, 29 windows, projective adds), SRS rebuild per call NOT included"
+                  % (total, per_proc, cores, busy, wall, 1.0 / per_blob),
+        "single_thread_ops_per_s": 1.0 / per_blob,
+        "gpu_outputs_match_oracle": verified,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BLOBS_PER_GPU, help="blobs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof"])
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import blobs as B
+    import lambdaworks_kzg_amd as K
+    from lambdaworks_kzg_amd import capi
+    from lambdaworks_kzg_amd import dist as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    K.set_device(local_rank)
+    K.set_mode(K.MODE_REFERENCE)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # trusted setup: rank 0 parses + validates + builds the fixed-base table, one RCCL broadcast delivers it
+    t_load0 = time.perf_counter()
+    ts = K.TrustedSetup.from_file(SETUP) if rank == 0 else None
+    if world > 1:
+        ts = D.broadcast_trusted_setup(ts, dev, src=0)
+    t_load = time.perf_counter() - t_load0
+
+    n = args.batch
+    first = rank * n                       # shard: blob k of the job lives on GPU floor(k / n)
+    host = np.frombuffer(B.synthetic_batch(first, n), dtype=np.uint8)
+    d_blobs = torch.from_numpy(host.copy()).to(dev)
+    d_out = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_comm = None
+    ts.reserve(n)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        if args.op == "commit":
+            K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
+        else:
+            K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, stream,
+                                                  d_status.data_ptr())
+
+    if args.op == "blob_proof":
+        d_comm = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+        K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+
+    capi.profile_reset()
+    capi.profile_enable(True)             # hipEvent pairs around every kernel, on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    capi.profile_enable(False)
+    prof = capi.profile_report()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(d_status.abs().sum().item()) == 0, "a blob was rejected"
+
+    if rank == 0:
+        total_blobs = n * world * args.steps
+        value = total_blobs / elapsed
+        dom = "k_bucket_accumulate"
+        k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
+        avg_ms = k["total_ms"] / max(1, k["launches"])
+        msms_per_launch = n
+        achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
+        # integer picture: 8M+2S per mixed add, 288 32x32 multiply-adds per Montgomery product (12-limb CIOS)
+        nwin, entries = K.lib().lwkzg_msm_num_windows(), None
+        adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
+        mads_per_launch = msms_per_launch * adds_per_msm * 10 * 288
+        res = {
+            "metric": "blob_to_kzg_commitment ops/sec (4096-elem blobs)" if args.op == "commit" else "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
+            "value": value,
+            "unit": "ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery, integer)",
+            "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
+            "config": {"workload": "BASELINE configs[1]: single-GPU G1 Pippenger MSM, 4096 scalars, batch=%d synthetic blobs "
+                                   "per GPU per step, device-resident, bit-exact vs CPU" % n,
+                       "blobs_per_gpu_per_step": n, "mode": "reference (big-endian monomial)", "op": args.op,
+                       "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": msms_per_launch * ALGO_BYTES_PER_MSM,
+                         "avg_launch_ms": avg_ms,
+                         "note": "integer-ALU bound, not HBM bound (about 600 int-ops per algorithmic byte): see int_mad",
+                         "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
+                                     "achieved_Gmad_per_s": mads_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}},
+            "kernels": kernels,
+            "setup_load_s": t_load,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
+            res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)])
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ts.free() if ts is not None else None
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+/*
+ * lambdaworks_kzg_amd.h -- C ABI of the MI355X-native KZG / EIP-4844 blob-commitment engine.
+ *
+ * Drop-in boundary for lambdaclass/lambdaworks_kzg's hot path. The first nine functions are
+ * exactly the reference's `#[no_mangle] extern "C"` symbols (the c-kzg-4844 surface); a
+ * maintainer links this library instead of liblambdaworks_kzg and keeps calling them.
+ * Header of record on the reference side: src/c_kzg_4844.h:85-231 (NOT the stale
+ * src/lambdaworks_kzg.h). Each declaration cites the Rust definition it replaces.
+ *
+ * Everything after "extensions" is additive: batched and device-resident entry points (a
+ * synchronous one-blob call cannot reach 10k ops/s), the R/C semantics switch, multi-GPU setup
+ * hand-off, and profiling hooks used by bench.py.
+ *
+ * Struct layouts follow the reference's #[repr(C)] types (src/lib.rs:45-232). NOTE the
+ * reference's blst_fp convention, which this library reproduces bit for bit and which is NOT
+ * blst's: limbs hold the canonical (non-Montgomery) integer, most-significant limb first
+ * (src/srs.rs:131-172; the reference's own test compares these structs, tests/lib_test.rs:153-163).
+ */
+#ifndef LAMBDAWORKS_KZG_AMD_H
+#define LAMBDAWORKS_KZG_AMD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the library is built with -fvisibility=hidden; these are its only exported symbols */
+#pragma GCC visibility push(default)
+
+#ifndef FIELD_ELEMENTS_PER_BLOB
+#define FIELD_ELEMENTS_PER_BLOB 4096 /* fixed in the reference: src/lib.rs:76 */
+#endif
+#if FIELD_ELEMENTS_PER_BLOB != 4096
+#error this engine is built for FIELD_ELEMENTS_PER_BLOB = 4096 (reference src/lib.rs:76)
+#endif
+
+#define BYTES_PER_COMMITMENT 48    /* src/lib.rs:67 */
+#define BYTES_PER_PROOF 48         /* src/lib.rs:70 */
+#define BYTES_PER_FIELD_ELEMENT 32 /* src/lib.rs:73 */
+#define BYTES_PER_BLOB (FIELD_ELEMENTS_PER_BLOB * BYTES_PER_FIELD_ELEMENT) /* src/lib.rs:81 */
+#define TRUSTED_SETUP_NUM_G1_POINTS FIELD_ELEMENTS_PER_BLOB                /* src/lib.rs:78 */
+#define TRUSTED_SETUP_NUM_G2_POINTS 65                                     /* src/lib.rs:92 */
+
+/* ---- blst-shaped types (src/lib.rs:100-166). Guarded so a real blst.h may come first. ---- */
+#ifndef LWKZG_HAVE_BLST_TYPES
+#ifndef __BLST_H__
+typedef uint64_t limb_t;
+typedef struct { limb_t l[256 / 8 / sizeof(limb_t)]; } blst_fr;
+typedef struct { limb_t l[384 / 8 / sizeof(limb_t)]; } blst_fp;
+typedef struct { blst_fp fp[2]; } blst_fp2;
+typedef struct { blst_fp x, y, z; } blst_p1;
+typedef struct { blst_fp x, y; } blst_p1_affine;
+typedef struct { blst_fp2 x, y, z; } blst_p2;
+typedef struct { blst_fp2 x, y; } blst_p2_affine;
+#endif
+#endif
+
+typedef blst_p1 g1_t;
+typedef blst_p2 g2_t;
+typedef blst_fr fr_t;
+
+typedef struct { uint8_t bytes[32]; } Bytes32;             /* src/lib.rs:94 */
+typedef struct { uint8_t bytes[48]; } Bytes48;             /* src/lib.rs:95 */
+typedef struct { uint8_t bytes[BYTES_PER_BLOB]; } Blob;    /* src/lib.rs:98 */
+typedef Bytes48 KZGCommitment;                             /* src/lib.rs:96 */
+typedef Bytes48 KZGProof;                                  /* src/lib.rs:97 */
+
+typedef enum {
+    C_KZG_OK = 0,  /* success */
+    C_KZG_BADARGS, /* the supplied data is invalid in some way */
+    C_KZG_ERROR,   /* internal error; the reference maps EVERY failure to this (src/lib.rs:263,267,272,...) */
+    C_KZG_MALLOC,  /* could not allocate memory */
+} C_KZG_RET;       /* src/lib.rs:45-57 */
+
+typedef struct {
+    uint64_t max_width;
+    fr_t *expanded_roots_of_unity; /* w^i, i = 0..max_width (max_width + 1 entries) */
+    fr_t *reverse_roots_of_unity;  /* w^-i, max_width + 1 entries */
+    fr_t *roots_of_unity;          /* w^bitrev(i), max_width entries */
+} FFTSettings;                     /* src/lib.rs:173-197 */
+
+typedef struct {
+    FFTSettings *fs;  /* reference: always NULL (src/lib.rs:754-758). Here: the engine's context; its
+                         first member is a genuine FFTSettings (max_width = 4096). */
+    g1_t *g1_values;  /* 4096 monomial points [tau^i]G, reference blst_fp convention, malloc'd */
+    g2_t *g2_values;  /* 65 points [tau^i]G2, malloc'd */
+} KZGSettings;        /* src/lib.rs:206-222 */
+
+/* ============================ the reference's nine symbols ============================ */
+
+/* src/lib.rs:709-776. n1 != 4096 or n2 != 65 -> C_KZG_BADARGS (the reference's only BADARGS). */
+C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_bytes /* n1*48 */, size_t n1,
+                             const uint8_t *g2_bytes /* n2*96 */, size_t n2);
+
+/* src/lib.rs:779-802 + src/srs.rs:25-128: line-based text format, decimal n1, n2, then hex points. */
+C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in);
+
+/* src/lib.rs:821-829. (c_kzg_4844.h:186 declares void; the Rust symbol returns C_KZG_OK.) */
+C_KZG_RET free_trusted_setup(KZGSettings *s);
+
+/* src/lib.rs:253-283 */
+C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KZGSettings *s);
+
+/* src/lib.rs:300-344 */
+C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob, const Bytes32 *z_bytes,
+                            const KZGSettings *s);
+
+/* src/lib.rs:361-404 */
+C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
+                                 const KZGSettings *s);
+
+/* src/lib.rs:407-453 */
+C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes, const Bytes32 *y_bytes,
+                           const Bytes48 *proof_bytes, const KZGSettings *s);
+
+/* src/lib.rs:456-505 */
+C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commitment_bytes,
+                                const Bytes48 *proof_bytes, const KZGSettings *s);
+
+/* src/lib.rs:525-614. n == 0 -> C_KZG_OK with *ok = false (reference behaviour, src/lib.rs:538-543). */
+C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
+                                      const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s);
+
+/* ==================================== extensions ==================================== */
+
+/* Semantics switch.
+ *   LWKZG_MODE_REFERENCE (default): what lambdaworks_kzg computes -- big-endian scalars are monomial
+ *       coefficients (src/utils.rs:27-41), big-endian z/y and Fiat-Shamir digest, every failure is
+ *       C_KZG_ERROR, scalars >= r are reduced.
+ *   LWKZG_MODE_CKZG: what the c-kzg-4844 vectors under the reference's tests/ encode -- canonical
+ *       little-endian scalars are evaluations on the bit-reversed 4096th roots of unity (inverse NTT
+ *       in front of the same MSM), little-endian z/y/digest, invalid input is C_KZG_BADARGS.
+ * Process-wide; initial value from the environment variable LWKZG_MODE ("reference"|"ckzg"). */
+#define LWKZG_MODE_REFERENCE 0
+#define LWKZG_MODE_CKZG 1
+int lwkzg_set_mode(int mode); /* returns the previous mode, or -1 if `mode` is invalid */
+int lwkzg_get_mode(void);
+
+/* Batched host-pointer forms of src/lib.rs:253 / :361 / :300: n blobs in, n results out, one launch
+ * set. On failure nothing useful is in `out`; `first_bad` (may be NULL) receives the index of the
+ * first offending blob. */
+C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s,
+                                             size_t *first_bad);
+C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
+                                             const KZGSettings *s, size_t *first_bad);
+C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs,
+                                        size_t n, const KZGSettings *s, size_t *first_bad);
+
+/* Device-resident forms: every pointer is a DEVICE pointer on the settings' GPU; `stream` is a
+ * hipStream_t (NULL = the engine's own stream). Asynchronous: kernels are enqueued and the call
+ * returns; per-blob status words (0 = ok, C_KZG_RET otherwise) are written to status_dev (n x int32,
+ * may be NULL). No allocation happens here once lwkzg_reserve() has been called for >= n. */
+C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void *blobs_dev, size_t n,
+                                                    const KZGSettings *s, void *stream, int32_t *status_dev);
+C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void *blobs_dev, const void *commitments48_dev,
+                                                    size_t n, const KZGSettings *s, void *stream, int32_t *status_dev);
+C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
+
+/* General G1 multi-scalar multiplication against the first `npoints` setup points:
+ * scalars_dev = n_msm x npoints x 32 bytes (big-endian, reduced mod r), out = n_msm x 48 bytes compressed.
+ * (reference: g1_lincomb, src/lib.rs:234-243, over srs.powers_main_group.) */
+C_KZG_RET lwkzg_g1_lincomb_setup_device(void *out48_dev, const void *scalars_be_dev, size_t n_msm, const KZGSettings *s,
+                                        void *stream);
+
+/* Batched Fr transform on device-resident data: n vectors of 4096 big-endian 32-byte elements,
+ * natural order in and out; inverse != 0 scales by 4096^-1. */
+C_KZG_RET lwkzg_fr_ntt4096_device(void *out_dev, const void *in_dev, size_t n, int inverse, const KZGSettings *s,
+                                  void *stream);
+
+/* Multi-GPU hand-off of a loaded setup (one process per GPU; rank 0 loads, the others import what an
+ * RCCL broadcast delivered). The image is one contiguous DEVICE buffer. */
+size_t lwkzg_setup_image_bytes(void);
+C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void *stream);
+C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev);
+
+/* Engine introspection / profiling (bench.py). Kernel timings use hipEvents on the launch stream. */
+int lwkzg_device_count(void);
+int lwkzg_set_device(int ordinal);                 /* device used by subsequent load_* calls */
+const char *lwkzg_version(void);
+const char *lwkzg_last_error(void);                /* thread-local, human readable */
+void lwkzg_profile_enable(int on);
+void lwkzg_profile_reset(void);
+/* JSON: {"kernel": {"launches": n, "total_ms": t}, ...}; returns bytes needed (incl. NUL) */
+size_t lwkzg_profile_report(char *buf, size_t cap);
+/* MSM plan constants, for roofline arithmetic in bench.py */
+int lwkzg_msm_window_bits(void);
+int lwkzg_msm_num_windows(void);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMBDAWORKS_KZG_AMD_H */

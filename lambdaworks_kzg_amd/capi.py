@@ -1,0 +1,308 @@
+"""ctypes binding of liblambdaworks_kzg.so -- the C ABI declared in include/lambdaworks_kzg_amd.h.
+
+This is the same stub a maintainer of a Python consumer of lambdaworks_kzg / c-kzg-4844 would write
+(INTEGRATION.md shows the cgo / Rust FFI equivalents). Function names, argument order and error
+behaviour mirror the reference's extern "C" surface (/root/reference/src/lib.rs:245-829).
+
+There is NO CPU fallback: without the built HIP library the import of `lib()` raises, and without a
+GPU every compute entry point returns C_KZG_ERROR.
+"""
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblambdaworks_kzg.so")
+
+C_KZG_OK, C_KZG_BADARGS, C_KZG_ERROR, C_KZG_MALLOC = 0, 1, 2, 3
+MODE_REFERENCE, MODE_CKZG = 0, 1
+FIELD_ELEMENTS_PER_BLOB = 4096
+BYTES_PER_BLOB = 4096 * 32
+BYTES_PER_COMMITMENT = 48
+BYTES_PER_PROOF = 48
+
+
+class KZGSettings(C.Structure):
+    """#[repr(C)] KZGSettings, /root/reference/src/lib.rs:206-222."""
+    _fields_ = [("fs", C.c_void_p), ("g1_values", C.c_void_p), ("g2_values", C.c_void_p)]
+
+
+class FFTSettings(C.Structure):
+    """#[repr(C)] FFTSettings, /root/reference/src/lib.rs:173-197."""
+    _fields_ = [("max_width", C.c_uint64), ("expanded_roots_of_unity", C.c_void_p),
+                ("reverse_roots_of_unity", C.c_void_p), ("roots_of_unity", C.c_void_p)]
+
+
+# every symbol include/lambdaworks_kzg_amd.h declares
+EXPORTED_SYMBOLS = [
+    "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
+    "compute_kzg_proof", "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof",
+    "verify_blob_kzg_proof_batch",
+    "lwkzg_set_mode", "lwkzg_get_mode", "lwkzg_blob_to_kzg_commitment_batch",
+    "lwkzg_compute_blob_kzg_proof_batch", "lwkzg_compute_kzg_proof_batch",
+    "lwkzg_blob_to_kzg_commitment_batch_device", "lwkzg_compute_blob_kzg_proof_batch_device", "lwkzg_reserve",
+    "lwkzg_g1_lincomb_setup_device", "lwkzg_fr_ntt4096_device",
+    "lwkzg_setup_image_bytes", "lwkzg_setup_export_device", "lwkzg_setup_import_device",
+    "lwkzg_device_count", "lwkzg_set_device", "lwkzg_version", "lwkzg_last_error",
+    "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
+    "lwkzg_msm_window_bits", "lwkzg_msm_num_windows",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP shared library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C lambdaworks_kzg_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    ps = C.POINTER(KZGSettings)
+    l.load_trusted_setup.argtypes = [ps, C.c_char_p, sz, C.c_char_p, sz]
+    l.load_trusted_setup_file.argtypes = [ps, vp]
+    l.free_trusted_setup.argtypes = [ps]
+    l.blob_to_kzg_commitment.argtypes = [C.c_char_p, C.c_char_p, ps]
+    l.compute_kzg_proof.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, ps]
+    l.compute_blob_kzg_proof.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, ps]
+    l.verify_kzg_proof.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, ps]
+    l.verify_blob_kzg_proof.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, ps]
+    l.verify_blob_kzg_proof_batch.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
+    l.lwkzg_set_mode.argtypes = [ci]
+    l.lwkzg_blob_to_kzg_commitment_batch.argtypes = [C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
+    l.lwkzg_compute_blob_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
+    l.lwkzg_compute_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
+    l.lwkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, ps, vp, vp]
+    l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
+    l.lwkzg_reserve.argtypes = [ps, sz]
+    l.lwkzg_g1_lincomb_setup_device.argtypes = [vp, vp, sz, ps, vp]
+    l.lwkzg_fr_ntt4096_device.argtypes = [vp, vp, sz, ci, ps, vp]
+    l.lwkzg_setup_image_bytes.restype = sz
+    l.lwkzg_setup_export_device.argtypes = [ps, vp, vp]
+    l.lwkzg_setup_import_device.argtypes = [ps, vp]
+    l.lwkzg_set_device.argtypes = [ci]
+    l.lwkzg_version.restype = C.c_char_p
+    l.lwkzg_last_error.restype = C.c_char_p
+    l.lwkzg_profile_enable.argtypes = [ci]
+    l.lwkzg_profile_enable.restype = None
+    l.lwkzg_profile_reset.restype = None
+    l.lwkzg_profile_report.argtypes = [C.c_char_p, sz]
+    l.lwkzg_profile_report.restype = sz
+    _lib = l
+    return l
+
+
+class KzgError(RuntimeError):
+    def __init__(self, fn, rc):
+        self.rc = rc
+        msg = lib().lwkzg_last_error().decode(errors="replace")
+        super().__init__("%s returned %s%s" % (fn, {1: "C_KZG_BADARGS", 2: "C_KZG_ERROR", 3: "C_KZG_MALLOC"}.get(rc, rc),
+                                               (": " + msg) if msg else ""))
+
+
+def _check(fn, rc):
+    if rc != C_KZG_OK:
+        raise KzgError(fn, rc)
+
+
+_libc = C.CDLL(None)
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+def set_mode(mode):
+    return lib().lwkzg_set_mode(mode)
+
+
+def get_mode():
+    return lib().lwkzg_get_mode()
+
+
+def set_device(ordinal):
+    if lib().lwkzg_set_device(ordinal) != 0:
+        raise KzgError("lwkzg_set_device", C_KZG_ERROR)
+
+
+class TrustedSetup:
+    """A loaded KZGSettings. Mirrors load_trusted_setup* / free_trusted_setup."""
+
+    def __init__(self):
+        self.s = KZGSettings()
+        self._loaded = False
+
+    @classmethod
+    def from_file(cls, path):
+        """load_trusted_setup_file(KZGSettings*, FILE*), /root/reference/src/lib.rs:779."""
+        self = cls()
+        fp = _libc.fopen(os.fsencode(path), b"r")
+        if not fp:
+            raise FileNotFoundError(path)
+        try:
+            _check("load_trusted_setup_file", lib().load_trusted_setup_file(C.byref(self.s), fp))
+        finally:
+            _libc.fclose(fp)
+        self._loaded = True
+        return self
+
+    @classmethod
+    def from_bytes(cls, g1_bytes, g2_bytes):
+        """load_trusted_setup(out, g1_bytes, n1, g2_bytes, n2), /root/reference/src/lib.rs:709."""
+        self = cls()
+        _check("load_trusted_setup", lib().load_trusted_setup(C.byref(self.s), g1_bytes, len(g1_bytes) // 48,
+                                                              g2_bytes, len(g2_bytes) // 96))
+        self._loaded = True
+        return self
+
+    @classmethod
+    def from_device_image(cls, image_dev_ptr):
+        self = cls()
+        _check("lwkzg_setup_import_device", lib().lwkzg_setup_import_device(C.byref(self.s), image_dev_ptr))
+        self._loaded = True
+        return self
+
+    def export_device_image(self, image_dev_ptr, stream=None):
+        _check("lwkzg_setup_export_device", lib().lwkzg_setup_export_device(C.byref(self.s), image_dev_ptr, stream))
+
+    def g1_values_bytes(self):
+        return C.string_at(self.s.g1_values, 4096 * 144)
+
+    def g2_values_bytes(self):
+        return C.string_at(self.s.g2_values, 65 * 288)
+
+    def fft_settings(self):
+        return FFTSettings.from_address(self.s.fs)
+
+    def ref(self):
+        return C.byref(self.s)
+
+    def reserve(self, n):
+        _check("lwkzg_reserve", lib().lwkzg_reserve(self.ref(), n))
+
+    def free(self):
+        if self._loaded:
+            lib().free_trusted_setup(C.byref(self.s))
+            self._loaded = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- the reference's functions, same names and argument meaning ---------------------------------
+
+def blob_to_kzg_commitment(blob, ts):
+    assert len(blob) == BYTES_PER_BLOB
+    out = C.create_string_buffer(48)
+    _check("blob_to_kzg_commitment", lib().blob_to_kzg_commitment(out, blob, ts.ref()))
+    return out.raw
+
+
+def compute_kzg_proof(blob, z_bytes, ts):
+    assert len(blob) == BYTES_PER_BLOB and len(z_bytes) == 32
+    proof, y = C.create_string_buffer(48), C.create_string_buffer(32)
+    _check("compute_kzg_proof", lib().compute_kzg_proof(proof, y, blob, z_bytes, ts.ref()))
+    return proof.raw, y.raw
+
+
+def compute_blob_kzg_proof(blob, commitment_bytes, ts):
+    assert len(blob) == BYTES_PER_BLOB and len(commitment_bytes) == 48
+    out = C.create_string_buffer(48)
+    _check("compute_blob_kzg_proof", lib().compute_blob_kzg_proof(out, blob, commitment_bytes, ts.ref()))
+    return out.raw
+
+
+def verify_kzg_proof(commitment_bytes, z_bytes, y_bytes, proof_bytes, ts):
+    ok = C.c_bool(False)
+    _check("verify_kzg_proof", lib().verify_kzg_proof(C.byref(ok), commitment_bytes, z_bytes, y_bytes, proof_bytes, ts.ref()))
+    return bool(ok.value)
+
+
+def verify_blob_kzg_proof(blob, commitment_bytes, proof_bytes, ts):
+    ok = C.c_bool(False)
+    _check("verify_blob_kzg_proof", lib().verify_blob_kzg_proof(C.byref(ok), blob, commitment_bytes, proof_bytes, ts.ref()))
+    return bool(ok.value)
+
+
+def verify_blob_kzg_proof_batch(blobs, commitments_bytes, proofs_bytes, n, ts):
+    ok = C.c_bool(False)
+    _check("verify_blob_kzg_proof_batch",
+           lib().verify_blob_kzg_proof_batch(C.byref(ok), blobs, commitments_bytes, proofs_bytes, n, ts.ref()))
+    return bool(ok.value)
+
+
+# ---- batched host-pointer extensions --------------------------------------------------------------
+
+def blob_to_kzg_commitment_batch(blobs, ts):
+    n = len(blobs) // BYTES_PER_BLOB
+    assert len(blobs) == n * BYTES_PER_BLOB
+    out = C.create_string_buffer(48 * max(n, 1))
+    bad = C.c_size_t(0)
+    _check("lwkzg_blob_to_kzg_commitment_batch",
+           lib().lwkzg_blob_to_kzg_commitment_batch(out, blobs, n, ts.ref(), C.byref(bad)))
+    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+
+def compute_blob_kzg_proof_batch(blobs, commitments, ts):
+    n = len(blobs) // BYTES_PER_BLOB
+    assert len(blobs) == n * BYTES_PER_BLOB and len(commitments) == 48 * n
+    out = C.create_string_buffer(48 * max(n, 1))
+    bad = C.c_size_t(0)
+    _check("lwkzg_compute_blob_kzg_proof_batch",
+           lib().lwkzg_compute_blob_kzg_proof_batch(out, blobs, commitments, n, ts.ref(), C.byref(bad)))
+    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+
+def compute_kzg_proof_batch(blobs, zs, ts):
+    n = len(blobs) // BYTES_PER_BLOB
+    assert len(blobs) == n * BYTES_PER_BLOB and len(zs) == 32 * n
+    out, ys = C.create_string_buffer(48 * max(n, 1)), C.create_string_buffer(32 * max(n, 1))
+    bad = C.c_size_t(0)
+    _check("lwkzg_compute_kzg_proof_batch",
+           lib().lwkzg_compute_kzg_proof_batch(out, ys, blobs, zs, n, ts.ref(), C.byref(bad)))
+    return [(out.raw[48 * i:48 * i + 48], ys.raw[32 * i:32 * i + 32]) for i in range(n)]
+
+
+# ---- device-resident extensions (pointers are ints: torch tensor .data_ptr()) -----------------------
+
+def blob_to_kzg_commitment_batch_device(out_ptr, blobs_ptr, n, ts, stream=None, status_ptr=None):
+    _check("lwkzg_blob_to_kzg_commitment_batch_device",
+           lib().lwkzg_blob_to_kzg_commitment_batch_device(out_ptr, blobs_ptr, n, ts.ref(), stream, status_ptr))
+
+
+def compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts, stream=None, status_ptr=None):
+    _check("lwkzg_compute_blob_kzg_proof_batch_device",
+           lib().lwkzg_compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts.ref(), stream, status_ptr))
+
+
+def g1_lincomb_setup_device(out_ptr, scalars_be_ptr, n_msm, ts, stream=None):
+    _check("lwkzg_g1_lincomb_setup_device", lib().lwkzg_g1_lincomb_setup_device(out_ptr, scalars_be_ptr, n_msm, ts.ref(), stream))
+
+
+def fr_ntt4096_device(out_ptr, in_ptr, n, inverse, ts, stream=None):
+    _check("lwkzg_fr_ntt4096_device", lib().lwkzg_fr_ntt4096_device(out_ptr, in_ptr, n, 1 if inverse else 0, ts.ref(), stream))
+
+
+def setup_image_bytes():
+    return lib().lwkzg_setup_image_bytes()
+
+
+def profile_enable(on=True):
+    lib().lwkzg_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().lwkzg_profile_reset()
+
+
+def profile_report():
+    n = lib().lwkzg_profile_report(None, 0)
+    buf = C.create_string_buffer(n)
+    lib().lwkzg_profile_report(buf, n)
+    return json.loads(buf.value.decode())

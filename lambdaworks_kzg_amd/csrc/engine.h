@@ -1,0 +1,76 @@
+// engine.h -- per-settings device context and the batch pipelines behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include "../../include/lambdaworks_kzg_amd.h"
+#include "kernels.h"
+
+namespace lwk {
+
+constexpr uint64_t kCtxMagic = 0x4c574b5a47414d44ull;  // "LWKZGAMD"
+constexpr size_t kMaxChunk = 1024;                      // blobs per launch set
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define LWK_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            lwk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return C_KZG_ERROR;                                                               \
+        }                                                                                     \
+    } while (0)
+
+struct Workspace {
+    size_t cap = 0;  // blobs
+    uint8_t *blobs = nullptr;        // host-API staging: cap x 131072
+    uint32_t *scalars = nullptr;     // cap x 4096 x 8   canonical coefficients
+    uint32_t *scalars2 = nullptr;    // cap x 4096 x 8   quotient coefficients
+    Fr *fr = nullptr;                // cap x 4096       Montgomery scratch (mode C / NTT)
+    uint32_t *sorted = nullptr;      // cap x 81920
+    uint32_t *bucket_start = nullptr;  // cap x 4097
+    uint32_t *perm = nullptr;        // cap x 4096
+    G1Xyzz *buckets = nullptr;       // cap x 4096
+    G1Xyzz *sums = nullptr;          // cap
+    uint8_t *out48 = nullptr;        // cap x 48
+    uint8_t *comm48 = nullptr;       // cap x 48
+    uint8_t *canon48 = nullptr;      // cap x 48
+    uint8_t *zbytes = nullptr;       // cap x 32
+    uint8_t *ybytes = nullptr;       // cap x 32
+    Fr *z = nullptr;                 // cap
+    int32_t *status = nullptr;       // cap
+};
+
+// The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
+struct Ctx {
+    FFTSettings fs;
+    uint64_t magic;
+    int device;
+    hipStream_t stream;
+    G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
+    G1Affine *table;   // kTablePoints
+    Fr *tw_fwd, *tw_inv;
+    Workspace ws;
+    std::mutex mu;
+    bool owns_fs_tables;
+};
+
+Ctx *ctx_of(const KZGSettings *s);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise
+
+C_KZG_RET ctx_reserve(Ctx *c, size_t n);
+
+// device-resident pipelines; all pointers device, async on st
+C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size_t n, int mode, hipStream_t st,
+                              int32_t *status);
+C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode,
+                                  hipStream_t st, int32_t *status);
+C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const uint8_t *blobs, const uint8_t *z32,
+                                   size_t n, int mode, hipStream_t st, int32_t *status);
+C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st);
+
+// G2 / pairing side (g2_pairing.hip, host only)
+bool g2_fill_values(g2_t *out65, const uint8_t *g2_bytes, size_t n2);
+
+}  // namespace lwk

@@ -1,0 +1,867 @@
+// engine.hip -- device context, workspace and the batch pipelines (host side, HIP runtime).
+//
+// One process drives one GPU (bench.py / torch.distributed launch one process per GPU). A loaded
+// trusted setup owns: the affine SRS points, the 20-window fixed-base table, the NTT twiddles, a
+// stream, and a grow-only workspace sized for up to kMaxChunk blobs per launch set.
+#include "engine.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <vector>
+
+namespace lwk {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    if (getenv("LWKZG_VERBOSE")) fprintf(stderr, "[lambdaworks_kzg_amd] %s\n", g_err);
+}
+const char *get_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// profiling: hipEvent pairs around every kernel launch, on the launch stream
+
+struct ProfRec {
+    const char *name;
+    hipEvent_t e0, e1;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_pending;
+struct ProfAgg {
+    uint64_t launches = 0;
+    double total_ms = 0;
+};
+static std::map<std::string, ProfAgg> g_prof_agg;
+
+ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), st(s), e0(nullptr), e1(nullptr), on(g_prof_on) {
+    if (!on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        on = false;
+        return;
+    }
+    hipEventRecord(e0, st);
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pending.push_back({name, e0, e1});
+}
+
+static void prof_drain() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto &a = g_prof_agg[r.name];
+            a.launches++;
+            a.total_ms += ms;
+        }
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    g_prof_pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// context registry (for KZGSettings built by hand: fs == NULL, caller-owned g1_values)
+
+static std::mutex g_reg_mu;
+static std::map<const void *, Ctx *> g_registry;
+static int g_default_device = 0;
+
+static C_KZG_RET dev_alloc(void **p, size_t bytes) {
+    LWK_HIP(hipMalloc(p, bytes));
+    return C_KZG_OK;
+}
+
+template <class T>
+static void dev_free(T *&p) {
+    if (p) hipFree(p);
+    p = nullptr;
+}
+
+static void ws_free(Workspace &w) {
+    dev_free(w.blobs);
+    dev_free(w.scalars);
+    dev_free(w.scalars2);
+    dev_free(w.fr);
+    dev_free(w.sorted);
+    dev_free(w.bucket_start);
+    dev_free(w.perm);
+    dev_free(w.buckets);
+    dev_free(w.sums);
+    dev_free(w.out48);
+    dev_free(w.comm48);
+    dev_free(w.canon48);
+    dev_free(w.zbytes);
+    dev_free(w.ybytes);
+    dev_free(w.z);
+    dev_free(w.status);
+    w.cap = 0;
+}
+
+C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
+    if (n > kMaxChunk) n = kMaxChunk;
+    if (n == 0) n = 1;
+    Workspace &w = c->ws;
+    if (w.cap >= n) return C_KZG_OK;
+    LWK_HIP(hipSetDevice(c->device));
+    LWK_HIP(hipStreamSynchronize(c->stream));
+    ws_free(w);
+    // round up so that repeated small growth does not reallocate every call
+    size_t cap = 1;
+    while (cap < n) cap <<= 1;
+    C_KZG_RET rc;
+#define WS_ALLOC(field, bytes)                                  \
+    if ((rc = dev_alloc((void **)&w.field, (bytes))) != C_KZG_OK) { \
+        ws_free(w);                                             \
+        return C_KZG_MALLOC;                                    \
+    }
+    WS_ALLOC(blobs, cap * (size_t)kBlobBytes);
+    WS_ALLOC(scalars, cap * (size_t)kBlobBytes);
+    WS_ALLOC(scalars2, cap * (size_t)kBlobBytes);
+    WS_ALLOC(fr, cap * (size_t)kBlobBytes);
+    WS_ALLOC(sorted, cap * (size_t)kMaxEntries * 4);
+    WS_ALLOC(bucket_start, cap * (size_t)(kNumBuckets + 1) * 4);
+    WS_ALLOC(perm, cap * (size_t)kNumBuckets * 4);
+    WS_ALLOC(buckets, cap * (size_t)kNumBuckets * sizeof(G1Xyzz));
+    WS_ALLOC(sums, cap * sizeof(G1Xyzz));
+    WS_ALLOC(out48, cap * 48);
+    WS_ALLOC(comm48, cap * 48);
+    WS_ALLOC(canon48, cap * 48);
+    WS_ALLOC(zbytes, cap * 32);
+    WS_ALLOC(ybytes, cap * 32);
+    WS_ALLOC(z, cap * sizeof(Fr));
+    WS_ALLOC(status, cap * 4);
+#undef WS_ALLOC
+    w.cap = cap;
+    return C_KZG_OK;
+}
+
+static void ctx_destroy(Ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    ws_free(c->ws);
+    dev_free(c->points);
+    dev_free(c->table);
+    dev_free(c->tw_fwd);
+    dev_free(c->tw_inv);
+    if (c->stream) hipStreamDestroy(c->stream);
+    free(c->fs.expanded_roots_of_unity);
+    free(c->fs.reverse_roots_of_unity);
+    free(c->fs.roots_of_unity);
+    c->magic = 0;
+    delete c;
+}
+
+static bool gpu_available() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available: this library has no CPU fallback (hipGetDeviceCount)");
+        return false;
+    }
+    return true;
+}
+
+// fs tables: canonical integers in the reference's limb convention (most-significant u64 first)
+static void fr_raw_to_blst(blst_fr *o, const uint32_t raw[8]) {
+    for (int k = 0; k < 4; k++) o->l[3 - k] = (uint64_t)raw[2 * k] | ((uint64_t)raw[2 * k + 1] << 32);
+}
+
+static C_KZG_RET ctx_new(Ctx **out) {
+    if (!gpu_available()) return C_KZG_ERROR;
+    Ctx *c = new Ctx();
+    memset(&c->fs, 0, sizeof c->fs);
+    c->magic = kCtxMagic;
+    c->device = g_default_device;
+    c->stream = nullptr;
+    c->points = nullptr;
+    c->table = nullptr;
+    c->tw_fwd = c->tw_inv = nullptr;
+    c->owns_fs_tables = true;
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->points, (size_t)kBlobElems * sizeof(G1Affine));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->tw_inv, (size_t)(kBlobElems / 2) * sizeof(Fr));
+    if (e != hipSuccess) {
+        set_error("device context allocation failed: %s", hipGetErrorString(e));
+        ctx_destroy(c);
+        return C_KZG_MALLOC;
+    }
+    *out = c;
+    return C_KZG_OK;
+}
+
+// twiddles on device + the genuine FFTSettings tables on the host
+static C_KZG_RET ctx_finish_fft(Ctx *c) {
+    launch_build_twiddles(c->tw_fwd, c->tw_inv, c->stream);
+    const int n = kBlobElems;
+    std::vector<Fr> h_f(n / 2), h_i(n / 2);
+    LWK_HIP(hipMemcpyAsync(h_f.data(), c->tw_fwd, (n / 2) * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    LWK_HIP(hipMemcpyAsync(h_i.data(), c->tw_inv, (n / 2) * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    LWK_HIP(hipStreamSynchronize(c->stream));
+    c->fs.max_width = n;
+    c->fs.expanded_roots_of_unity = (fr_t *)calloc(n + 1, sizeof(fr_t));
+    c->fs.reverse_roots_of_unity = (fr_t *)calloc(n + 1, sizeof(fr_t));
+    c->fs.roots_of_unity = (fr_t *)calloc(n, sizeof(fr_t));
+    if (!c->fs.expanded_roots_of_unity || !c->fs.reverse_roots_of_unity || !c->fs.roots_of_unity) return C_KZG_MALLOC;
+    // w^(k + n/2) = -w^k
+    for (int k = 0; k <= n; k++) {
+        int kk = k % n;
+        Fr f = h_f[kk % (n / 2)], b = h_i[kk % (n / 2)];
+        if (kk >= n / 2) {
+            f = neg(f);
+            b = neg(b);
+        }
+        uint32_t raw[8];
+        fe_to_raw<FrParams>(raw, f);
+        fr_raw_to_blst(&c->fs.expanded_roots_of_unity[k], raw);
+        fe_to_raw<FrParams>(raw, b);
+        fr_raw_to_blst(&c->fs.reverse_roots_of_unity[k], raw);
+    }
+    for (int k = 0; k < n; k++) {
+        unsigned r = 0;
+        for (int b = 0; b < 12; b++) r |= ((k >> b) & 1u) << (11 - b);
+        c->fs.roots_of_unity[k] = c->fs.expanded_roots_of_unity[r];
+    }
+    return C_KZG_OK;
+}
+
+Ctx *ctx_of(const KZGSettings *s) {
+    if (!s) {
+        set_error("KZGSettings pointer is NULL");
+        return nullptr;
+    }
+    if (s->fs) {
+        Ctx *c = (Ctx *)s->fs;
+        if (c->magic == kCtxMagic) return c;
+    }
+    // hand-built settings (the reference's own layout: fs == NULL): build and cache a context from g1_values
+    if (!s->g1_values) {
+        set_error("KZGSettings has neither an engine context nor g1_values");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_registry.find(s->g1_values);
+    if (it != g_registry.end()) return it->second;
+    Ctx *c = nullptr;
+    if (ctx_new(&c) != C_KZG_OK) return nullptr;
+    uint64_t *d_blst = nullptr;
+    int32_t *d_status = nullptr;
+    std::vector<int32_t> h_status(kBlobElems);
+    bool ok = hipMalloc((void **)&d_blst, (size_t)kBlobElems * 144) == hipSuccess &&
+              hipMalloc((void **)&d_status, (size_t)kBlobElems * 4) == hipSuccess &&
+              hipMemcpyAsync(d_blst, s->g1_values, (size_t)kBlobElems * 144, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (ok) {
+        launch_g1_from_blst(d_blst, c->points, d_status, kBlobElems, c->stream);
+        launch_build_table(c->points, c->table, c->stream);
+        ok = hipMemcpyAsync(h_status.data(), d_status, (size_t)kBlobElems * 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+             hipStreamSynchronize(c->stream) == hipSuccess;
+    }
+    if (d_blst) hipFree(d_blst);
+    if (d_status) hipFree(d_status);
+    if (ok)
+        for (int i = 0; i < kBlobElems; i++)
+            if (h_status[i] != 0) {
+                set_error("g1_values[%d] is not a point on the curve", i);  // reference: srs.rs:171 error
+                ok = false;
+                break;
+            }
+    if (ok) ok = ctx_finish_fft(c) == C_KZG_OK;
+    if (!ok) {
+        if (!get_error()[0]) set_error("building a device context from g1_values failed");
+        ctx_destroy(c);
+        return nullptr;
+    }
+    g_registry[s->g1_values] = c;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pipelines (device-resident, asynchronous)
+
+static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st) {
+    Workspace &w = c->ws;
+    launch_digit_sort(scalars_raw, w.sorted, w.bucket_start, w.perm, n, st);
+    launch_bucket_accumulate(c->table, w.sorted, w.bucket_start, w.perm, w.buckets, n, st);
+    launch_bucket_reduce(w.buckets, w.sums, n, st);
+    launch_finalize_compress(w.sums, out48, n, st);
+}
+
+// blob bytes -> canonical monomial coefficients in ws.scalars
+static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st) {
+    Workspace &w = c->ws;
+    if (mode == LWKZG_MODE_REFERENCE) {
+        launch_parse_be_reduce(blobs, w.scalars, n * kBlobElems, st);
+    } else {
+        launch_parse_le_canonical(blobs, w.fr, status, n, st);
+        launch_ntt4096(w.fr, (Fr *)w.scalars, c->tw_inv, 1, n, st);
+    }
+}
+
+C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st) {
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        msm_stages(c, scalars_raw + off * (size_t)kBlobElems * 8, out48 + 48 * off, m, st);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size_t n, int mode, hipStream_t st,
+                              int32_t *status) {
+    C_KZG_RET rc = ctx_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        int32_t *stt = status ? status + off : c->ws.status;
+        LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
+        coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
+        msm_stages(c, c->ws.scalars, out48 + 48 * off, m, st);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode,
+                                  hipStream_t st, int32_t *status) {
+    C_KZG_RET rc = ctx_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    const int le = mode == LWKZG_MODE_CKZG;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        int32_t *stt = status ? status + off : w.status;
+        const uint8_t *bl = blobs + off * (size_t)kBlobBytes;
+        LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
+        // lib.rs:372-375: the commitment is decompressed (and subgroup-checked) first
+        launch_validate_commitments(comm48 + 48 * off, w.canon48, stt, le ? kStatusBadArgs : kStatusError, m, st);
+        coefficients_stage(c, bl, m, mode, stt, st);
+        launch_challenge(bl, w.canon48, w.z, le, m, st);
+        launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+        msm_stages(c, w.scalars2, out48 + 48 * off, m, st);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const uint8_t *blobs, const uint8_t *z32,
+                                   size_t n, int mode, hipStream_t st, int32_t *status) {
+    C_KZG_RET rc = ctx_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    const int le = mode == LWKZG_MODE_CKZG;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        int32_t *stt = status ? status + off : w.status;
+        LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
+        coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
+        launch_z_from_bytes(z32 + 32 * off, w.z, stt, le, m, st);
+        launch_eval_quotient(w.scalars, w.z, w.scalars2, y32 + 32 * off, le, m, st);
+        msm_stages(c, w.scalars2, proof48 + 48 * off, m, st);
+    }
+    return C_KZG_OK;
+}
+
+}  // namespace lwk
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+
+using namespace lwk;
+
+static int g_mode = -1;
+
+static int mode_now() {
+    if (g_mode < 0) {
+        const char *e = getenv("LWKZG_MODE");
+        g_mode = (e && (!strcmp(e, "ckzg") || !strcmp(e, "c") || !strcmp(e, "C") || !strcmp(e, "1"))) ? LWKZG_MODE_CKZG
+                                                                                                      : LWKZG_MODE_REFERENCE;
+    }
+    return g_mode;
+}
+
+extern "C" {
+
+int lwkzg_set_mode(int mode) {
+    int prev = mode_now();
+    if (mode != LWKZG_MODE_REFERENCE && mode != LWKZG_MODE_CKZG) return -1;
+    g_mode = mode;
+    return prev;
+}
+int lwkzg_get_mode(void) { return mode_now(); }
+
+int lwkzg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int lwkzg_set_device(int ordinal) {
+    int n = lwkzg_device_count();
+    if (ordinal < 0 || ordinal >= n) {
+        set_error("lwkzg_set_device(%d): %d device(s) visible", ordinal, n);
+        return -1;
+    }
+    g_default_device = ordinal;
+    return 0;
+}
+const char *lwkzg_version(void) { return "lambdaworks_kzg_amd 0.1 (gfx950; fixed-base Pippenger c=13, 20 windows)"; }
+const char *lwkzg_last_error(void) { return get_error(); }
+int lwkzg_msm_window_bits(void) { return kWindowBits; }
+int lwkzg_msm_num_windows(void) { return kNumWindows; }
+
+void lwkzg_profile_enable(int on) {
+    if (!on) prof_drain();
+    g_prof_on = on != 0;
+}
+void lwkzg_profile_reset(void) {
+    prof_drain();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_agg.clear();
+}
+size_t lwkzg_profile_report(char *buf, size_t cap) {
+    prof_drain();
+    std::string s = "{";
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        bool first = true;
+        for (auto &kv : g_prof_agg) {
+            char line[256];
+            snprintf(line, sizeof line, "%s\"%s\": {\"launches\": %llu, \"total_ms\": %.6f}", first ? "" : ", ",
+                     kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.total_ms);
+            s += line;
+            first = false;
+        }
+    }
+    s += "}";
+    if (buf && cap) {
+        size_t k = s.size() < cap - 1 ? s.size() : cap - 1;
+        memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return s.size() + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// trusted setup
+
+static C_KZG_RET setup_from_bytes(KZGSettings *out, const uint8_t *g1_bytes, const uint8_t *g2_bytes) {
+    Ctx *c = nullptr;
+    C_KZG_RET rc = ctx_new(&c);
+    if (rc != C_KZG_OK) return rc;
+    const size_t n1 = kBlobElems, n2 = TRUSTED_SETUP_NUM_G2_POINTS;
+    uint8_t *d_in = nullptr;
+    int32_t *d_status = nullptr;
+    uint64_t *d_blst = nullptr;
+    g1_t *g1v = (g1_t *)malloc(n1 * sizeof(g1_t));  // libc malloc: the reference frees these with libc::free (lib.rs:824-826)
+    g2_t *g2v = (g2_t *)malloc(n2 * sizeof(g2_t));
+    std::vector<int32_t> h_status(n1);
+    rc = C_KZG_ERROR;
+    do {
+        if (!g1v || !g2v) { rc = C_KZG_MALLOC; break; }
+        if (hipMalloc((void **)&d_in, n1 * 48) != hipSuccess || hipMalloc((void **)&d_status, n1 * 4) != hipSuccess ||
+            hipMalloc((void **)&d_blst, n1 * 144) != hipSuccess) { rc = C_KZG_MALLOC; set_error("hipMalloc failed in setup load"); break; }
+        if (hipMemcpyAsync(d_in, g1_bytes, n1 * 48, hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("H2D of g1 bytes failed"); break; }
+        // decompress_g1_point incl. the [r]P subgroup check for every point (compression.rs:62-103)
+        launch_g1_decompress(d_in, c->points, d_status, n1, 1, c->stream);
+        launch_g1_to_blst(c->points, d_status, d_blst, n1, c->stream);
+        launch_build_table(c->points, c->table, c->stream);
+        if (hipMemcpyAsync(h_status.data(), d_status, n1 * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(g1v, d_blst, n1 * 144, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { set_error("setup kernels failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        bool good = true;
+        for (size_t i = 0; i < n1; i++) {
+            if (h_status[i] == 2) { set_error("g1 point %zu: invalid compressed point or not in the subgroup", i); good = false; break; }
+            if (h_status[i] == 1) { set_error("g1 point %zu is the point at infinity: the reference cannot read such a setup back (srs.rs:155-172)", i); good = false; break; }
+        }
+        if (!good) break;
+        if (!g2_fill_values(g2v, g2_bytes, n2)) { if (!get_error()[0]) set_error("invalid g2 point in trusted setup"); break; }
+        rc = ctx_finish_fft(c);
+    } while (0);
+    if (d_in) hipFree(d_in);
+    if (d_status) hipFree(d_status);
+    if (d_blst) hipFree(d_blst);
+    if (rc != C_KZG_OK) {
+        free(g1v);
+        free(g2v);
+        ctx_destroy(c);
+        return rc;
+    }
+    out->fs = &c->fs;
+    out->g1_values = g1v;
+    out->g2_values = g2v;
+    return C_KZG_OK;
+}
+
+C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2) {
+    if (!out || !g1_bytes || !g2_bytes) return C_KZG_BADARGS;
+    if (n1 != TRUSTED_SETUP_NUM_G1_POINTS || n2 != TRUSTED_SETUP_NUM_G2_POINTS) return C_KZG_BADARGS;  // lib.rs:716-718
+    return setup_from_bytes(out, g1_bytes, g2_bytes);
+}
+
+static int hexv(int ch) {
+    if (ch >= '0' && ch <= '9') return ch - '0';
+    if (ch >= 'a' && ch <= 'f') return ch - 'a' + 10;
+    if (ch >= 'A' && ch <= 'F') return ch - 'A' + 10;
+    return -1;
+}
+
+// srs.rs:25-82: line 1 = n1, line 2 = n2 (decimal), then exactly one hex point per line.
+C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in) {
+    if (!out || !in) return C_KZG_BADARGS;
+    std::string text;
+    char buf[64 * 1024];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, in)) > 0) text.append(buf, got);  // lib.rs:780-789
+    std::vector<std::pair<size_t, size_t>> lines;  // (offset, length), str::lines semantics
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        size_t len = e - pos;
+        if (len && text[pos + len - 1] == '\r') len--;
+        lines.push_back({pos, len});
+        pos = e + 1;
+    }
+    auto parse_count = [&](size_t li, size_t *v) -> bool {
+        if (li >= lines.size()) return false;
+        size_t o = lines[li].first, l = lines[li].second, k = 0;
+        if (l && text[o] == '+') k = 1;
+        if (k == l) return false;
+        size_t acc = 0;
+        for (; k < l; k++) {
+            char ch = text[o + k];
+            if (ch < '0' || ch > '9') return false;
+            acc = acc * 10 + (size_t)(ch - '0');
+            if (acc > (1u << 24)) return false;
+        }
+        *v = acc;
+        return true;
+    };
+    size_t n1 = 0, n2 = 0;
+    if (!parse_count(0, &n1) || !parse_count(1, &n2)) {
+        set_error("trusted setup file: bad header");
+        return C_KZG_ERROR;
+    }
+    // The reference does not check n1 here and later reads 4096 entries regardless (UB for other
+    // sizes); this engine is built for 4096/65 and says so.
+    if (n1 != TRUSTED_SETUP_NUM_G1_POINTS || n2 != TRUSTED_SETUP_NUM_G2_POINTS) {
+        set_error("trusted setup file announces %zu/%zu points; this engine needs 4096/65", n1, n2);
+        return C_KZG_BADARGS;
+    }
+    if (lines.size() < 2 + n1 + n2) {
+        set_error("trusted setup file: %zu point lines, expected %zu", lines.size() - 2, n1 + n2);
+        return C_KZG_ERROR;
+    }
+    std::vector<uint8_t> g1(n1 * 48), g2(n2 * 96);
+    for (size_t i = 0; i < n1 + n2; i++) {
+        size_t nb = i < n1 ? 48 : 96;
+        uint8_t *dst = i < n1 ? &g1[i * 48] : &g2[(i - n1) * 96];
+        size_t o = lines[2 + i].first, l = lines[2 + i].second;
+        if (l != 2 * nb) {
+            set_error("trusted setup file: line %zu has %zu characters, expected %zu", i + 3, l, 2 * nb);
+            return C_KZG_ERROR;
+        }
+        for (size_t k = 0; k < nb; k++) {
+            int h = hexv(text[o + 2 * k]), lo = hexv(text[o + 2 * k + 1]);
+            if (h < 0 || lo < 0) {
+                set_error("trusted setup file: line %zu is not hex", i + 3);
+                return C_KZG_ERROR;
+            }
+            dst[k] = (uint8_t)(h * 16 + lo);
+        }
+    }
+    return setup_from_bytes(out, g1.data(), g2.data());
+}
+
+C_KZG_RET free_trusted_setup(KZGSettings *s) {
+    if (!s) return C_KZG_OK;
+    Ctx *c = nullptr;
+    if (s->fs && ((Ctx *)s->fs)->magic == kCtxMagic) {
+        c = (Ctx *)s->fs;
+    } else {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_registry.find(s->g1_values);
+        if (it != g_registry.end()) {
+            c = it->second;
+            g_registry.erase(it);
+        }
+    }
+    ctx_destroy(c);
+    free(s->g1_values);  // lib.rs:824-826
+    free(s->g2_values);
+    s->fs = nullptr;
+    s->g1_values = nullptr;
+    s->g2_values = nullptr;
+    return C_KZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer entry points
+
+// maps per-blob status words to one return code; first_bad gets the first offender
+static C_KZG_RET collect_status(Ctx *c, const int32_t *d_status, size_t n, size_t base, size_t *first_bad) {
+    std::vector<int32_t> h(n);
+    LWK_HIP(hipMemcpyAsync(h.data(), d_status, n * 4, hipMemcpyDeviceToHost, c->stream));
+    LWK_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++)
+        if (h[i] != 0) {
+            if (first_bad) *first_bad = base + i;
+            set_error("blob %zu rejected (status %d)", base + i, h[i]);
+            return (C_KZG_RET)h[i];
+        }
+    return C_KZG_OK;
+}
+
+// In reference mode every failure is C_KZG_ERROR (lib.rs:263,267,272,...).
+static C_KZG_RET map_rc(C_KZG_RET rc, int mode) {
+    if (rc == C_KZG_OK) return rc;
+    if (mode == LWKZG_MODE_REFERENCE) return C_KZG_ERROR;
+    return rc;
+}
+
+C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s,
+                                             size_t *first_bad) {
+    const int mode = mode_now();
+    if (!out || !blobs) return map_rc(C_KZG_BADARGS, mode);
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        C_KZG_RET rc = ctx_reserve(c, m);
+        if (rc != C_KZG_OK) return rc;
+        Workspace &w = c->ws;
+        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
+        rc = commit_batch_device(c, w.out48, w.blobs, m, mode, c->stream, w.status);
+        if (rc != C_KZG_OK) return rc;
+        std::vector<uint8_t> h_out(m * 48);
+        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
+        rc = collect_status(c, w.status, m, off, first_bad);
+        if (rc != C_KZG_OK) return map_rc(rc, mode);
+        memcpy(out + off, h_out.data(), m * 48);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
+                                             const KZGSettings *s, size_t *first_bad) {
+    const int mode = mode_now();
+    if (!out || !blobs || !commitments) return map_rc(C_KZG_BADARGS, mode);
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        C_KZG_RET rc = ctx_reserve(c, m);
+        if (rc != C_KZG_OK) return rc;
+        Workspace &w = c->ws;
+        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
+        LWK_HIP(hipMemcpyAsync(w.comm48, commitments + off, m * 48, hipMemcpyHostToDevice, c->stream));
+        rc = blob_proof_batch_device(c, w.out48, w.blobs, w.comm48, m, mode, c->stream, w.status);
+        if (rc != C_KZG_OK) return rc;
+        std::vector<uint8_t> h_out(m * 48);
+        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
+        rc = collect_status(c, w.status, m, off, first_bad);
+        if (rc != C_KZG_OK) return map_rc(rc, mode);
+        memcpy(out + off, h_out.data(), m * 48);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs,
+                                        size_t n, const KZGSettings *s, size_t *first_bad) {
+    const int mode = mode_now();
+    if (!proofs_out || !ys_out || !blobs || !zs) return map_rc(C_KZG_BADARGS, mode);
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        C_KZG_RET rc = ctx_reserve(c, m);
+        if (rc != C_KZG_OK) return rc;
+        Workspace &w = c->ws;
+        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
+        LWK_HIP(hipMemcpyAsync(w.zbytes, zs + off, m * 32, hipMemcpyHostToDevice, c->stream));
+        rc = point_proof_batch_device(c, w.out48, w.ybytes, w.blobs, w.zbytes, m, mode, c->stream, w.status);
+        if (rc != C_KZG_OK) return rc;
+        std::vector<uint8_t> h_out(m * 48), h_y(m * 32);
+        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
+        LWK_HIP(hipMemcpyAsync(h_y.data(), w.ybytes, m * 32, hipMemcpyDeviceToHost, c->stream));
+        rc = collect_status(c, w.status, m, off, first_bad);
+        if (rc != C_KZG_OK) return map_rc(rc, mode);
+        memcpy(proofs_out + off, h_out.data(), m * 48);
+        memcpy(ys_out + off, h_y.data(), m * 32);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KZGSettings *s) {
+    return lwkzg_blob_to_kzg_commitment_batch(out, blob, 1, s, nullptr);
+}
+
+C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob, const Bytes32 *z_bytes,
+                            const KZGSettings *s) {
+    return lwkzg_compute_kzg_proof_batch(proof_out, y_out, blob, z_bytes, 1, s, nullptr);
+}
+
+C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes, const KZGSettings *s) {
+    return lwkzg_compute_blob_kzg_proof_batch(out, blob, commitment_bytes, 1, s, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident entry points
+
+C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return ctx_reserve(c, max_batch);
+}
+
+C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void *blobs_dev, size_t n, const KZGSettings *s,
+                                                    void *stream, int32_t *status_dev) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    return commit_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, n, mode_now(), st, status_dev);
+}
+
+C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void *blobs_dev, const void *commitments48_dev,
+                                                    size_t n, const KZGSettings *s, void *stream, int32_t *status_dev) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    return blob_proof_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev,
+                                   n, mode_now(), st, status_dev);
+}
+
+C_KZG_RET lwkzg_g1_lincomb_setup_device(void *out48_dev, const void *scalars_be_dev, size_t n_msm, const KZGSettings *s,
+                                        void *stream) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    C_KZG_RET rc = ctx_reserve(c, n_msm);
+    if (rc != C_KZG_OK) return rc;
+    for (size_t off = 0; off < n_msm; off += kMaxChunk) {
+        size_t m = n_msm - off < kMaxChunk ? n_msm - off : kMaxChunk;
+        launch_parse_be_reduce((const uint8_t *)scalars_be_dev + off * (size_t)kBlobBytes, c->ws.scalars, m * kBlobElems, st);
+        msm_scalars_raw_device(c, (uint8_t *)out48_dev + 48 * off, c->ws.scalars, m, st);
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET lwkzg_fr_ntt4096_device(void *out_dev, const void *in_dev, size_t n, int inverse, const KZGSettings *s,
+                                  void *stream) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    C_KZG_RET rc = ctx_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        const uint8_t *src = (const uint8_t *)in_dev + off * (size_t)kBlobBytes;
+        uint8_t *dst = (uint8_t *)out_dev + off * (size_t)kBlobBytes;
+        launch_fr_be_to_mont(src, (Fr *)w.scalars2, m * kBlobElems, st);
+        launch_bitrev_permute((const Fr *)w.scalars2, w.fr, m, st);  // natural order in -> DIT wants bit-reversed
+        if (inverse) {
+            launch_ntt4096(w.fr, (Fr *)w.scalars, c->tw_inv, 1, m, st);  // scaled by 4096^-1, canonical limbs out
+            launch_raw_to_be(w.scalars, dst, m * kBlobElems, st);
+        } else {
+            launch_ntt4096(w.fr, (Fr *)w.scalars2, c->tw_fwd, 0, m, st);
+            launch_fr_mont_to_be((const Fr *)w.scalars2, dst, m * kBlobElems, st);
+        }
+    }
+    return C_KZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU setup hand-off: [hdr 64][g1_values 589,824][g2_values 18,720 -> padded][table][tw_fwd][tw_inv]
+
+static constexpr size_t kImgHdr = 64;
+static constexpr size_t kImgG1 = (size_t)kBlobElems * 144;
+static constexpr size_t kImgG2 = ((size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288 + 63) / 64 * 64;
+static constexpr size_t kImgTable = (size_t)kTablePoints * sizeof(G1Affine);
+static constexpr size_t kImgTw = (size_t)(kBlobElems / 2) * sizeof(Fr);
+static constexpr size_t kImgBytes = kImgHdr + kImgG1 + kImgG2 + kImgTable + 2 * kImgTw;
+
+size_t lwkzg_setup_image_bytes(void) { return kImgBytes; }
+
+C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void *stream) {
+    Ctx *c = ctx_of(s);
+    if (!c || !image_dev) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    uint8_t *img = (uint8_t *)image_dev;
+    uint64_t hdr[8] = {kCtxMagic, kImgBytes, (uint64_t)kWindowBits, (uint64_t)kNumWindows, 0, 0, 0, 0};
+    LWK_HIP(hipMemcpyAsync(img, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
+    LWK_HIP(hipMemcpyAsync(img + kImgHdr, s->g1_values, kImgG1, hipMemcpyHostToDevice, st));
+    LWK_HIP(hipMemsetAsync(img + kImgHdr + kImgG1, 0, kImgG2, st));
+    LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1, s->g2_values, (size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288, hipMemcpyHostToDevice, st));
+    LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2, c->table, kImgTable, hipMemcpyDeviceToDevice, st));
+    LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2 + kImgTable, c->tw_fwd, kImgTw, hipMemcpyDeviceToDevice, st));
+    LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2 + kImgTable + kImgTw, c->tw_inv, kImgTw, hipMemcpyDeviceToDevice, st));
+    LWK_HIP(hipStreamSynchronize(st));  // the host sources above must stay valid until the copies ran
+    return C_KZG_OK;
+}
+
+C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev) {
+    if (!out || !image_dev) return C_KZG_BADARGS;
+    Ctx *c = nullptr;
+    C_KZG_RET rc = ctx_new(&c);
+    if (rc != C_KZG_OK) return rc;
+    const uint8_t *img = (const uint8_t *)image_dev;
+    uint64_t hdr[8];
+    g1_t *g1v = (g1_t *)malloc(kImgG1);
+    g2_t *g2v = (g2_t *)malloc((size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288);
+    bool ok = g1v && g2v && hipMemcpy(hdr, img, sizeof hdr, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && (hdr[0] != kCtxMagic || hdr[1] != kImgBytes || hdr[2] != (uint64_t)kWindowBits || hdr[3] != (uint64_t)kNumWindows)) {
+        set_error("setup image header mismatch (different build or not an image)");
+        ok = false;
+    }
+    ok = ok && hipMemcpy(g1v, img + kImgHdr, kImgG1, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(g2v, img + kImgHdr + kImgG1, (size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(c->table, img + kImgHdr + kImgG1 + kImgG2, kImgTable, hipMemcpyDeviceToDevice) == hipSuccess &&
+         hipMemcpy(c->points, c->table, (size_t)kBlobElems * sizeof(G1Affine), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (ok) ok = ctx_finish_fft(c) == C_KZG_OK;
+    if (!ok) {
+        if (!get_error()[0]) set_error("setup image import failed");
+        free(g1v);
+        free(g2v);
+        ctx_destroy(c);
+        return C_KZG_ERROR;
+    }
+    out->fs = &c->fs;
+    out->g1_values = g1v;
+    out->g2_values = g2v;
+    return C_KZG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// fr_ops.hip -- scalar-field (Fr) side of the pipeline on gfx950.
+//
+//  * 4096-point radix-2 NTT/INTT, one workgroup per blob, whole transform in LDS (128 KiB of the
+//    CU's 160 KiB). SURVEY a15: the reference never calls an FFT (KZGSettings.fs is always NULL,
+//    /root/reference/src/lib.rs:754-758; the Lagrange conversion is commented out, :760-770); the
+//    north star and the c-kzg-4844 semantics (evaluation-form blobs) need it.
+//  * Polynomial::evaluate (Horner) + ruffini_division as ONE affine-map suffix scan per blob
+//    (call sites /root/reference/src/lib.rs:320,329,389,394).
+#include "kernels.h"
+
+namespace lwk {
+
+// omega = 7^((r-1)/4096) and its inverse, canonical little-endian limbs
+__device__ __constant__ uint32_t kOmegaRaw[8] = {0xa5d36306u, 0xe206da11u, 0x378fbf96u, 0x0ad1347bu,
+                                                 0xe0f8245fu, 0xfc3e8acfu, 0xa0f704f4u, 0x564c0a11u};
+__device__ __constant__ uint32_t kOmegaInvRaw[8] = {0xd8543362u, 0x961a252du, 0x64183203u, 0x5046d178u,
+                                                    0xb9dc5986u, 0x4ae25ffau, 0xc609b478u, 0x391b2856u};
+// 4096^-1 mod r, canonical limbs (NOT Montgomery: multiplying a Montgomery value by it yields the raw product)
+__device__ __constant__ uint32_t kNInvRaw[8] = {0x00100001u, 0x400fffffu, 0xbfce5c19u, 0xd3686828u,
+                                                0x89213de7u, 0x5eb6a46au, 0xb46ae370u, 0x73e66878u};
+
+// tw_fwd[k] = w^k, tw_inv[k] = w^-k, k < 2048 (Montgomery). One lane per entry: square-and-multiply.
+__global__ __launch_bounds__(256) void k_build_twiddles(Fr *__restrict__ tw_fwd, Fr *__restrict__ tw_inv) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= kBlobElems / 2) return;
+    uint32_t raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) raw[i] = kOmegaRaw[i];
+    Fr w = fe_from_raw<FrParams>(raw);
+#pragma unroll
+    for (int i = 0; i < 8; i++) raw[i] = kOmegaInvRaw[i];
+    Fr wi = fe_from_raw<FrParams>(raw);
+    Fr a = Fr::one(), b = Fr::one();
+    for (int bit = 10; bit >= 0; bit--) {
+        a = sqr(a);
+        b = sqr(b);
+        if ((k >> bit) & 1) {
+            a = a * w;
+            b = b * wi;
+        }
+    }
+    tw_fwd[k] = a;
+    tw_inv[k] = b;
+}
+
+void launch_build_twiddles(Fr *tw_fwd, Fr *tw_inv, hipStream_t st) {
+    ProfScope p("k_build_twiddles", st);
+    hipLaunchKernelGGL(k_build_twiddles, dim3(kBlobElems / 2 / 256), dim3(256), 0, st, tw_fwd, tw_inv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4096-point DIT transform in LDS.  The input is consumed in the order given: feeding evaluations in
+// bit-reversed order (exactly how a c-kzg-4844 blob stores them) yields natural-order output, so the
+// usual bit-reversal pass disappears.
+
+constexpr int kNttThreads = 1024;
+
+__global__ __launch_bounds__(kNttThreads) void k_ntt4096(const Fr *__restrict__ in, Fr *__restrict__ out,
+                                                         const Fr *__restrict__ tw, int scale_to_raw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Fr *a = (Fr *)lds_raw;  // 4096 x 32 B = 128 KiB
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kBlobElems;
+    for (int i = tid; i < kBlobElems; i += kNttThreads) a[i] = in[base + i];
+    __syncthreads();
+    // stage s: butterflies of span half = 2^s; twiddle index = (k mod half) * (2048 / half)
+    for (int s = 0; s < 12; s++) {
+        const int half = 1 << s;
+        const int tshift = 11 - s;
+        for (int bfly = tid; bfly < kBlobElems / 2; bfly += kNttThreads) {
+            int k = bfly & (half - 1);
+            int i0 = ((bfly >> s) << (s + 1)) + k;
+            int i1 = i0 + half;
+            Fr u = a[i0];
+            Fr v = a[i1] * tw[k << tshift];
+            a[i0] = u + v;
+            a[i1] = u - v;
+        }
+        __syncthreads();
+    }
+    if (scale_to_raw) {
+        Fr ninv;
+#pragma unroll
+        for (int i = 0; i < 8; i++) ninv.l[i] = kNInvRaw[i];
+        for (int i = tid; i < kBlobElems; i += kNttThreads) out[base + i] = a[i] * ninv;  // Montgomery x raw -> raw
+    } else {
+        for (int i = tid; i < kBlobElems; i += kNttThreads) out[base + i] = a[i];
+    }
+}
+
+void launch_ntt4096(const Fr *in, Fr *out, const Fr *tw, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_ntt4096", st);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *)k_ntt4096, hipFuncAttributeMaxDynamicSharedMemorySize, kBlobElems * 32);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_ntt4096, dim3((unsigned)n_blobs), dim3(kNttThreads), kBlobElems * 32, st, in, out, tw,
+                       inverse_scale_to_raw);
+}
+
+__global__ __launch_bounds__(256) void k_bitrev_permute(const Fr *__restrict__ in, Fr *__restrict__ out, size_t n) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint32_t i = (uint32_t)(g & (kBlobElems - 1));
+    uint32_t r = __brev(i) >> 20;
+    out[(g - i) + r] = in[g];
+}
+
+void launch_bitrev_permute(const Fr *in, Fr *out, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_bitrev_permute", st);
+    size_t n = n_blobs * kBlobElems;
+    hipLaunchKernelGGL(k_bitrev_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+
+__global__ __launch_bounds__(256) void k_fr_be_to_mont(const uint4 *__restrict__ in, Fr *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 hi = in[2 * i], lo = in[2 * i + 1];
+    uint32_t s[8] = {__builtin_bswap32(lo.w), __builtin_bswap32(lo.z), __builtin_bswap32(lo.y), __builtin_bswap32(lo.x),
+                     __builtin_bswap32(hi.w), __builtin_bswap32(hi.z), __builtin_bswap32(hi.y), __builtin_bswap32(hi.x)};
+    out[i] = fe_from_raw<FrParams>(s);
+}
+void launch_fr_be_to_mont(const uint8_t *in_be, Fr *out, size_t n_elems, hipStream_t st) {
+    ProfScope p("k_fr_be_to_mont", st);
+    hipLaunchKernelGGL(k_fr_be_to_mont, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, (const uint4 *)in_be,
+                       out, n_elems);
+}
+
+__global__ __launch_bounds__(256) void k_fr_mont_to_be(const Fr *__restrict__ in, uint4 *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    fe_to_raw<FrParams>(s, in[i]);
+    out[2 * i] = make_uint4(__builtin_bswap32(s[7]), __builtin_bswap32(s[6]), __builtin_bswap32(s[5]),
+                            __builtin_bswap32(s[4]));
+    out[2 * i + 1] = make_uint4(__builtin_bswap32(s[3]), __builtin_bswap32(s[2]), __builtin_bswap32(s[1]),
+                                __builtin_bswap32(s[0]));
+}
+void launch_fr_mont_to_be(const Fr *in, uint8_t *out_be, size_t n_elems, hipStream_t st) {
+    ProfScope p("k_fr_mont_to_be", st);
+    hipLaunchKernelGGL(k_fr_mont_to_be, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, in, (uint4 *)out_be,
+                       n_elems);
+}
+
+__global__ __launch_bounds__(256) void k_raw_to_be(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 lo = in[2 * i], hi = in[2 * i + 1];
+    out[2 * i] = make_uint4(__builtin_bswap32(hi.w), __builtin_bswap32(hi.z), __builtin_bswap32(hi.y),
+                            __builtin_bswap32(hi.x));
+    out[2 * i + 1] = make_uint4(__builtin_bswap32(lo.w), __builtin_bswap32(lo.z), __builtin_bswap32(lo.y),
+                                __builtin_bswap32(lo.x));
+}
+void launch_raw_to_be(const uint32_t *raw, uint8_t *out_be, size_t n_elems, hipStream_t st) {
+    ProfScope p("k_raw_to_be", st);
+    hipLaunchKernelGGL(k_raw_to_be, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, (const uint4 *)raw,
+                       (uint4 *)out_be, n_elems);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = p(z), q = (p - y) / (x - z)
+//
+// Horner: acc_i = c_i + z * acc_{i+1}, acc_4096 = 0.  Then y = acc_0 and q_{i-1} = acc_i (Ruffini).
+// The recurrence is a composition of affine maps x -> c + m x, so it parallelises as a suffix scan:
+// lane t owns coefficients [16t, 16t+16); L_t = sum_k c_{16t+k} z^k; H_t = L_t + z^16 H_{t+1}
+// (Hillis-Steele over (multiplier, value) pairs in LDS); acc at the chunk's upper edge is H_{t+1}.
+
+constexpr int kEvalThreads = 256;
+constexpr int kEvalChunk = kBlobElems / kEvalThreads;  // 16
+
+__global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__restrict__ coeffs_raw,
+                                                                const Fr *__restrict__ z_mont,
+                                                                uint4 *__restrict__ quot_raw, uint8_t *__restrict__ y_out,
+                                                                int le) {
+    __shared__ Fr sh_m[kEvalThreads];
+    __shared__ Fr sh_v[kEvalThreads];
+    const int t = threadIdx.x;
+    const size_t blob = blockIdx.x;
+    const uint4 *cin = coeffs_raw + (blob * kBlobElems + (size_t)t * kEvalChunk) * 2;
+    const Fr z = z_mont[blob];
+
+    Fr c[kEvalChunk];
+#pragma unroll
+    for (int k = 0; k < kEvalChunk; k++) {
+        uint4 lo = cin[2 * k], hi = cin[2 * k + 1];
+        uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        c[k] = fe_from_raw<FrParams>(s);
+    }
+    Fr L = c[kEvalChunk - 1];
+#pragma unroll
+    for (int k = kEvalChunk - 2; k >= 0; k--) L = L * z + c[k];
+    Fr m = z;
+#pragma unroll
+    for (int k = 1; k < kEvalChunk; k <<= 1) m = sqr(m);  // z^16
+
+    Fr v = L;
+    sh_m[t] = m;
+    sh_v[t] = v;
+    __syncthreads();
+    for (int d = 1; d < kEvalThreads; d <<= 1) {
+        bool has = t + d < kEvalThreads;
+        Fr om = has ? sh_m[t + d] : Fr::zero();
+        Fr ov = has ? sh_v[t + d] : Fr::zero();
+        __syncthreads();
+        if (has) {
+            v = v + m * ov;
+            m = m * om;
+        }
+        sh_m[t] = m;
+        sh_v[t] = v;
+        __syncthreads();
+    }
+    // v == H_t
+    Fr acc = (t + 1 < kEvalThreads) ? sh_v[t + 1] : Fr::zero();
+    uint4 *qout = quot_raw + (blob * kBlobElems) * 2;
+    const int i0 = t * kEvalChunk;
+#pragma unroll
+    for (int k = kEvalChunk - 1; k >= 0; k--) {
+        acc = c[k] + z * acc;
+        int i = i0 + k;
+        if (i >= 1) {
+            uint32_t s[8];
+            fe_to_raw<FrParams>(s, acc);
+            qout[2 * (i - 1)] = make_uint4(s[0], s[1], s[2], s[3]);
+            qout[2 * (i - 1) + 1] = make_uint4(s[4], s[5], s[6], s[7]);
+        }
+    }
+    if (t == kEvalThreads - 1) {
+        qout[2 * (kBlobElems - 1)] = make_uint4(0, 0, 0, 0);
+        qout[2 * (kBlobElems - 1) + 1] = make_uint4(0, 0, 0, 0);
+    }
+    if (t == 0 && y_out) {
+        uint32_t s[8];
+        fe_to_raw<FrParams>(s, acc);  // acc_0 = y
+        uint8_t *yo = y_out + 32 * blob;
+        if (le) raw_to_le<8>(yo, s); else raw_to_be<8>(yo, s);
+    }
+}
+
+void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
+                          size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_eval_quotient", st);
+    hipLaunchKernelGGL(k_eval_quotient, dim3((unsigned)n_blobs), dim3(kEvalThreads), 0, st, (const uint4 *)coeffs_raw,
+                       z_mont, (uint4 *)quot_raw, y_out, le);
+}
+
+__global__ __launch_bounds__(64) void k_z_from_bytes(const uint8_t *__restrict__ zb, Fr *__restrict__ z_mont,
+                                                     int32_t *__restrict__ status, int le, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    if (le) {
+        raw_from_le<8>(s, zb + 32 * i);
+        if (raw_geq<8>(s, FrParams::MOD)) status[i] = kStatusBadArgs;
+    } else {
+        raw_from_be<8>(s, zb + 32 * i);
+    }
+    z_mont[i] = fe_from_raw<FrParams>(s);  // reduces when >= r (reference mode)
+}
+
+void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, int le, size_t n, hipStream_t st) {
+    ProfScope p("k_z_from_bytes", st);
+    hipLaunchKernelGGL(k_z_from_bytes, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, z_bytes, z_mont, status, le, n);
+}
+
+}  // namespace lwk

@@ -1,0 +1,76 @@
+// kernels.h -- host-side launchers of the HIP kernels (one per pipeline stage).
+// Every launcher only enqueues work on `st`; nothing here synchronises or allocates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "g1.cuh"
+#include "plan.h"
+
+namespace lwk {
+
+// ---- profiling hook (engine.hip): wraps a launch in hipEvents when profiling is on
+struct ProfScope {
+    ProfScope(const char *name, hipStream_t st);
+    ~ProfScope();
+    const char *name;
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    bool on;
+};
+
+// ---- scalar ingest (msm.hip)
+// Mode R: 32-byte big-endian elements -> canonical 8xu32 little-endian limbs, reduced mod r
+// (blob_to_polynomial, /root/reference/src/utils.rs:27-41).
+void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st);
+// Mode C: 32-byte little-endian elements, must be canonical (else status[blob] = BADARGS) -> Montgomery Fr
+void launch_parse_le_canonical(const uint8_t *blobs, Fr *out_mont, int32_t *status, size_t n_blobs, hipStream_t st);
+
+// ---- MSM (msm.hip)
+void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *bucket_start, uint32_t *perm,
+                       size_t n_blobs, hipStream_t st);
+void launch_bucket_accumulate(const G1Affine *table, const uint32_t *sorted, const uint32_t *bucket_start,
+                              const uint32_t *perm, G1Xyzz *buckets, size_t n_blobs, hipStream_t st);
+void launch_bucket_reduce(const G1Xyzz *buckets, G1Xyzz *sums, size_t n_blobs, hipStream_t st);
+// sums -> 48-byte compressed points (compress_g1_point, /root/reference/src/compression.rs:33-60)
+void launch_finalize_compress(const G1Xyzz *sums, uint8_t *out48, size_t n, hipStream_t st);
+
+// ---- setup (setup.hip)
+// 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check
+void launch_g1_decompress(const uint8_t *in48, G1Affine *out, int32_t *status, size_t n, int subgroup_check,
+                          hipStream_t st);
+// reference blst_p1 (canonical big-endian-limb x, y; z ignored) -> affine Montgomery, curve check
+// (blst_p1_to_g1_point, /root/reference/src/srs.rs:155-172)
+void launch_g1_from_blst(const uint64_t *blst_p1, G1Affine *out, int32_t *status, size_t n, hipStream_t st);
+// affine Montgomery -> reference blst_p1 layout (g1_point_to_blst_p1, /root/reference/src/srs.rs:131-153)
+void launch_g1_to_blst(const G1Affine *in, const int32_t *status, uint64_t *blst_p1, size_t n, hipStream_t st);
+// T[j][i] = 2^(13 j) P_i
+void launch_build_table(const G1Affine *points, G1Affine *table, hipStream_t st);
+
+// ---- Fr (fr_ops.hip)
+// twiddle table: w^-k (inverse) and w^k (forward), k < 2048, Montgomery; built once on device
+void launch_build_twiddles(Fr *tw_fwd, Fr *tw_inv, hipStream_t st);
+// in-place-in-LDS 4096-point radix-2 DIT over Fr. Input is consumed in the order given
+// (bit-reversed-order input -> natural-order output). `scale_raw_out`: if set, output is multiplied by
+// 4096^-1 and written as canonical raw limbs; otherwise Montgomery.
+void launch_ntt4096(const Fr *in, Fr *out, const Fr *tw, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st);
+void launch_bitrev_permute(const Fr *in, Fr *out, size_t n_blobs, hipStream_t st);
+void launch_fr_be_to_mont(const uint8_t *in_be, Fr *out, size_t n_elems, hipStream_t st);
+void launch_fr_mont_to_be(const Fr *in, uint8_t *out_be, size_t n_elems, hipStream_t st);
+void launch_raw_to_be(const uint32_t *raw, uint8_t *out_be, size_t n_elems, hipStream_t st);
+// y = p(z) and q = (p - y)/(x - z) per blob (Polynomial::evaluate + ruffini_division, call sites
+// /root/reference/src/lib.rs:320,329,389,394). coeffs_raw/quot_raw: canonical limbs. y_out: 32 bytes,
+// big-endian (le = 0) or little-endian (le = 1); may be NULL.
+void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
+                          size_t n_blobs, hipStream_t st);
+// z bytes -> Montgomery. le = 0: big-endian, reduced. le = 1: little-endian, must be canonical else BADARGS.
+void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, int le, size_t n, hipStream_t st);
+
+// ---- Fiat-Shamir (sha256.hip)
+// validate + canonicalise commitments (decompress incl. subgroup check, recompress), then
+// z = sha256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blob | commitment) as Fr
+// (compute_challenge, /root/reference/src/utils.rs:120-154).
+void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
+                                 hipStream_t st);
+void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st);
+
+}  // namespace lwk

@@ -1,0 +1,328 @@
+// msm.hip -- batched fixed-base Pippenger G1 MSM for gfx950 (MI355X).
+//
+// Replaces lambdaworks_math::msm::pippenger::msm as reached from KZG::commit / KZG::open
+// (call sites /root/reference/src/lib.rs:242,270,329,394) for 4096-term MSMs over the trusted
+// setup. Not a port of the upstream loop (one sequential window at a time, projective adds into a
+// heap Vec): see plan.h for the shape. Stages, each its own kernel, all blobs of a batch at once:
+//
+//   k_parse_*          blob bytes -> canonical 256-bit scalars                (HBM streaming, 16 B/lane)
+//   k_digit_sort       signed 13-bit digits, LDS histogram + wave64 prefix sum, counting-sort the
+//                      (window, point, sign) entries by bucket; also orders buckets by population
+//   k_bucket_accumulate one lane per bucket, XYZZ accumulator in VGPRs, affine table point gathered
+//                      from the Infinity-Cache-resident table (96 B contiguous per lane)
+//   k_bucket_reduce    sum_k k*B_k per blob: per-lane running sums + LDS suffix scan / tree
+//   k_finalize_compress one inversion per blob, ZCash compression
+//
+// The work is integer-ALU bound (about 1e6 381-bit Montgomery products per blob against 0.5 MB
+// of algorithmic traffic), so the kernels are organised around VGPR residency and wave balance,
+// not around HBM bandwidth; DESIGN.md has the arithmetic.
+#include "kernels.h"
+
+namespace lwk {
+
+// ------------------------------------------------------------------------------------------------
+// scalar ingest
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// one lane per field element; 32 B in (2 x 16 B), 32 B out
+__global__ __launch_bounds__(256) void k_parse_be_reduce(const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                         size_t n_elems) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elems) return;
+    uint4 hi = in[2 * i], lo = in[2 * i + 1];  // big-endian: first 16 bytes are the most significant
+    uint32_t s[8];
+    s[7] = bswap32(hi.x);
+    s[6] = bswap32(hi.y);
+    s[5] = bswap32(hi.z);
+    s[4] = bswap32(hi.w);
+    s[3] = bswap32(lo.x);
+    s[2] = bswap32(lo.y);
+    s[1] = bswap32(lo.z);
+    s[0] = bswap32(lo.w);
+    // reduce mod r: 2^256 < 3r, so at most two subtractions
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        uint32_t d[8];
+        uint32_t br = raw_sub<8>(d, s, FrParams::MOD);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = br ? s[j] : d[j];
+    }
+    out[2 * i] = make_uint4(s[0], s[1], s[2], s[3]);
+    out[2 * i + 1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+__global__ __launch_bounds__(256) void k_parse_le_canonical(const uint4 *__restrict__ in, Fr *__restrict__ out,
+                                                            int32_t *__restrict__ status, size_t n_elems) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elems) return;
+    uint4 lo = in[2 * i], hi = in[2 * i + 1];
+    uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (raw_geq<8>(s, FrParams::MOD)) status[i / kBlobElems] = kStatusBadArgs;  // benign race: same value
+    out[i] = fe_from_raw<FrParams>(s);
+}
+
+void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st) {
+    ProfScope p("k_parse_be_reduce", st);
+    unsigned grid = (unsigned)((n_elems + 255) / 256);
+    hipLaunchKernelGGL(k_parse_be_reduce, dim3(grid), dim3(256), 0, st, (const uint4 *)blobs, (uint4 *)scalars_raw,
+                       n_elems);
+}
+
+void launch_parse_le_canonical(const uint8_t *blobs, Fr *out_mont, int32_t *status, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_parse_le_canonical", st);
+    size_t n_elems = n_blobs * kBlobElems;
+    unsigned grid = (unsigned)((n_elems + 255) / 256);
+    hipLaunchKernelGGL(k_parse_le_canonical, dim3(grid), dim3(256), 0, st, (const uint4 *)blobs, out_mont, status,
+                       n_elems);
+}
+
+// ------------------------------------------------------------------------------------------------
+// digits + counting sort
+
+// window j of a 256-bit little-endian-limb scalar (j, and so every index below, is a compile-time
+// constant after unrolling)
+template <int J>
+__device__ __forceinline__ uint32_t window_bits(const uint32_t *s) {
+    constexpr int o = J * kWindowBits;
+    constexpr int limb = o >> 5;
+    constexpr int sh = o & 31;
+    uint32_t v = s[limb] >> sh;
+    if constexpr (sh + kWindowBits > 32 && limb + 1 < 8) v |= s[limb + 1] << (32 - sh);
+    return v & ((1u << kWindowBits) - 1);
+}
+
+// calls f(j, bucket_index, negative) for every non-zero signed digit of s
+template <int J, class F>
+__device__ __forceinline__ void for_each_digit(const uint32_t *s, uint32_t carry, F &&f) {
+    if constexpr (J < kNumWindows) {
+        uint32_t raw = window_bits<J>(s) + carry;
+        uint32_t neg = raw > (1u << (kWindowBits - 1)) ? 1u : 0u;
+        uint32_t mag = neg ? (1u << kWindowBits) - raw : raw;  // 0 .. 2^(c-1)
+        if (mag) f(J, mag - 1, neg);
+        for_each_digit<J + 1>(s, neg, f);
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+constexpr int kSortThreads = 1024;
+constexpr int kBucketsPerSortThread = kNumBuckets / kSortThreads;  // 4
+constexpr int kScalarsPerSortThread = kBlobElems / kSortThreads;   // 4
+static_assert(kNumBuckets % kSortThreads == 0 && kBlobElems % kSortThreads == 0, "sort tiling");
+
+// one workgroup (16 waves) per blob
+__global__ __launch_bounds__(kSortThreads) void k_digit_sort(const uint4 *__restrict__ scalars,
+                                                             uint32_t *__restrict__ sorted,
+                                                             uint32_t *__restrict__ bucket_start,
+                                                             uint32_t *__restrict__ perm) {
+    __shared__ uint32_t cnt[kNumBuckets];  // histogram, then scatter cursors
+    __shared__ uint32_t wave_tot[kSortThreads / 64];
+    __shared__ uint32_t pop_hist[256];  // buckets per (clamped) population
+    __shared__ uint32_t pop_cur[256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const size_t blob = blockIdx.x;
+    const uint4 *sc = scalars + blob * (size_t)kBlobElems * 2;
+
+    for (int k = tid; k < kNumBuckets; k += kSortThreads) cnt[k] = 0;
+    if (tid < 256) pop_hist[tid] = 0;
+    __syncthreads();
+
+    uint32_t s[kScalarsPerSortThread][8];
+#pragma unroll
+    for (int q = 0; q < kScalarsPerSortThread; q++) {
+        int e = q * kSortThreads + tid;
+        uint4 lo = sc[2 * e], hi = sc[2 * e + 1];
+        s[q][0] = lo.x; s[q][1] = lo.y; s[q][2] = lo.z; s[q][3] = lo.w;
+        s[q][4] = hi.x; s[q][5] = hi.y; s[q][6] = hi.z; s[q][7] = hi.w;
+        for_each_digit<0>(s[q], 0u, [&](int, uint32_t b, uint32_t) { atomicAdd(&cnt[b], 1u); });
+    }
+    __syncthreads();
+
+    // exclusive prefix sum over the 4096 bucket counts: 4 per lane, wave64 shuffle scan, 16 wave totals
+    uint32_t c[kBucketsPerSortThread];
+    uint32_t local = 0;
+#pragma unroll
+    for (int k = 0; k < kBucketsPerSortThread; k++) {
+        c[k] = cnt[tid * kBucketsPerSortThread + k];
+        local += c[k];
+    }
+    uint32_t incl = wave_inclusive_scan(local, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t t = lane < kSortThreads / 64 ? wave_tot[lane] : 0u;
+        uint32_t ti = wave_inclusive_scan(t, lane);
+        if (lane < kSortThreads / 64) wave_tot[lane] = ti - t;  // exclusive
+    }
+    __syncthreads();
+    uint32_t base = wave_tot[wave] + incl - local;
+    uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
+#pragma unroll
+    for (int k = 0; k < kBucketsPerSortThread; k++) {
+        int b = tid * kBucketsPerSortThread + k;
+        bs[b] = base;
+        cnt[b] = base;
+        base += c[k];
+        atomicAdd(&pop_hist[c[k] > 255u ? 255u : c[k]], 1u);
+    }
+    if (tid == kSortThreads - 1) bs[kNumBuckets] = base;
+    __syncthreads();
+
+    // order buckets by descending population so that the 64 lanes of an accumulate wave get
+    // near-equal trip counts (counting sort on the clamped population)
+    if (tid < 256) {
+        uint32_t before = 0;
+        for (int k = tid + 1; k < 256; k++) before += pop_hist[k];
+        pop_cur[tid] = before;
+    }
+    __syncthreads();
+    uint32_t *pm = perm + blob * (size_t)kNumBuckets;
+#pragma unroll
+    for (int k = 0; k < kBucketsPerSortThread; k++) {
+        uint32_t pos = atomicAdd(&pop_cur[c[k] > 255u ? 255u : c[k]], 1u);
+        pm[pos] = (uint32_t)(tid * kBucketsPerSortThread + k);
+    }
+
+    // scatter: entry = window * 4096 + point (the table index), sign in bit 31
+    uint32_t *out = sorted + blob * (size_t)kMaxEntries;
+#pragma unroll
+    for (int q = 0; q < kScalarsPerSortThread; q++) {
+        uint32_t e = (uint32_t)(q * kSortThreads + tid);
+        for_each_digit<0>(s[q], 0u, [&](int j, uint32_t b, uint32_t neg) {
+            uint32_t pos = atomicAdd(&cnt[b], 1u);
+            out[pos] = ((uint32_t)j * kBlobElems + e) | (neg ? kEntryNegBit : 0u);
+        });
+    }
+}
+
+void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *bucket_start, uint32_t *perm,
+                       size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_digit_sort", st);
+    hipLaunchKernelGGL(k_digit_sort, dim3((unsigned)n_blobs), dim3(kSortThreads), 0, st, (const uint4 *)scalars_raw,
+                       sorted, bucket_start, perm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket accumulation: THE hot kernel
+
+constexpr int kAccThreads = 256;
+
+__global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine *__restrict__ table,
+                                                                   const uint32_t *__restrict__ sorted,
+                                                                   const uint32_t *__restrict__ bucket_start,
+                                                                   const uint32_t *__restrict__ perm,
+                                                                   G1Xyzz *__restrict__ buckets) {
+    const size_t blob = blockIdx.y;
+    const int t = blockIdx.x * kAccThreads + threadIdx.x;  // rank in the population order
+    const uint32_t b = perm[blob * (size_t)kNumBuckets + t];
+    const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t begin = bs[b], end = bs[b + 1];
+    const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
+
+    G1Xyzz acc = G1Xyzz::infinity();
+    for (uint32_t k = begin; k < end; k++) {
+        uint32_t e = ent[k];
+        G1Affine p = table[e & ~kEntryNegBit];
+        if (e & kEntryNegBit) p.y = neg(p.y);
+        acc = xyzz_madd(acc, p);
+    }
+    buckets[blob * (size_t)kNumBuckets + b] = acc;
+}
+
+void launch_bucket_accumulate(const G1Affine *table, const uint32_t *sorted, const uint32_t *bucket_start,
+                              const uint32_t *perm, G1Xyzz *buckets, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_bucket_accumulate", st);
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3(kNumBuckets / kAccThreads, (unsigned)n_blobs), dim3(kAccThreads), 0,
+                       st, table, sorted, bucket_start, perm, buckets);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket reduction: S = sum_{k=1..NB} k * B_k per blob
+
+constexpr int kRedThreads = 256;
+constexpr int kBucketsPerRedThread = kNumBuckets / kRedThreads;  // 16
+static_assert((kBucketsPerRedThread & (kBucketsPerRedThread - 1)) == 0, "chunk must be a power of two");
+
+__global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz *__restrict__ buckets,
+                                                               G1Xyzz *__restrict__ sums) {
+    __shared__ G1Xyzz sh[kRedThreads];
+    const int t = threadIdx.x;
+    const size_t blob = blockIdx.x;
+    const G1Xyzz *B = buckets + blob * (size_t)kNumBuckets + (size_t)t * kBucketsPerRedThread;
+
+    // lane t owns bucket values k = t*16 + 1 .. t*16 + 16:
+    //   run = sum B_k,  wsum = sum (k - t*16) B_k     (descending running sums)
+    G1Xyzz run = G1Xyzz::infinity(), wsum = G1Xyzz::infinity();
+    for (int k = kBucketsPerRedThread - 1; k >= 0; k--) {
+        run = xyzz_add(run, B[k]);
+        wsum = xyzz_add(wsum, run);
+    }
+    // total = sum_t wsum_t + 16 * sum_t t * run_t, and sum_t t*run_t = sum_{t>=1} (suffix sum of run)_t
+    sh[t] = run;
+    __syncthreads();
+    for (int d = 1; d < kRedThreads; d <<= 1) {
+        G1Xyzz other = (t + d < kRedThreads) ? sh[t + d] : G1Xyzz::infinity();
+        __syncthreads();
+        run = xyzz_add(run, other);
+        sh[t] = run;
+        __syncthreads();
+    }
+    // tree-sum the suffix sums over t >= 1
+    sh[t] = (t >= 1) ? run : G1Xyzz::infinity();
+    __syncthreads();
+    for (int d = kRedThreads / 2; d >= 1; d >>= 1) {
+        if (t < d) sh[t] = xyzz_add(sh[t], sh[t + d]);
+        __syncthreads();
+    }
+    G1Xyzz hi = sh[0];
+    __syncthreads();
+    // tree-sum the weighted sums
+    sh[t] = wsum;
+    __syncthreads();
+    for (int d = kRedThreads / 2; d >= 1; d >>= 1) {
+        if (t < d) sh[t] = xyzz_add(sh[t], sh[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        for (int k = 1; k < kBucketsPerRedThread; k <<= 1) hi = xyzz_dbl(hi);
+        sums[blob] = xyzz_add(sh[0], hi);
+    }
+}
+
+void launch_bucket_reduce(const G1Xyzz *buckets, G1Xyzz *sums, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_bucket_reduce", st);
+    hipLaunchKernelGGL(k_bucket_reduce, dim3((unsigned)n_blobs), dim3(kRedThreads), 0, st, buckets, sums);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: affine + ZCash compression, one lane per result
+
+__global__ __launch_bounds__(64) void k_finalize_compress(const G1Xyzz *__restrict__ sums, uint8_t *__restrict__ out48,
+                                                          size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t b[48];
+    g1_compress(b, sums[i]);
+    uint32_t *o = (uint32_t *)(out48 + 48 * i);
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        o[k] = (uint32_t)b[4 * k] | ((uint32_t)b[4 * k + 1] << 8) | ((uint32_t)b[4 * k + 2] << 16) |
+               ((uint32_t)b[4 * k + 3] << 24);
+}
+
+void launch_finalize_compress(const G1Xyzz *sums, uint8_t *out48, size_t n, hipStream_t st) {
+    ProfScope p("k_finalize_compress", st);
+    hipLaunchKernelGGL(k_finalize_compress, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, sums, out48, n);
+}
+
+}  // namespace lwk

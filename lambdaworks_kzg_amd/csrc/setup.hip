@@ -1,0 +1,120 @@
+// setup.hip -- trusted-setup load path on the GPU.
+//
+// Replaces the reference's per-point CPU loop in load_trusted_setup_file / load_trusted_setup
+// (/root/reference/src/srs.rs:56-79, src/lib.rs:728-741): 4096 x (Fp sqrt + 255-bit scalar
+// multiplication by r) is the slowest thing the reference does after the MSM and is embarrassingly
+// parallel -- one lane per point here. Also replaces the per-call SRS rebuild
+// kzgsettings_to_structured_reference_string (/root/reference/src/srs.rs:258-280): the device
+// table is built once and cached in the settings' context.
+#include "kernels.h"
+
+namespace lwk {
+
+__global__ __launch_bounds__(64) void k_g1_decompress(const uint8_t *__restrict__ in48, G1Affine *__restrict__ out,
+                                                      int32_t *__restrict__ status, size_t n, int subgroup_check) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t b[48];
+    const uint32_t *src = (const uint32_t *)(in48 + 48 * i);
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint32_t w = src[k];
+        b[4 * k] = (uint8_t)w;
+        b[4 * k + 1] = (uint8_t)(w >> 8);
+        b[4 * k + 2] = (uint8_t)(w >> 16);
+        b[4 * k + 3] = (uint8_t)(w >> 24);
+    }
+    G1Affine p;
+    p.x = Fp::zero();
+    p.y = Fp::zero();
+    int rc = g1_decompress_nocheck(p, b);
+    if (rc == 0 && subgroup_check && !g1_in_subgroup(p)) rc = 2;
+    out[i] = p;
+    status[i] = rc;
+}
+
+void launch_g1_decompress(const uint8_t *in48, G1Affine *out, int32_t *status, size_t n, int subgroup_check,
+                          hipStream_t st) {
+    ProfScope p("k_g1_decompress", st);
+    hipLaunchKernelGGL(k_g1_decompress, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in48, out, status, n,
+                       subgroup_check);
+}
+
+// reference blst_fp: 6 x u64, most-significant limb first, canonical integer
+__device__ __forceinline__ void blst_fp_to_raw(uint32_t raw[12], const uint64_t *l) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint64_t v = l[5 - k];
+        raw[2 * k] = (uint32_t)v;
+        raw[2 * k + 1] = (uint32_t)(v >> 32);
+    }
+}
+__device__ __forceinline__ void raw_to_blst_fp(uint64_t *l, const uint32_t raw[12]) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) l[5 - k] = (uint64_t)raw[2 * k] | ((uint64_t)raw[2 * k + 1] << 32);
+}
+
+__global__ __launch_bounds__(64) void k_g1_from_blst(const uint64_t *__restrict__ in, G1Affine *__restrict__ out,
+                                                     int32_t *__restrict__ status, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *p = in + 18 * i;
+    uint32_t rx[12], ry[12];
+    blst_fp_to_raw(rx, p);
+    blst_fp_to_raw(ry, p + 6);
+    G1Affine a;
+    a.x = fe_from_raw<FpParams>(rx);
+    a.y = fe_from_raw<FpParams>(ry);
+    out[i] = a;
+    status[i] = g1_on_curve(a) ? 0 : 2;  // from_affine's curve check; z is ignored (srs.rs:155-172)
+}
+
+void launch_g1_from_blst(const uint64_t *blst_p1, G1Affine *out, int32_t *status, size_t n, hipStream_t st) {
+    ProfScope p("k_g1_from_blst", st);
+    hipLaunchKernelGGL(k_g1_from_blst, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blst_p1, out, status, n);
+}
+
+__global__ __launch_bounds__(64) void k_g1_to_blst(const G1Affine *__restrict__ in, const int32_t *__restrict__ status,
+                                                   uint64_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t *o = out + 18 * i;
+    if (status && status[i] == 1) {  // neutral element: x = y = 0, z = [0,0,0,0,0,1] (srs.rs:132-140)
+        for (int k = 0; k < 18; k++) o[k] = 0;
+        o[17] = 1;
+        return;
+    }
+    uint32_t raw[12];
+    fe_to_raw<FpParams>(raw, in[i].x);
+    raw_to_blst_fp(o, raw);
+    fe_to_raw<FpParams>(raw, in[i].y);
+    raw_to_blst_fp(o + 6, raw);
+    for (int k = 12; k < 17; k++) o[k] = 0;
+    o[17] = 1;  // z = 1 (from_affine)
+}
+
+void launch_g1_to_blst(const G1Affine *in, const int32_t *status, uint64_t *blst_p1, size_t n, hipStream_t st) {
+    ProfScope p("k_g1_to_blst", st);
+    hipLaunchKernelGGL(k_g1_to_blst, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in, status, blst_p1, n);
+}
+
+// T[j][i] = 2^(13 j) * P_i, affine. One lane per point walks its 20 windows.
+__global__ __launch_bounds__(64) void k_build_table(const G1Affine *__restrict__ points, G1Affine *__restrict__ table) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kBlobElems) return;
+    G1Affine a = points[i];
+    table[i] = a;
+    G1Xyzz cur = G1Xyzz::from_affine(a);
+    for (int j = 1; j < kNumWindows; j++) {
+        for (int d = 0; d < kWindowBits; d++) cur = xyzz_dbl(cur);
+        // P has prime order r and 2^(13 j) is a unit mod r, so cur is never the point at infinity
+        table[(size_t)j * kBlobElems + i] = xyzz_to_affine(cur);
+    }
+}
+
+void launch_build_table(const G1Affine *points, G1Affine *table, hipStream_t st) {
+    ProfScope p("k_build_table", st);
+    hipLaunchKernelGGL(k_build_table, dim3(kBlobElems / 64), dim3(64), 0, st, points, table);
+}
+
+}  // namespace lwk

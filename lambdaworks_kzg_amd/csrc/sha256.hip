@@ -1,0 +1,144 @@
+// sha256.hip -- Fiat-Shamir challenge on the GPU.
+//
+// compute_challenge (/root/reference/src/utils.rs:120-144) hashes
+//     "FSBLOBVERIFY_V1_" | usize(4096) LE | u64(0) LE | blob (131072 B) | compress(commitment) (48 B)
+// = 131,152 bytes with SHA-256 and reads the digest as a field element (hash_field_unsafe,
+// utils.rs:148-154: big-endian, reduced mod r; the c-kzg-4844 vectors read it little-endian).
+// The reference builds that 131 KB Vec byte by byte on the host for every blob; here the blob is
+// already in HBM, so one lane per blob streams it through the compression function (16 B loads).
+// SHA-256 is sequential per message: the parallelism is across the blobs of the batch.
+#include "kernels.h"
+
+namespace lwk {
+
+__device__ __constant__ uint32_t kShaK[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+// w[16] holds the block as big-endian words
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t wi;
+        if (i < 16) {
+            wi = w[i];
+        } else {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            w[i & 15] = wi;
+        }
+        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + kShaK[i] + wi;
+        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// The 131,152-byte message as 8,200 16-byte chunks (with padding): chunk q ->
+//   0..1      header  ("FSBLOBVERIFY_V1_", le64(4096) le64(0))
+//   2..8193   blob
+//   8194..8196 commitment
+//   8197      0x80 then zeros, 8198 zeros, 8199 zeros + 64-bit big-endian bit length
+__device__ __forceinline__ uint4 challenge_chunk(int q, const uint4 *blob, const uint4 *comm) {
+    if (q >= 2 && q < 2 + kBlobBytes / 16) {
+        uint4 v = blob[q - 2];
+        return make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    }
+    if (q == 0) return make_uint4(0x4653424cu, 0x4f425645u, 0x52494659u, 0x5f56315fu);  // "FSBL" "OBVE" "RIFY" "_V1_"
+    if (q == 1) return make_uint4(0x00100000u, 0u, 0u, 0u);                             // 4096 little-endian, then 0
+    if (q < 2 + kBlobBytes / 16 + 3) {
+        uint4 v = comm[q - 2 - kBlobBytes / 16];
+        return make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+    }
+    constexpr int kPad0 = 2 + kBlobBytes / 16 + 3;
+    if (q == kPad0) return make_uint4(0x80000000u, 0u, 0u, 0u);
+    if (q == kPad0 + 2) return make_uint4(0u, 0u, 0u, (uint32_t)((kBlobBytes + 80) * 8));  // 1,049,216 bits
+    return make_uint4(0u, 0u, 0u, 0u);
+}
+
+__global__ __launch_bounds__(64) void k_challenge(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
+                                                  Fr *__restrict__ z_mont, int le, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *blob = (const uint4 *)(blobs + (size_t)kBlobBytes * i);
+    const uint4 *comm = (const uint4 *)(canon48 + 48 * i);
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    constexpr int kBlocks = (2 + kBlobBytes / 16 + 3 + 3) / 4;  // 2050
+    for (int blk = 0; blk < kBlocks; blk++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint4 v = challenge_chunk(4 * blk + c, blob, comm);
+            w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+        }
+        sha256_compress(h, w);
+    }
+    // digest bytes d[0..32) = big-endian h[0..8)
+    uint32_t s[8];
+    if (le) {
+        // little-endian integer: limb k = bytes 4k..4k+3 little-endian = bswap(h[k])
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = __builtin_bswap32(h[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = h[7 - k];
+    }
+    z_mont[i] = fe_from_raw<FrParams>(s);  // reduced mod r
+}
+
+void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st) {
+    ProfScope p("k_challenge", st);
+    hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blobs, canon48, z_mont, le, n);
+}
+
+// decompress_g1_point (incl. [r]P subgroup check) then compress_g1_point again, as
+// compute_blob_kzg_proof + compute_challenge do (/root/reference/src/lib.rs:372-375, src/utils.rs:138).
+__global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__restrict__ comm48,
+                                                             uint8_t *__restrict__ canon48, int32_t *__restrict__ status,
+                                                             int bad_code, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t b[48];
+    for (int k = 0; k < 48; k++) b[k] = comm48[48 * i + k];
+    G1Affine p;
+    p.x = Fp::zero();
+    p.y = Fp::zero();
+    int rc = g1_decompress_nocheck(p, b);
+    uint8_t o[48];
+    if (rc == 0) {
+        if (!g1_in_subgroup(p)) rc = 2;
+        else g1_compress_affine(o, p);
+    } else if (rc == 1) {
+        for (int k = 0; k < 48; k++) o[k] = 0;
+        o[0] = 0xc0;
+    }
+    if (rc == 2) {
+        status[i] = bad_code;
+        for (int k = 0; k < 48; k++) o[k] = 0;
+    }
+    for (int k = 0; k < 48; k++) canon48[48 * i + k] = o[k];
+}
+
+void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
+                                 hipStream_t st) {
+    ProfScope p("k_validate_commitments", st);
+    hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, comm48, canon48, status,
+                       bad_code, n);
+}
+
+}  // namespace lwk

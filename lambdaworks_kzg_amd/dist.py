@@ -1,0 +1,66 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+SURVEY section 8e: batches of blobs are independent units -> contiguous shards, every GPU holds the full
+setup, NO data-path collective. The only collective is ONE broadcast of the prepared setup image
+(g1_values | g2_values | fixed-base table | twiddles, about 8.6 MB) from the rank that loaded and
+validated the trusted setup, over xGMI. torch is plumbing here (device memory + the process group).
+"""
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous partition: item k belongs to rank floor(k * world_size / n_items).
+    Returns (start, count) for `rank`; the shards cover [0, n_items) exactly once."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    start = -(-rank * n_items // world_size)          # ceil(rank * n / G)
+    end = -(-(rank + 1) * n_items // world_size)
+    return start, end - start
+
+
+def owner_of(item, n_items, world_size):
+    return item * world_size // n_items
+
+
+def broadcast_bytes(buf, src=0, group=None):
+    """Broadcast a uint8 tensor in place (CPU tensor under gloo, device tensor under RCCL)."""
+    if buf.dtype != torch.uint8:
+        raise TypeError("broadcast_bytes expects a uint8 tensor")
+    dist.broadcast(buf, src=src, group=group)
+    return buf
+
+
+def broadcast_trusted_setup(ts, device, src=0, group=None):
+    """Rank `src` passes its loaded TrustedSetup, every other rank passes None.
+    Returns a TrustedSetup usable on this rank's GPU. One RCCL broadcast, no other traffic."""
+    rank = dist.get_rank(group)
+    nbytes = capi.setup_image_bytes()
+    image = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if rank == src:
+        if ts is None:
+            raise ValueError("source rank must hold a loaded trusted setup")
+        ts.export_device_image(image.data_ptr())
+    broadcast_bytes(image, src=src, group=group)
+    if rank == src:
+        return ts
+    torch.cuda.synchronize(device)
+    out = capi.TrustedSetup.from_device_image(image.data_ptr())
+    return out
+
+
+def gather_shards(local, n_items, item_bytes, group=None):
+    """All ranks contribute their shard's result bytes (uint8 tensor, count x item_bytes); every rank
+    gets the full n_items x item_bytes tensor in item order. Used by tests and by callers that want
+    results in one place; the bench does not need it."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [shard_range(n_items, world, r)[1] for r in range(world)]
+    mx = max(counts) if counts else 0
+    pad = torch.zeros(mx * item_bytes, dtype=torch.uint8, device=local.device)
+    pad[: counts[rank] * item_bytes] = local.reshape(-1)[: counts[rank] * item_bytes]
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([parts[r][: counts[r] * item_bytes] for r in range(world)])

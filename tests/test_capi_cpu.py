@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads, exports every symbol include/lambdaworks_kzg_amd.h declares, has the
+reference's struct layouts, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, SETUP_PATH
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "lambdaworks_kzg_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(?:C_KZG_RET|int|size_t|void|const char \*)\s*\*?\s*([a-z_0-9]+)\s*\(", src)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_and_binding_agree(K):
+    from lambdaworks_kzg_amd import capi
+    declared = _declared_functions()
+    assert len(declared) >= 30
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+
+
+def test_library_exports_every_declared_symbol(K):
+    l = K.lib()
+    for name in _declared_functions():
+        assert hasattr(l, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "lambdaworks_kzg_amd", "lib",
+                                                                              "liblambdaworks_kzg.so")]).decode()
+    exported = set(re.findall(r" T ([A-Za-z_0-9]+)", out))
+    assert set(_declared_functions()) <= exported
+    # nothing of the oracle leaks into the product
+    assert not any(s.startswith("orc_") for s in exported)
+
+
+def test_product_does_not_reference_oracle():
+    pkg = os.path.join(ROOT, "lambdaworks_kzg_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in txt.replace("TEST INFRASTRUCTURE", ""), os.path.join(dp, f)
+
+
+def test_header_compiles_as_c_and_layouts_match_reference(tmp_path):
+    # sizes from /root/reference/src/lib.rs:103-232 (blst_p1 144 B, blst_p2 288 B, Blob 131072 B, three pointers)
+    src = tmp_path / "t.c"
+    src.write_text('#include "lambdaworks_kzg_amd.h"\n#include <stdio.h>\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(blst_fp), sizeof(blst_p1),'
+                   'sizeof(blst_p2), sizeof(Blob), sizeof(KZGSettings), sizeof(FFTSettings), sizeof(Bytes48),'
+                   '(int)C_KZG_MALLOC);return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).split() == [b"48", b"144", b"288", b"131072", b"24", b"32", b"48", b"3"]
+
+
+def test_mode_switch(K):
+    prev = K.set_mode(K.MODE_CKZG)
+    assert K.get_mode() == K.MODE_CKZG
+    assert K.set_mode(7) == -1 and K.get_mode() == K.MODE_CKZG
+    K.set_mode(prev)
+    assert K.get_mode() == prev
+
+
+def test_argument_checks_need_no_gpu(K):
+    l = K.lib()
+    s = K.KZGSettings()
+    # lib.rs:716-718: wrong counts are the reference's only BADARGS
+    assert l.load_trusted_setup(C.byref(s), b"\0" * 48, 1, b"\0" * 96, 1) == K.C_KZG_BADARGS
+    ok = C.c_bool(True)
+    # lib.rs:538-543: n == 0 -> OK with ok = false
+    assert l.verify_blob_kzg_proof_batch(C.byref(ok), None, None, None, 0, C.byref(s)) == K.C_KZG_OK
+    assert ok.value is False
+
+
+def test_fails_loudly_without_gpu(K):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(K.KzgError) as e:
+        K.TrustedSetup.from_file(SETUP_PATH)
+    assert e.value.rc == K.C_KZG_ERROR and "no CPU fallback" in str(e.value)

@@ -1,0 +1,74 @@
+"""CPU: the multi-GPU layer's host logic -- contiguous sharding and the setup-image broadcast /
+result gather -- with world_size 2 over gloo (the GPU path uses the same code over RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lambdaworks_kzg_amd import dist as D
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 2, 7, 8, 9, 64, 1000, 1024, 4096):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                start, count = D.shard_range(n, world, r)
+                assert count >= 0
+                seen.extend(range(start, start + count))
+                for k in range(start, start + count):
+                    assert D.owner_of(k, n, world) == r      # blob k -> GPU floor(k * G / B), SURVEY 8e
+            assert seen == list(range(n))
+            counts = [D.shard_range(n, world, r)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+
+
+def test_shard_range_rejects_bad_rank():
+    with pytest.raises(ValueError):
+        D.shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the "setup image": rank 0 owns the bytes, everyone ends up with them (one broadcast)
+        img = torch.arange(4096, dtype=torch.int64).to(torch.uint8) if rank == 0 else torch.zeros(4096, dtype=torch.uint8)
+        D.broadcast_bytes(img, src=0)
+        ok_img = bool((img == torch.arange(4096, dtype=torch.int64).to(torch.uint8)).all())
+        # every rank "commits" its own shard: result of item k is 48 bytes of value k % 251
+        start, count = D.shard_range(n_items, world, rank)
+        local = torch.stack([torch.full((48,), k % 251, dtype=torch.uint8) for k in range(start, start + count)]) \
+            if count else torch.zeros((0, 48), dtype=torch.uint8)
+        full = D.gather_shards(local, n_items, 48)
+        want = torch.stack([torch.full((48,), k % 251, dtype=torch.uint8) for k in range(n_items)]).reshape(-1)
+        q.put((rank, ok_img, bool((full == want).all())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [5, 8])
+def test_world_size_2_broadcast_and_gather(n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)]

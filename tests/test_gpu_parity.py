@@ -1,0 +1,302 @@
+"""GPU: parity of the HIP path (through the C ABI) with the CPU oracle, the committed golden vectors
+and the tau = 1337 closed form. Bit-exact: every output is a canonical byte encoding."""
+import ctypes as C
+import random
+
+import pytest
+
+import blobs as B
+from conftest import R, TAU, hx, tau_closed_form
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(data):
+    import torch
+    return torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+
+
+def _host(t):
+    return bytes(t.cpu().numpy().tobytes())
+
+
+@pytest.fixture(autouse=True)
+def _reference_mode(K):
+    K.set_mode(K.MODE_REFERENCE)
+    yield
+    K.set_mode(K.MODE_REFERENCE)
+
+
+# ---- setup load (a12, a13, a14) --------------------------------------------------------------------
+
+def test_setup_load_matches_reference_layout(K, gpu_setup, oracle, oracle_setup):
+    # g1_point_to_blst_p1 (srs.rs:131-153) bytes, produced by GPU decompression of all 4096 points
+    assert gpu_setup.g1_values_bytes() == oracle_setup.g1_blst()
+    fs = gpu_setup.fft_settings()
+    assert fs.max_width == 4096
+    w = pow(7, (R - 1) // 4096, R)
+    import struct
+    def fr_at(ptr, i):
+        l = struct.unpack("<4Q", C.string_at(ptr + 32 * i, 32))
+        return (l[0] << 192) | (l[1] << 128) | (l[2] << 64) | l[3]
+    for i in (0, 1, 2, 2047, 2048, 4095, 4096):
+        assert fr_at(fs.expanded_roots_of_unity, i) == pow(w, i, R)
+        assert fr_at(fs.reverse_roots_of_unity, i) == pow(w, -i, R)
+    assert fr_at(fs.roots_of_unity, 1) == pow(w, 2048, R)   # bit-reversed order
+
+
+def test_setup_from_bytes_and_bad_inputs(K, oracle_setup):
+    g1, g2 = oracle_setup.g1_compressed(), oracle_setup.g2_compressed()
+    ts = K.TrustedSetup.from_bytes(g1, g2)
+    assert ts.g1_values_bytes() == oracle_setup.g1_blst()
+    ts.free()
+    bad = bytearray(g1)
+    bad[48 * 7 + 20] ^= 1                                   # x no longer on the curve / wrong subgroup
+    with pytest.raises(K.KzgError) as e:
+        K.TrustedSetup.from_bytes(bytes(bad), g2)
+    assert e.value.rc == K.C_KZG_ERROR
+    notsub = bytearray(g1)
+    notsub[48:96] = bytes([0x80]) + bytes(47)               # (0, 2): on the curve, not in G1 (compression.rs:155-165)
+    with pytest.raises(K.KzgError):
+        K.TrustedSetup.from_bytes(bytes(notsub), g2)
+
+
+def test_hand_built_settings_without_context(K, gpu_setup, oracle, oracle_setup):
+    # a caller may fill KZGSettings itself (fs = NULL), exactly the reference's own layout (lib.rs:754-758)
+    s = K.KZGSettings()
+    g1 = C.create_string_buffer(oracle_setup.g1_blst())
+    s.fs, s.g1_values, s.g2_values = None, C.cast(g1, C.c_void_p), gpu_setup.s.g2_values
+    blob = B.synthetic_blob(3)
+    out = C.create_string_buffer(48)
+    assert K.lib().blob_to_kzg_commitment(out, blob, C.byref(s)) == K.C_KZG_OK
+    assert out.raw == oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_R)[1]
+
+
+# ---- stage level: NTT, MSM -------------------------------------------------------------------------
+
+def test_ntt_kernel_vs_oracle(K, gpu_setup, oracle):
+    import torch
+    from lambdaworks_kzg_amd import capi
+    rnd = random.Random(11)
+    vecs = [b"".join(rnd.randrange(R).to_bytes(32, "big") for _ in range(4096)) for _ in range(3)]
+    vecs.append(b"".join((R - 1).to_bytes(32, "big") for _ in range(4096)))
+    d_in = _dev(b"".join(vecs))
+    d_out = torch.empty_like(d_in)
+    for inverse in (False, True):
+        capi.fr_ntt4096_device(d_out.data_ptr(), d_in.data_ptr(), len(vecs), inverse, gpu_setup)
+        torch.cuda.synchronize()
+        got = _host(d_out)
+        for i, v in enumerate(vecs):
+            assert got[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB] == oracle.fr_ntt4096(v, inverse=inverse)
+
+
+def test_msm_kernel_vs_oracle_and_closed_form(K, gpu_setup, oracle, oracle_setup):
+    import torch
+    from lambdaworks_kzg_amd import capi
+    rnd = random.Random(12)
+    sets = [[rnd.randrange(R) for _ in range(4096)],
+            [rnd.randrange(1 << 256) for _ in range(4096)],          # non-canonical: reduced mod r
+            [0] * 4096,
+            [1] * 4096,
+            [R - 1] * 4096,                                          # every digit pattern identical
+            [0] * 4095 + [5],
+            [(1 << 12)] * 4096, [(1 << 12) + 1] * 4096,              # signed-digit boundary 2^(c-1) and +1
+            [(1 << 13) - 1] * 4096, [(1 << 255) - 1] * 4096]
+    data = b"".join(b"".join(s.to_bytes(32, "big") for s in ss) for ss in sets)
+    d_in = _dev(data)
+    d_out = torch.empty(48 * len(sets), dtype=torch.uint8, device="cuda")
+    capi.g1_lincomb_setup_device(d_out.data_ptr(), d_in.data_ptr(), len(sets), gpu_setup)
+    torch.cuda.synchronize()
+    got = _host(d_out)
+    for i, ss in enumerate(sets):
+        assert got[48 * i:48 * i + 48] == tau_closed_form(oracle, ss), i
+    # first set also against the oracle's own Pippenger (reference algorithm shape)
+    rc, cm = oracle.blob_to_kzg_commitment(data[:B.BYTES_PER_BLOB], oracle_setup, oracle.MODE_R)
+    assert got[:48] == cm
+
+
+# ---- blob_to_kzg_commitment (a1-a7) ------------------------------------------------------------------
+
+def test_lib_test_rs_behaviours(K, gpu_setup, oracle_setup):
+    g1 = oracle_setup.g1_compressed()
+    one, two = (1).to_bytes(32, "big"), (2).to_bytes(32, "big")
+    blob1 = one + bytes(B.BYTES_PER_BLOB - 32)
+    blobx = bytes(32) + one + bytes(B.BYTES_PER_BLOB - 64)
+    # tests/lib_test.rs:19-87
+    pr, y = K.compute_kzg_proof(blob1, one, gpu_setup)
+    assert pr == bytes([0xc0]) + bytes(47) and y == one
+    # tests/lib_test.rs:89-167
+    pr, y = K.compute_kzg_proof(blobx, two, gpu_setup)
+    assert y == two and pr == g1[:48]
+    assert K.blob_to_kzg_commitment(blobx, gpu_setup) == g1[48:96]
+    assert K.blob_to_kzg_commitment(bytes(B.BYTES_PER_BLOB), gpu_setup) == bytes([0xc0]) + bytes(47)
+
+
+def test_commitment_reference_mode_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+    blobs = [B.synthetic_blob(i) for i in range(5)]
+    blobs += [B.make_blob(n) for n in ("pow2", "pow3", "pow5", "r_minus_1", "delta_3211", "zero", "all_ff", "r_at_2111")]
+    got = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
+    for b, g in zip(blobs, got):
+        rc, want = oracle.blob_to_kzg_commitment(b, oracle_setup, oracle.MODE_R)
+        assert rc == 0 and g == want
+    # single-blob symbol == batch symbol
+    assert K.blob_to_kzg_commitment(blobs[0], gpu_setup) == got[0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64])
+def test_commitment_batch_sizes_closed_form(K, gpu_setup, oracle, n):
+    blobs = [B.synthetic_blob(100 + i) for i in range(n)]
+    got = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
+    for b, g in zip(blobs, got):
+        assert g == tau_closed_form(oracle, B.blob_scalars(b))
+
+
+def test_commitment_ckzg_vectors(K, gpu_setup, vectors):
+    K.set_mode(K.MODE_CKZG)
+    n = 0
+    for c in vectors["suites"]["blob_to_kzg_commitment"]:
+        blob = B.make_blob(c["input"]["blob"])
+        if len(blob) != B.BYTES_PER_BLOB:
+            continue
+        if c["output"] is None:
+            with pytest.raises(K.KzgError) as e:
+                K.blob_to_kzg_commitment(blob, gpu_setup)
+            assert e.value.rc == K.C_KZG_BADARGS
+        else:
+            assert K.blob_to_kzg_commitment(blob, gpu_setup) == hx(c["output"])
+        n += 1
+    assert n == 8
+
+
+def test_ckzg_batch_reports_first_bad(K, gpu_setup):
+    K.set_mode(K.MODE_CKZG)
+    blobs = B.make_blob("pow2") + B.make_blob("pow3") + B.make_blob("r_at_2111") + B.make_blob("all_ff")
+    out = C.create_string_buffer(48 * 4)
+    bad = C.c_size_t(99)
+    rc = K.lib().lwkzg_blob_to_kzg_commitment_batch(out, blobs, 4, gpu_setup.ref(), C.byref(bad))
+    assert rc == K.C_KZG_BADARGS and bad.value == 2
+
+
+# ---- proofs (a8-a11) --------------------------------------------------------------------------------
+
+def test_compute_kzg_proof_ckzg_vectors(K, gpu_setup, vectors):
+    K.set_mode(K.MODE_CKZG)
+    n = 0
+    for c in vectors["suites"]["compute_kzg_proof"]:
+        blob, z = B.make_blob(c["input"]["blob"]), hx(c["input"]["z"])
+        if len(blob) != B.BYTES_PER_BLOB or len(z) != 32:
+            continue
+        if c["output"] is None:
+            with pytest.raises(K.KzgError) as e:
+                K.compute_kzg_proof(blob, z, gpu_setup)
+            assert e.value.rc == K.C_KZG_BADARGS
+        else:
+            pr, y = K.compute_kzg_proof(blob, z, gpu_setup)
+            assert pr == hx(c["output"][0]) and y == hx(c["output"][1])
+        n += 1
+    assert n == 42
+
+
+def test_compute_blob_kzg_proof_ckzg_vectors(K, gpu_setup, vectors):
+    K.set_mode(K.MODE_CKZG)
+    n = 0
+    for c in vectors["suites"]["compute_blob_kzg_proof"]:
+        blob, cm = B.make_blob(c["input"]["blob"]), hx(c["input"]["commitment"])
+        if len(blob) != B.BYTES_PER_BLOB or len(cm) != 48:
+            continue
+        if c["output"] is None:
+            with pytest.raises(K.KzgError) as e:
+                K.compute_blob_kzg_proof(blob, cm, gpu_setup)
+            assert e.value.rc == K.C_KZG_BADARGS
+        else:
+            assert K.compute_blob_kzg_proof(blob, cm, gpu_setup) == hx(c["output"])
+        n += 1
+    assert n == 10
+
+
+def test_proofs_reference_mode_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+    blobs = [B.synthetic_blob(40 + i) for i in range(3)] + [B.make_blob("pow2"), B.make_blob("r_minus_1"), B.make_blob("zero")]
+    comms = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
+    proofs = K.compute_blob_kzg_proof_batch(b"".join(blobs), b"".join(comms), gpu_setup)
+    for b, cm, pr in zip(blobs, comms, proofs):
+        rc, want = oracle.compute_blob_kzg_proof(b, cm, oracle_setup, oracle.MODE_R)
+        assert rc == 0 and pr == want
+    # SURVEY 4.3 smoke value
+    assert proofs[3].hex() == ("b352a02445cc2f74ecf7bdb12380fd2debce3f352407514b8645d940a26079d9"
+                               "b7167c68ac5957dc22c23d2aabbe471b")
+    rnd = random.Random(3)
+    zs = [rnd.randrange(R).to_bytes(32, "big") for _ in blobs]
+    zs[1] = (R + 7).to_bytes(32, "big")            # reference mode reduces z
+    res = K.compute_kzg_proof_batch(b"".join(blobs), b"".join(zs), gpu_setup)
+    for b, z, (pr, y) in zip(blobs, zs, res):
+        rc, wpr, wy = oracle.compute_kzg_proof(b, z, oracle_setup, oracle.MODE_R)
+        assert rc == 0 and pr == wpr and y == wy
+        # and the proof verifies (closed form for the known tau)
+        rc, cm = oracle.blob_to_kzg_commitment(b, oracle_setup, oracle.MODE_R)
+        zz = (int.from_bytes(z, "big") % R).to_bytes(32, "big")
+        assert oracle.verify_kzg_proof_known_tau(cm, zz, y, pr, TAU, oracle.MODE_R) == (0, True)
+
+
+def test_blob_proof_rejects_bad_commitment(K, gpu_setup):
+    blob = B.synthetic_blob(1)
+    for bad in (bytes(48), bytes([0x80]) + bytes(47), bytes([0x9f]) + b"\xff" * 47):
+        with pytest.raises(K.KzgError) as e:
+            K.compute_blob_kzg_proof(blob, bad, gpu_setup)
+        assert e.value.rc == K.C_KZG_ERROR          # reference mode: every failure is C_KZG_ERROR
+    K.set_mode(K.MODE_CKZG)
+    with pytest.raises(K.KzgError) as e:
+        K.compute_blob_kzg_proof(B.make_blob("pow2"), bytes(48), gpu_setup)
+    assert e.value.rc == K.C_KZG_BADARGS
+
+
+# ---- full-size properties (BASELINE config 2: batch up to 1024) ------------------------------------------
+
+def test_batch_1024_device_resident_closed_form_and_determinism(K, gpu_setup, oracle):
+    import numpy as np
+    import torch
+    n = 1024
+    data = B.synthetic_batch(1000, n)
+    d_blobs = _dev(data)
+    d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    d_status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, gpu_setup, None, d_status.data_ptr())
+    torch.cuda.synchronize()
+    first = _host(d_out)
+    assert int(d_status.abs().sum()) == 0
+    # determinism: atomics reorder bucket contents, the canonical output must not change
+    K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, gpu_setup, None, d_status.data_ptr())
+    torch.cuda.synchronize()
+    assert _host(d_out) == first
+    # closed form for a spread of blobs, incl. first/last of the batch
+    for i in (0, 1, 63, 64, 511, 1022, 1023):
+        blob = data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
+        assert first[48 * i:48 * i + 48] == tau_closed_form(oracle, B.blob_scalars(blob)), i
+    # linearity: commit(a) + commit(b) == commit(a + b) -- checked through scalars: blob c = a + b mod r
+    a = B.blob_scalars(data[:B.BYTES_PER_BLOB])
+    b = B.blob_scalars(data[B.BYTES_PER_BLOB:2 * B.BYTES_PER_BLOB])
+    csum = b"".join(((x + y) % R).to_bytes(32, "big") for x, y in zip(a, b))
+    got = K.blob_to_kzg_commitment(csum, gpu_setup)
+    xa, _ = oracle.g1_decompress(first[:48])
+    xb, _ = oracle.g1_decompress(first[48:96])
+    s, inf = oracle.g1_add_affine(xa, False, xb, False)
+    assert not inf and oracle.g1_compress(s) == got
+    # partition invariance (what 1/2/4/8-GPU sharding relies on): any sub-range gives the same bytes
+    from lambdaworks_kzg_amd.dist import shard_range
+    for world in (2, 8):
+        for r in (0, world - 1):
+            st, cnt = shard_range(n, world, r)
+            sub = K.blob_to_kzg_commitment_batch(data[st * B.BYTES_PER_BLOB:(st + min(cnt, 3)) * B.BYTES_PER_BLOB], gpu_setup)
+            assert b"".join(sub) == first[48 * st:48 * (st + min(cnt, 3))]
+
+
+def test_setup_image_export_import_roundtrip(K, gpu_setup, oracle):
+    import torch
+    from lambdaworks_kzg_amd import capi
+    img = torch.empty(capi.setup_image_bytes(), dtype=torch.uint8, device="cuda")
+    gpu_setup.export_device_image(img.data_ptr())
+    ts2 = K.TrustedSetup.from_device_image(img.data_ptr())
+    assert ts2.g1_values_bytes() == gpu_setup.g1_values_bytes()
+    assert ts2.g2_values_bytes() == gpu_setup.g2_values_bytes()
+    blob = B.synthetic_blob(9)
+    assert K.blob_to_kzg_commitment(blob, ts2) == tau_closed_form(oracle, B.blob_scalars(blob))
+    ts2.free()
