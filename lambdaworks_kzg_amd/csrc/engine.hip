@@ -136,7 +136,7 @@ C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
     WS_ALLOC(fr, cap * (size_t)kBlobBytes);
     WS_ALLOC(sorted, cap * (size_t)kMaxEntries * 4);
     WS_ALLOC(bucket_start, cap * (size_t)(kNumBuckets + 1) * 4);
-    WS_ALLOC(perm, cap * (size_t)kNumBuckets * 4);
+    WS_ALLOC(perm, cap * (size_t)(kNumBuckets + 1) * 4);
     WS_ALLOC(buckets, cap * (size_t)kNumBuckets * sizeof(G1Xyzz));
     WS_ALLOC(sums, cap * sizeof(G1Xyzz));
     WS_ALLOC(out48, cap * 48);

@@ -114,6 +114,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 }
 
 constexpr int kSortThreads = 1024;
+constexpr int kHeavyThreshold = 64;  // buckets above this many entries get a workgroup instead of a lane
 constexpr int kBucketsPerSortThread = kNumBuckets / kSortThreads;  // 4
 constexpr int kScalarsPerSortThread = kBlobElems / kSortThreads;   // 4
 static_assert(kNumBuckets % kSortThreads == 0 && kBlobElems % kSortThreads == 0, "sort tiling");
@@ -184,9 +185,12 @@ __global__ __launch_bounds__(kSortThreads) void k_digit_sort(const uint4 *__rest
         uint32_t before = 0;
         for (int k = tid + 1; k < 256; k++) before += pop_hist[k];
         pop_cur[tid] = before;
+        // buckets with more than kHeavyThreshold entries come first in the order; their number is
+        // stored behind the permutation for the two accumulate kernels
+        if (tid == kHeavyThreshold) perm[blob * (size_t)(kNumBuckets + 1) + kNumBuckets] = before;
     }
     __syncthreads();
-    uint32_t *pm = perm + blob * (size_t)kNumBuckets;
+    uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
 #pragma unroll
     for (int k = 0; k < kBucketsPerSortThread; k++) {
         uint32_t pos = atomicAdd(&pop_cur[c[k] > 255u ? 255u : c[k]], 1u);
@@ -217,6 +221,8 @@ void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *
 
 constexpr int kAccThreads = 256;
 
+// Light buckets (<= kHeavyThreshold entries, i.e. all of them for uniformly random scalars): one lane
+// per bucket, lanes ordered by population so a wave's 64 trip counts are near-equal.
 __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine *__restrict__ table,
                                                                    const uint32_t *__restrict__ sorted,
                                                                    const uint32_t *__restrict__ bucket_start,
@@ -224,7 +230,9 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
                                                                    G1Xyzz *__restrict__ buckets) {
     const size_t blob = blockIdx.y;
     const int t = blockIdx.x * kAccThreads + threadIdx.x;  // rank in the population order
-    const uint32_t b = perm[blob * (size_t)kNumBuckets + t];
+    const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
+    if ((uint32_t)t < pm[kNumBuckets]) return;  // heavy: k_heavy_bucket_accumulate's job
+    const uint32_t b = pm[t];
     const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
     const uint32_t begin = bs[b], end = bs[b + 1];
     const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
@@ -239,11 +247,57 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
     buckets[blob * (size_t)kNumBuckets + b] = acc;
 }
 
+// Heavy buckets: a whole workgroup per bucket, entries strided over the lanes, LDS tree at the end.
+// They appear whenever many scalars share a digit: the top window of blobs whose elements carry 31
+// payload bytes (the common EIP-4844 packing, and the bench workload) holds only the values 0..2, and
+// adversarial blobs (all scalars equal) put 4096 entries into each of 20 buckets.
+constexpr int kHeavyBlocksPerBlob = 8;
+
+__global__ __launch_bounds__(kAccThreads) void k_heavy_bucket_accumulate(const G1Affine *__restrict__ table,
+                                                                         const uint32_t *__restrict__ sorted,
+                                                                         const uint32_t *__restrict__ bucket_start,
+                                                                         const uint32_t *__restrict__ perm,
+                                                                         G1Xyzz *__restrict__ buckets) {
+    __shared__ G1Xyzz sh[kAccThreads];
+    const size_t blob = blockIdx.y;
+    const int tid = threadIdx.x;
+    const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t n_heavy = pm[kNumBuckets];
+    const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
+    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const uint32_t b = pm[h];
+        const uint32_t begin = bs[b], end = bs[b + 1];
+        G1Xyzz acc = G1Xyzz::infinity();
+        for (uint32_t k = begin + tid; k < end; k += kAccThreads) {
+            uint32_t e = ent[k];
+            G1Affine p = table[e & ~kEntryNegBit];
+            if (e & kEntryNegBit) p.y = neg(p.y);
+            acc = xyzz_madd(acc, p);
+        }
+        sh[tid] = acc;
+        __syncthreads();
+        for (int d = kAccThreads / 2; d >= 1; d >>= 1) {
+            if (tid < d) sh[tid] = xyzz_add(sh[tid], sh[tid + d]);
+            __syncthreads();
+        }
+        if (tid == 0) buckets[blob * (size_t)kNumBuckets + b] = sh[0];
+        __syncthreads();
+    }
+}
+
 void launch_bucket_accumulate(const G1Affine *table, const uint32_t *sorted, const uint32_t *bucket_start,
                               const uint32_t *perm, G1Xyzz *buckets, size_t n_blobs, hipStream_t st) {
-    ProfScope p("k_bucket_accumulate", st);
-    hipLaunchKernelGGL(k_bucket_accumulate, dim3(kNumBuckets / kAccThreads, (unsigned)n_blobs), dim3(kAccThreads), 0,
-                       st, table, sorted, bucket_start, perm, buckets);
+    {
+        ProfScope p("k_bucket_accumulate", st);
+        hipLaunchKernelGGL(k_bucket_accumulate, dim3(kNumBuckets / kAccThreads, (unsigned)n_blobs), dim3(kAccThreads),
+                           0, st, table, sorted, bucket_start, perm, buckets);
+    }
+    {
+        ProfScope p("k_heavy_bucket_accumulate", st);
+        hipLaunchKernelGGL(k_heavy_bucket_accumulate, dim3(kHeavyBlocksPerBlob, (unsigned)n_blobs), dim3(kAccThreads),
+                           0, st, table, sorted, bucket_start, perm, buckets);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
