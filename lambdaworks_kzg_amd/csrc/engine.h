@@ -32,8 +32,8 @@ struct Workspace {
     uint32_t *sorted = nullptr;      // cap x 81920
     uint32_t *bucket_start = nullptr;  // cap x 4097
     uint32_t *perm = nullptr;        // cap x 4096
-    G1Xyzz *buckets = nullptr;       // cap x 4096
-    G1Xyzz *sums = nullptr;          // cap
+    G1Xyzz29 *buckets = nullptr;       // cap x 4096
+    G1Xyzz29 *sums = nullptr;          // cap
     uint8_t *out48 = nullptr;        // cap x 48
     uint8_t *comm48 = nullptr;       // cap x 48
     uint8_t *canon48 = nullptr;      // cap x 48
@@ -50,7 +50,7 @@ struct Ctx {
     int device;
     hipStream_t stream;
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
-    G1Affine *table;   // kTablePoints
+    G1Affine29 *table;  // kTablePoints, hot-loop representation
     Fr *tw_fwd, *tw_inv;
     Workspace ws;
     std::mutex mu;

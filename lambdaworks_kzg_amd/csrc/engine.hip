@@ -137,8 +137,8 @@ C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
     WS_ALLOC(sorted, cap * (size_t)kMaxEntries * 4);
     WS_ALLOC(bucket_start, cap * (size_t)(kNumBuckets + 1) * 4);
     WS_ALLOC(perm, cap * (size_t)(kNumBuckets + 1) * 4);
-    WS_ALLOC(buckets, cap * (size_t)kNumBuckets * sizeof(G1Xyzz));
-    WS_ALLOC(sums, cap * sizeof(G1Xyzz));
+    WS_ALLOC(buckets, cap * (size_t)kNumBuckets * sizeof(G1Xyzz29));
+    WS_ALLOC(sums, cap * sizeof(G1Xyzz29));
     WS_ALLOC(out48, cap * 48);
     WS_ALLOC(comm48, cap * 48);
     WS_ALLOC(canon48, cap * 48);
@@ -196,7 +196,7 @@ static C_KZG_RET ctx_new(Ctx **out) {
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->points, (size_t)kBlobElems * sizeof(G1Affine));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine29));
     if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc((void **)&c->tw_inv, (size_t)(kBlobElems / 2) * sizeof(Fr));
     if (e != hipSuccess) {
@@ -802,14 +802,15 @@ C_KZG_RET lwkzg_fr_ntt4096_device(void *out_dev, const void *in_dev, size_t n, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// multi-GPU setup hand-off: [hdr 64][g1_values 589,824][g2_values 18,720 -> padded][table][tw_fwd][tw_inv]
+// multi-GPU setup hand-off: [hdr 64][g1_values 589,824][g2_values 18,720 -> padded][table][tw_fwd][tw_inv][points]
 
 static constexpr size_t kImgHdr = 64;
 static constexpr size_t kImgG1 = (size_t)kBlobElems * 144;
 static constexpr size_t kImgG2 = ((size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288 + 63) / 64 * 64;
-static constexpr size_t kImgTable = (size_t)kTablePoints * sizeof(G1Affine);
+static constexpr size_t kImgTable = (size_t)kTablePoints * sizeof(G1Affine29);
 static constexpr size_t kImgTw = (size_t)(kBlobElems / 2) * sizeof(Fr);
-static constexpr size_t kImgBytes = kImgHdr + kImgG1 + kImgG2 + kImgTable + 2 * kImgTw;
+static constexpr size_t kImgPoints = (size_t)kBlobElems * sizeof(G1Affine);
+static constexpr size_t kImgBytes = kImgHdr + kImgG1 + kImgG2 + kImgTable + 2 * kImgTw + kImgPoints;
 
 size_t lwkzg_setup_image_bytes(void) { return kImgBytes; }
 
@@ -828,6 +829,7 @@ C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void 
     LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2, c->table, kImgTable, hipMemcpyDeviceToDevice, st));
     LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2 + kImgTable, c->tw_fwd, kImgTw, hipMemcpyDeviceToDevice, st));
     LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2 + kImgTable + kImgTw, c->tw_inv, kImgTw, hipMemcpyDeviceToDevice, st));
+    LWK_HIP(hipMemcpyAsync(img + kImgHdr + kImgG1 + kImgG2 + kImgTable + 2 * kImgTw, c->points, kImgPoints, hipMemcpyDeviceToDevice, st));
     LWK_HIP(hipStreamSynchronize(st));  // the host sources above must stay valid until the copies ran
     return C_KZG_OK;
 }
@@ -849,7 +851,7 @@ C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev) {
     ok = ok && hipMemcpy(g1v, img + kImgHdr, kImgG1, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(g2v, img + kImgHdr + kImgG1, (size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(c->table, img + kImgHdr + kImgG1 + kImgG2, kImgTable, hipMemcpyDeviceToDevice) == hipSuccess &&
-         hipMemcpy(c->points, c->table, (size_t)kBlobElems * sizeof(G1Affine), hipMemcpyDeviceToDevice) == hipSuccess;
+         hipMemcpy(c->points, img + kImgHdr + kImgG1 + kImgG2 + kImgTable + 2 * kImgTw, kImgPoints, hipMemcpyDeviceToDevice) == hipSuccess;
     if (ok) ok = ctx_finish_fft(c) == C_KZG_OK;
     if (!ok) {
         if (!get_error()[0]) set_error("setup image import failed");

@@ -14,34 +14,57 @@
 // (P+P, P+(-P), P+O, O+P): formula-generated blobs do hit them (hard part c).
 #pragma once
 #include "field.cuh"
+#include "field29.cuh"
 
 namespace lwk {
 
-struct G1Affine {
-    Fp x, y;  // Montgomery form; the point at infinity is not representable (never needed in tables)
+// ---- representation-generic point types -----------------------------------------------------------
+// Two instantiations: saturated Fp (host, setup kernels) and the lazy 29-bit-limb F29<B> of
+// field29.cuh (MSM hot loop), whose value bounds (multiples of p) are part of the member types below
+// and are re-derived by the compiler through every formula (`auto` temporaries).
+
+LWK_HD bool literal_zero(const Fp &a) { return a.is_zero(); }
+template <int B>
+LWK_HD bool literal_zero(const F29<B> &a) { return a.is_literal_zero(); }
+
+template <class FX, class FY>
+struct alignas(16) AffineT {
+    FX x;
+    FY y;  // the point at infinity is not representable (never needed in tables)
 };
 
-struct G1Xyzz {
-    Fp x, y, zz, zzz;  // infinity <=> zz == 0
+template <class FX, class FY, class FZ>
+struct alignas(16) XyzzT {
+    FX x;
+    FY y;
+    FZ zz, zzz;  // infinity <=> zz is literally zero
 
-    LWK_HD static G1Xyzz infinity() {
-        G1Xyzz r;
-        r.x = Fp::zero();
-        r.y = Fp::zero();
-        r.zz = Fp::zero();
-        r.zzz = Fp::zero();
+    LWK_HD static XyzzT infinity() {
+        XyzzT r;
+        r.x = FX::zero();
+        r.y = FY::zero();
+        r.zz = FZ::zero();
+        r.zzz = FZ::zero();
         return r;
     }
-    LWK_HD bool is_inf() const { return zz.is_zero(); }
-    LWK_HD static G1Xyzz from_affine(const G1Affine &p) {
-        G1Xyzz r;
-        r.x = p.x;
-        r.y = p.y;
-        r.zz = Fp::one();
-        r.zzz = Fp::one();
+    LWK_HD bool is_inf() const { return literal_zero(zz); }
+    template <class QX, class QY>
+    LWK_HD static XyzzT from_affine(const QX &qx, const QY &qy) {
+        XyzzT r;
+        r.x = qx;
+        r.y = qy;
+        r.zz = FZ::one();
+        r.zzz = FZ::one();
         return r;
     }
 };
+
+typedef AffineT<Fp, Fp> G1Affine;    // 96 B, Montgomery 12x32
+typedef XyzzT<Fp, Fp, Fp> G1Xyzz;    // 192 B
+// hot-loop forms. Bounds: table coordinates < 2p; an accumulator leaves every formula below with
+// X < 14p, Y < 6p, ZZ, ZZZ < 2p (derivation in DESIGN.md section 4a; enforced by static_asserts).
+typedef AffineT<F29<2>, F29<2>> G1Affine29;          // 112 B
+typedef XyzzT<F29<14>, F29<6>, F29<2>> G1Xyzz29;     // 224 B
 
 LWK_HD Fp fp_from_u32(uint32_t v) {
     uint32_t raw[12];
@@ -56,82 +79,92 @@ LWK_HD bool g1_on_curve(const G1Affine &p) {
     return l == r;
 }
 
-// 2P for affine P (mdbl-2008-s-1, a = 0)
-LWK_HD G1Xyzz xyzz_dbl_affine(const G1Affine &p) {
-    if (p.y.is_zero()) return G1Xyzz::infinity();  // order-2 point: cannot occur in G1, kept for completeness
-    Fp u = dbl(p.y);
-    Fp v = sqr(u);
-    Fp w = u * v;
-    Fp s = p.x * v;
-    Fp xx = sqr(p.x);
-    Fp m = dbl(xx) + xx;
-    G1Xyzz r;
-    r.x = sqr(m) - dbl(s);
-    r.y = m * (s - r.x) - w * p.y;
+// 2Q for affine Q (mdbl-2008-s-1, a = 0)
+template <class X, class QX, class QY>
+LWK_HD X xyzz_dbl_affine(const QX &qx, const QY &qy) {
+    if (qy.is_zero()) return X::infinity();  // order-2 point: cannot occur in G1, kept for completeness
+    auto u = dbl(qy);
+    auto v = sqr(u);
+    auto w = u * v;
+    auto s = qx * v;
+    auto xx = sqr(qx);
+    auto m = dbl(xx) + xx;
+    X r;
+    auto x3 = sqr(m) - dbl(s);
+    r.x = x3;
+    r.y = m * (s - x3) - w * qy;
     r.zz = v;
     r.zzz = w;
     return r;
 }
 
 // 2P (dbl-2008-s-1, a = 0)
-LWK_HD G1Xyzz xyzz_dbl(const G1Xyzz &p) {
-    if (p.is_inf() || p.y.is_zero()) return G1Xyzz::infinity();
-    Fp u = dbl(p.y);
-    Fp v = sqr(u);
-    Fp w = u * v;
-    Fp s = p.x * v;
-    Fp xx = sqr(p.x);
-    Fp m = dbl(xx) + xx;
-    G1Xyzz r;
-    r.x = sqr(m) - dbl(s);
-    r.y = m * (s - r.x) - w * p.y;
+template <class X>
+LWK_HD X xyzz_dbl(const X &p) {
+    if (p.is_inf() || p.y.is_zero()) return X::infinity();
+    auto u = dbl(p.y);
+    auto v = sqr(u);
+    auto w = u * v;
+    auto s = p.x * v;
+    auto xx = sqr(p.x);
+    auto m = dbl(xx) + xx;
+    X r;
+    auto x3 = sqr(m) - dbl(s);
+    r.x = x3;
+    r.y = m * (s - x3) - w * p.y;
     r.zz = v * p.zz;
     r.zzz = w * p.zzz;
     return r;
 }
 
-// acc + q for affine q (madd-2008-s), complete
-LWK_HD G1Xyzz xyzz_madd(const G1Xyzz &acc, const G1Affine &q) {
-    if (acc.is_inf()) return G1Xyzz::from_affine(q);
-    Fp u2 = q.x * acc.zz;
-    Fp s2 = q.y * acc.zzz;
-    Fp pp_ = u2 - acc.x;
-    Fp rr = s2 - acc.y;
+// acc + Q for affine Q = (qx, qy) (madd-2008-s), complete
+template <class X, class QX, class QY>
+LWK_HD X xyzz_madd(const X &acc, const QX &qx, const QY &qy) {
+    if (acc.is_inf()) return X::from_affine(qx, qy);
+    auto u2 = qx * acc.zz;
+    auto s2 = qy * acc.zzz;
+    auto pp_ = u2 - acc.x;
+    auto rr = s2 - acc.y;
     if (pp_.is_zero()) {
-        if (rr.is_zero()) return xyzz_dbl_affine(q);
-        return G1Xyzz::infinity();
+        if (rr.is_zero()) return xyzz_dbl_affine<X>(qx, qy);
+        return X::infinity();
     }
-    Fp pp = sqr(pp_);
-    Fp ppp = pp_ * pp;
-    Fp qq = acc.x * pp;
-    G1Xyzz r;
-    r.x = sqr(rr) - ppp - dbl(qq);
-    r.y = rr * (qq - r.x) - acc.y * ppp;
+    auto pp = sqr(pp_);
+    auto ppp = pp_ * pp;
+    auto qq = acc.x * pp;
+    X r;
+    auto x3 = sqr(rr) - ppp - dbl(qq);
+    r.x = x3;
+    r.y = rr * (qq - x3) - acc.y * ppp;
     r.zz = acc.zz * pp;
     r.zzz = acc.zzz * ppp;
     return r;
 }
 
+LWK_HD G1Xyzz xyzz_madd(const G1Xyzz &acc, const G1Affine &q) { return xyzz_madd(acc, q.x, q.y); }
+
 // a + b (add-2008-s), complete
-LWK_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
+template <class X>
+LWK_HD X xyzz_add(const X &a, const X &b) {
     if (a.is_inf()) return b;
     if (b.is_inf()) return a;
-    Fp u1 = a.x * b.zz;
-    Fp u2 = b.x * a.zz;
-    Fp s1 = a.y * b.zzz;
-    Fp s2 = b.y * a.zzz;
-    Fp pp_ = u2 - u1;
-    Fp rr = s2 - s1;
+    auto u1 = a.x * b.zz;
+    auto u2 = b.x * a.zz;
+    auto s1 = a.y * b.zzz;
+    auto s2 = b.y * a.zzz;
+    auto pp_ = u2 - u1;
+    auto rr = s2 - s1;
     if (pp_.is_zero()) {
         if (rr.is_zero()) return xyzz_dbl(a);
-        return G1Xyzz::infinity();
+        return X::infinity();
     }
-    Fp pp = sqr(pp_);
-    Fp ppp = pp_ * pp;
-    Fp qq = u1 * pp;
-    G1Xyzz r;
-    r.x = sqr(rr) - ppp - dbl(qq);
-    r.y = rr * (qq - r.x) - s1 * ppp;
+    auto pp = sqr(pp_);
+    auto ppp = pp_ * pp;
+    auto qq = u1 * pp;
+    X r;
+    auto x3 = sqr(rr) - ppp - dbl(qq);
+    r.x = x3;
+    r.y = rr * (qq - x3) - s1 * ppp;
     r.zz = a.zz * b.zz * pp;
     r.zzz = a.zzz * b.zzz * ppp;
     return r;
@@ -155,13 +188,31 @@ LWK_HD G1Affine xyzz_to_affine(const G1Xyzz &p) {
     return r;
 }
 
+// same, from the hot-loop representation to canonical saturated coordinates
+LWK_HD G1Affine xyzz_to_affine(const G1Xyzz29 &p) {
+    auto i = f29_inv(p.zz * p.zzz);
+    auto izz = i * p.zzz;
+    auto izzz = i * p.zz;
+    G1Affine r;
+    r.x = f29_to_fp(p.x * izz);
+    r.y = f29_to_fp(p.y * izzz);
+    return r;
+}
+
+LWK_HD G1Affine29 affine_to_29(const G1Affine &p) {
+    G1Affine29 r;
+    r.x = f29_from_fp(p.x);
+    r.y = f29_from_fp(p.y);
+    return r;
+}
+
 // [k]P, k = NK little-endian 32-bit limbs (plain integer, not reduced); left-to-right double-and-add
 template <int NK>
 LWK_HD G1Xyzz xyzz_mul_affine(const G1Affine &p, const uint32_t *k) {
     G1Xyzz acc = G1Xyzz::infinity();
     for (int i = NK * 32 - 1; i >= 0; i--) {
         acc = xyzz_dbl(acc);
-        if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_madd(acc, p);
+        if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_madd(acc, p.x, p.y);
     }
     return acc;
 }
@@ -187,7 +238,8 @@ LWK_HD void g1_compress_affine(uint8_t out[48], const G1Affine &a) {
     if (!raw_geq<12>(ryn, ry)) out[0] |= 0x20;
 }
 
-LWK_HD void g1_compress(uint8_t out[48], const G1Xyzz &p) {
+template <class X>
+LWK_HD void g1_compress(uint8_t out[48], const X &p) {
     if (p.is_inf()) {
         for (int i = 0; i < 48; i++) out[i] = 0;
         out[0] = 0xc0;

@@ -28,11 +28,11 @@ void launch_parse_le_canonical(const uint8_t *blobs, Fr *out_mont, int32_t *stat
 // ---- MSM (msm.hip)
 void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *bucket_start, uint32_t *perm,
                        size_t n_blobs, hipStream_t st);
-void launch_bucket_accumulate(const G1Affine *table, const uint32_t *sorted, const uint32_t *bucket_start,
-                              const uint32_t *perm, G1Xyzz *buckets, size_t n_blobs, hipStream_t st);
-void launch_bucket_reduce(const G1Xyzz *buckets, G1Xyzz *sums, size_t n_blobs, hipStream_t st);
+void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, const uint32_t *bucket_start,
+                              const uint32_t *perm, G1Xyzz29 *buckets, size_t n_blobs, hipStream_t st);
+void launch_bucket_reduce(const G1Xyzz29 *buckets, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st);
 // sums -> 48-byte compressed points (compress_g1_point, /root/reference/src/compression.rs:33-60)
-void launch_finalize_compress(const G1Xyzz *sums, uint8_t *out48, size_t n, hipStream_t st);
+void launch_finalize_compress(const G1Xyzz29 *sums, uint8_t *out48, size_t n, hipStream_t st);
 
 // ---- setup (setup.hip)
 // 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check
@@ -44,7 +44,7 @@ void launch_g1_from_blst(const uint64_t *blst_p1, G1Affine *out, int32_t *status
 // affine Montgomery -> reference blst_p1 layout (g1_point_to_blst_p1, /root/reference/src/srs.rs:131-153)
 void launch_g1_to_blst(const G1Affine *in, const int32_t *status, uint64_t *blst_p1, size_t n, hipStream_t st);
 // T[j][i] = 2^(13 j) P_i
-void launch_build_table(const G1Affine *points, G1Affine *table, hipStream_t st);
+void launch_build_table(const G1Affine *points, G1Affine29 *table, hipStream_t st);
 
 // ---- Fr (fr_ops.hip)
 // twiddle table: w^-k (inverse) and w^k (forward), k < 2048, Montgomery; built once on device

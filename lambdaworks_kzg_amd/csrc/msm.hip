@@ -223,11 +223,11 @@ constexpr int kAccThreads = 256;
 
 // Light buckets (<= kHeavyThreshold entries, i.e. all of them for uniformly random scalars): one lane
 // per bucket, lanes ordered by population so a wave's 64 trip counts are near-equal.
-__global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine *__restrict__ table,
+__global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine29 *__restrict__ table,
                                                                    const uint32_t *__restrict__ sorted,
                                                                    const uint32_t *__restrict__ bucket_start,
                                                                    const uint32_t *__restrict__ perm,
-                                                                   G1Xyzz *__restrict__ buckets) {
+                                                                   G1Xyzz29 *__restrict__ buckets) {
     const size_t blob = blockIdx.y;
     const int t = blockIdx.x * kAccThreads + threadIdx.x;  // rank in the population order
     const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
@@ -237,12 +237,11 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
     const uint32_t begin = bs[b], end = bs[b + 1];
     const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
 
-    G1Xyzz acc = G1Xyzz::infinity();
+    G1Xyzz29 acc = G1Xyzz29::infinity();
     for (uint32_t k = begin; k < end; k++) {
         uint32_t e = ent[k];
-        G1Affine p = table[e & ~kEntryNegBit];
-        if (e & kEntryNegBit) p.y = neg(p.y);
-        acc = xyzz_madd(acc, p);
+        G1Affine29 p = table[e & ~kEntryNegBit];
+        acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
     }
     buckets[blob * (size_t)kNumBuckets + b] = acc;
 }
@@ -253,12 +252,12 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
 // adversarial blobs (all scalars equal) put 4096 entries into each of 20 buckets.
 constexpr int kHeavyBlocksPerBlob = 8;
 
-__global__ __launch_bounds__(kAccThreads) void k_heavy_bucket_accumulate(const G1Affine *__restrict__ table,
+__global__ __launch_bounds__(kAccThreads) void k_heavy_bucket_accumulate(const G1Affine29 *__restrict__ table,
                                                                          const uint32_t *__restrict__ sorted,
                                                                          const uint32_t *__restrict__ bucket_start,
                                                                          const uint32_t *__restrict__ perm,
-                                                                         G1Xyzz *__restrict__ buckets) {
-    __shared__ G1Xyzz sh[kAccThreads];
+                                                                         G1Xyzz29 *__restrict__ buckets) {
+    __shared__ G1Xyzz29 sh[kAccThreads];
     const size_t blob = blockIdx.y;
     const int tid = threadIdx.x;
     const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
@@ -268,12 +267,11 @@ __global__ __launch_bounds__(kAccThreads) void k_heavy_bucket_accumulate(const G
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const uint32_t b = pm[h];
         const uint32_t begin = bs[b], end = bs[b + 1];
-        G1Xyzz acc = G1Xyzz::infinity();
+        G1Xyzz29 acc = G1Xyzz29::infinity();
         for (uint32_t k = begin + tid; k < end; k += kAccThreads) {
             uint32_t e = ent[k];
-            G1Affine p = table[e & ~kEntryNegBit];
-            if (e & kEntryNegBit) p.y = neg(p.y);
-            acc = xyzz_madd(acc, p);
+            G1Affine29 p = table[e & ~kEntryNegBit];
+            acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
         }
         sh[tid] = acc;
         __syncthreads();
@@ -286,8 +284,8 @@ __global__ __launch_bounds__(kAccThreads) void k_heavy_bucket_accumulate(const G
     }
 }
 
-void launch_bucket_accumulate(const G1Affine *table, const uint32_t *sorted, const uint32_t *bucket_start,
-                              const uint32_t *perm, G1Xyzz *buckets, size_t n_blobs, hipStream_t st) {
+void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, const uint32_t *bucket_start,
+                              const uint32_t *perm, G1Xyzz29 *buckets, size_t n_blobs, hipStream_t st) {
     {
         ProfScope p("k_bucket_accumulate", st);
         hipLaunchKernelGGL(k_bucket_accumulate, dim3(kNumBuckets / kAccThreads, (unsigned)n_blobs), dim3(kAccThreads),
@@ -307,16 +305,16 @@ constexpr int kRedThreads = 256;
 constexpr int kBucketsPerRedThread = kNumBuckets / kRedThreads;  // 16
 static_assert((kBucketsPerRedThread & (kBucketsPerRedThread - 1)) == 0, "chunk must be a power of two");
 
-__global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz *__restrict__ buckets,
-                                                               G1Xyzz *__restrict__ sums) {
-    __shared__ G1Xyzz sh[kRedThreads];
+__global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz29 *__restrict__ buckets,
+                                                               G1Xyzz29 *__restrict__ sums) {
+    __shared__ G1Xyzz29 sh[kRedThreads];
     const int t = threadIdx.x;
     const size_t blob = blockIdx.x;
-    const G1Xyzz *B = buckets + blob * (size_t)kNumBuckets + (size_t)t * kBucketsPerRedThread;
+    const G1Xyzz29 *B = buckets + blob * (size_t)kNumBuckets + (size_t)t * kBucketsPerRedThread;
 
     // lane t owns bucket values k = t*16 + 1 .. t*16 + 16:
     //   run = sum B_k,  wsum = sum (k - t*16) B_k     (descending running sums)
-    G1Xyzz run = G1Xyzz::infinity(), wsum = G1Xyzz::infinity();
+    G1Xyzz29 run = G1Xyzz29::infinity(), wsum = G1Xyzz29::infinity();
     for (int k = kBucketsPerRedThread - 1; k >= 0; k--) {
         run = xyzz_add(run, B[k]);
         wsum = xyzz_add(wsum, run);
@@ -325,20 +323,20 @@ __global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz *__r
     sh[t] = run;
     __syncthreads();
     for (int d = 1; d < kRedThreads; d <<= 1) {
-        G1Xyzz other = (t + d < kRedThreads) ? sh[t + d] : G1Xyzz::infinity();
+        G1Xyzz29 other = (t + d < kRedThreads) ? sh[t + d] : G1Xyzz29::infinity();
         __syncthreads();
         run = xyzz_add(run, other);
         sh[t] = run;
         __syncthreads();
     }
     // tree-sum the suffix sums over t >= 1
-    sh[t] = (t >= 1) ? run : G1Xyzz::infinity();
+    sh[t] = (t >= 1) ? run : G1Xyzz29::infinity();
     __syncthreads();
     for (int d = kRedThreads / 2; d >= 1; d >>= 1) {
         if (t < d) sh[t] = xyzz_add(sh[t], sh[t + d]);
         __syncthreads();
     }
-    G1Xyzz hi = sh[0];
+    G1Xyzz29 hi = sh[0];
     __syncthreads();
     // tree-sum the weighted sums
     sh[t] = wsum;
@@ -353,7 +351,7 @@ __global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz *__r
     }
 }
 
-void launch_bucket_reduce(const G1Xyzz *buckets, G1Xyzz *sums, size_t n_blobs, hipStream_t st) {
+void launch_bucket_reduce(const G1Xyzz29 *buckets, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st) {
     ProfScope p("k_bucket_reduce", st);
     hipLaunchKernelGGL(k_bucket_reduce, dim3((unsigned)n_blobs), dim3(kRedThreads), 0, st, buckets, sums);
 }
@@ -361,7 +359,7 @@ void launch_bucket_reduce(const G1Xyzz *buckets, G1Xyzz *sums, size_t n_blobs, h
 // ------------------------------------------------------------------------------------------------
 // finalize: affine + ZCash compression, one lane per result
 
-__global__ __launch_bounds__(64) void k_finalize_compress(const G1Xyzz *__restrict__ sums, uint8_t *__restrict__ out48,
+__global__ __launch_bounds__(64) void k_finalize_compress(const G1Xyzz29 *__restrict__ sums, uint8_t *__restrict__ out48,
                                                           size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(64) void k_finalize_compress(const G1Xyzz *__restri
                ((uint32_t)b[4 * k + 3] << 24);
 }
 
-void launch_finalize_compress(const G1Xyzz *sums, uint8_t *out48, size_t n, hipStream_t st) {
+void launch_finalize_compress(const G1Xyzz29 *sums, uint8_t *out48, size_t n, hipStream_t st) {
     ProfScope p("k_finalize_compress", st);
     hipLaunchKernelGGL(k_finalize_compress, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, sums, out48, n);
 }

@@ -99,20 +99,22 @@ void launch_g1_to_blst(const G1Affine *in, const int32_t *status, uint64_t *blst
 }
 
 // T[j][i] = 2^(13 j) * P_i, affine. One lane per point walks its 20 windows.
-__global__ __launch_bounds__(64) void k_build_table(const G1Affine *__restrict__ points, G1Affine *__restrict__ table) {
+// Entries are stored in the hot loop's 29-bit-limb Montgomery form (field29.cuh), 112 B each.
+__global__ __launch_bounds__(64) void k_build_table(const G1Affine *__restrict__ points,
+                                                    G1Affine29 *__restrict__ table) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= kBlobElems) return;
     G1Affine a = points[i];
-    table[i] = a;
-    G1Xyzz cur = G1Xyzz::from_affine(a);
+    table[i] = affine_to_29(a);
+    G1Xyzz cur = G1Xyzz::from_affine(a.x, a.y);
     for (int j = 1; j < kNumWindows; j++) {
         for (int d = 0; d < kWindowBits; d++) cur = xyzz_dbl(cur);
         // P has prime order r and 2^(13 j) is a unit mod r, so cur is never the point at infinity
-        table[(size_t)j * kBlobElems + i] = xyzz_to_affine(cur);
+        table[(size_t)j * kBlobElems + i] = affine_to_29(xyzz_to_affine(cur));
     }
 }
 
-void launch_build_table(const G1Affine *points, G1Affine *table, hipStream_t st) {
+void launch_build_table(const G1Affine *points, G1Affine29 *table, hipStream_t st) {
     ProfScope p("k_build_table", st);
     hipLaunchKernelGGL(k_build_table, dim3(kBlobElems / 64), dim3(64), 0, st, points, table);
 }

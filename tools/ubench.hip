@@ -80,11 +80,32 @@ __global__ __launch_bounds__(256) void k_xyzz_madd(uint32_t *out, uint32_t seed)
     G1Affine q;
     for (int i = 0; i < 12; i++) { q.x.l[i] = seed + threadIdx.x * 7 + i; q.y.l[i] = seed * 3 + i; }
     q.x.l[11] &= 0x0fffffff; q.y.l[11] &= 0x0fffffff;
-    G1Xyzz acc = G1Xyzz::from_affine(q);
+    G1Xyzz acc = G1Xyzz::from_affine(q.x, q.y);
     acc.x.l[0] ^= 5;
     for (int it = 0; it < 64; it++) acc = xyzz_madd(acc, q);   // not on the curve: only the arithmetic cost matters
     uint32_t s = 0;
     for (int i = 0; i < 12; i++) s ^= acc.x.l[i] ^ acc.y.l[i] ^ acc.zz.l[i] ^ acc.zzz.l[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_f29_mul(uint32_t *out, uint32_t seed) {
+    F29<2> x, y;
+    for (int i = 0; i < 14; i++) { x.l[i] = (seed + threadIdx.x * 7 + i) & P29::MASK; y.l[i] = (seed * 3 + i) & P29::MASK; }
+    x.l[13] = 5; y.l[13] = 7;
+    for (int it = 0; it < 256; it++) x = x * y;
+    uint32_t s = 0;
+    for (int i = 0; i < 14; i++) s ^= x.l[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_xyzz_madd29(uint32_t *out, uint32_t seed) {
+    G1Affine29 q;
+    for (int i = 0; i < 14; i++) { q.x.l[i] = (seed + threadIdx.x * 7 + i) & P29::MASK; q.y.l[i] = (seed * 3 + i) & P29::MASK; }
+    q.x.l[13] = 5; q.y.l[13] = 7;
+    G1Xyzz29 acc = G1Xyzz29::from_affine(q.x, q.y);
+    acc.x.l[0] ^= 5;
+    for (int it = 0; it < 64; it++) acc = xyzz_madd(acc, q.x, cneg(q.y, (it & 1) != 0));
+    uint32_t s = 0;
+    for (int i = 0; i < 14; i++) s ^= acc.x.l[i] ^ acc.y.l[i] ^ acc.zz.l[i] ^ acc.zzz.l[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -124,7 +145,7 @@ int main() {
     uint32_t *d_out;
     CHECK(hipMalloc(&d_out, (size_t)n_cu * 16 * 256 * 4));
     double per = (double)ITERS * UNROLL;
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {8}) {
         run("v_add_u32", k_add_u32, per, w, d_out, n_cu);
         run("v_add3_u32", k_add3_u32, per, w, d_out, n_cu);
         run("v_mad_u64_u32", k_mad_u64_u32, per, w, d_out, n_cu);
@@ -139,6 +160,8 @@ int main() {
         run("fp_mul_call", k_fp_mul, 256, w, d_out, n_cu);
         run("fp_mul_inline", k_fp_mul_inl, 256, w, d_out, n_cu);
         run("xyzz_madd", k_xyzz_madd, 64, w, d_out, n_cu);
+        run("f29_mul_call", k_f29_mul, 256, w, d_out, n_cu);
+        run("xyzz_madd_f29", k_xyzz_madd29, 64, w, d_out, n_cu);
     }
     return 0;
 }
