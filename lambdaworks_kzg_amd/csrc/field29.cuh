@@ -67,7 +67,10 @@ LWK_HD uint32_t kp_limb(int i) {
     else return P29::KP32[i];
 }
 
-template <int B>
+// INL selects how operator* is emitted on the device: false = call of the shared mont_mul29_call
+// function (small code, used where many group operations are instantiated), true = inlined into the
+// caller (no call overhead or forced s_waitcnt at call boundaries; used by the accumulate loop).
+template <int B, bool INL = false>
 struct alignas(8) F29 {
     static constexpr int BOUND = B;
     uint32_t l[14];
@@ -75,7 +78,7 @@ struct alignas(8) F29 {
     F29() = default;
     // widening the bound is free
     template <int A>
-    LWK_HD F29(const F29<A> &o) {
+    LWK_HD F29(const F29<A, INL> &o) {
         static_assert(A <= B, "bound would shrink: a value < A*p is not known to be < B*p");
 #pragma unroll
         for (int i = 0; i < 14; i++) l[i] = o.l[i];
@@ -135,36 +138,36 @@ LWK_HD void norm29(uint32_t *l) {
     }
 }
 
-template <int A, int B>
-LWK_HD F29<A + B> operator+(const F29<A> &a, const F29<B> &b) {
+template <int A, int B, bool I>
+LWK_HD F29<A + B, I> operator+(const F29<A, I> &a, const F29<B, I> &b) {
     static_assert(A + B <= 4096, "value bound");
-    F29<A + B> r;
+    F29<A + B, I> r;
 #pragma unroll
     for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + b.l[i];
     norm29(r.l);
     return r;
 }
 
-template <int A, int B>
-LWK_HD F29<A + sub_offset(B)> operator-(const F29<A> &a, const F29<B> &b) {
+template <int A, int B, bool I>
+LWK_HD F29<A + sub_offset(B), I> operator-(const F29<A, I> &a, const F29<B, I> &b) {
     constexpr int K = sub_offset(B);
     static_assert(A + K <= 4096, "value bound");
-    F29<A + K> r;
+    F29<A + K, I> r;
 #pragma unroll
     for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + kp_limb<K>(i) - b.l[i];
     norm29(r.l);
     return r;
 }
 
-template <int A>
-LWK_HD F29<2 * A> dbl(const F29<A> &a) {
+template <int A, bool I>
+LWK_HD F29<2 * A, I> dbl(const F29<A, I> &a) {
     return a + a;
 }
 
-template <int A>
-LWK_HD F29<sub_offset(A)> neg(const F29<A> &a) {
+template <int A, bool I>
+LWK_HD F29<sub_offset(A), I> neg(const F29<A, I> &a) {
     constexpr int K = sub_offset(A);
-    F29<K> r;
+    F29<K, I> r;
 #pragma unroll
     for (int i = 0; i < 14; i++) r.l[i] = kp_limb<K>(i) - a.l[i];
     norm29(r.l);
@@ -172,10 +175,10 @@ LWK_HD F29<sub_offset(A)> neg(const F29<A> &a) {
 }
 
 // flag ? -a : a, one type for both outcomes
-template <int A>
-LWK_HD F29<sub_offset(A)> cneg(const F29<A> &a, bool flag) {
+template <int A, bool I>
+LWK_HD F29<sub_offset(A), I> cneg(const F29<A, I> &a, bool flag) {
     constexpr int K = sub_offset(A);
-    F29<K> r;
+    F29<K, I> r;
 #pragma unroll
     for (int i = 0; i < 14; i++) r.l[i] = flag ? kp_limb<K>(i) - a.l[i] : a.l[i];
     norm29(r.l);
@@ -231,11 +234,15 @@ __device__ __noinline__ Raw29 mont_mul29_call(Raw29 a, Raw29 b) {
 }
 #endif
 
-template <int A, int B>
-LWK_HD F29<2> operator*(const F29<A> &a, const F29<B> &b) {
+template <int A, int B, bool I>
+LWK_HD F29<2, I> operator*(const F29<A, I> &a, const F29<B, I> &b) {
     static_assert((long long)A * B <= (1ll << 22), "product of bounds too large for the Montgomery radix");
-    F29<2> r;
+    F29<2, I> r;
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (I) {
+        mont_mul29(r.l, a.l, b.l);
+        return r;
+    }
     Raw29 x, y;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
@@ -251,8 +258,8 @@ LWK_HD F29<2> operator*(const F29<A> &a, const F29<B> &b) {
     return r;
 }
 
-template <int A>
-LWK_HD F29<2> sqr(const F29<A> &a) {
+template <int A, bool I>
+LWK_HD F29<2, I> sqr(const F29<A, I> &a) {
     return a * a;
 }
 

@@ -24,8 +24,8 @@ namespace lwk {
 // and are re-derived by the compiler through every formula (`auto` temporaries).
 
 LWK_HD bool literal_zero(const Fp &a) { return a.is_zero(); }
-template <int B>
-LWK_HD bool literal_zero(const F29<B> &a) { return a.is_literal_zero(); }
+template <int B, bool I>
+LWK_HD bool literal_zero(const F29<B, I> &a) { return a.is_literal_zero(); }
 
 template <class FX, class FY>
 struct alignas(16) AffineT {
@@ -65,6 +65,10 @@ typedef XyzzT<Fp, Fp, Fp> G1Xyzz;    // 192 B
 // X < 14p, Y < 6p, ZZ, ZZZ < 2p (derivation in DESIGN.md section 4a; enforced by static_asserts).
 typedef AffineT<F29<2>, F29<2>> G1Affine29;          // 112 B
 typedef XyzzT<F29<14>, F29<6>, F29<2>> G1Xyzz29;     // 224 B
+// same layouts, field products inlined (see F29's INL): the accumulate loop's view of the same memory
+typedef AffineT<F29<2, true>, F29<2, true>> G1Affine29i;
+typedef XyzzT<F29<14, true>, F29<6, true>, F29<2, true>> G1Xyzz29i;
+static_assert(sizeof(G1Affine29i) == sizeof(G1Affine29) && sizeof(G1Xyzz29i) == sizeof(G1Xyzz29), "layout");
 
 LWK_HD Fp fp_from_u32(uint32_t v) {
     uint32_t raw[12];

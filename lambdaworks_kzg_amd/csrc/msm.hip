@@ -18,6 +18,8 @@
 // not around HBM bandwidth; DESIGN.md has the arithmetic.
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace lwk {
 
 // ------------------------------------------------------------------------------------------------
@@ -221,81 +223,86 @@ void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *
 
 constexpr int kAccThreads = 256;
 
-// Light buckets (<= kHeavyThreshold entries, i.e. all of them for uniformly random scalars): one lane
-// per bucket, lanes ordered by population so a wave's 64 trip counts are near-equal.
+// lane i receives lane i+d's point (all 56 limbs travel by ds_bpermute-free DPP/shuffle, no LDS)
+template <class PX>
+__device__ __forceinline__ PX wave_shfl_down(const PX &v, int d) {
+    PX r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = __shfl_down(v.x.l[i], d, 64);
+        r.y.l[i] = __shfl_down(v.y.l[i], d, 64);
+        r.zz.l[i] = __shfl_down(v.zz.l[i], d, 64);
+        r.zzz.l[i] = __shfl_down(v.zzz.l[i], d, 64);
+    }
+    return r;
+}
+
+// ONE launch accumulates every bucket of every blob of the batch: grid = (kHeavyBlocks + 16, blobs).
+//
+//  * blockIdx.x >= kHeavyBlocks -- light buckets (<= kHeavyThreshold entries; all of them for uniformly
+//    random scalars): one lane per bucket, lanes ordered by population so a wave's 64 trip counts are
+//    near-equal; the XYZZ accumulator never leaves VGPRs. Field products are inlined here
+//    (G1Affine29i / G1Xyzz29i: no call overhead, no forced s_waitcnt at call boundaries).
+//  * blockIdx.x < kHeavyBlocks -- heavy buckets: one WAVE per bucket, entries strided over the 64
+//    lanes, then a shuffle tree. They are the normal case, not an edge case: blobs whose elements
+//    carry 31 payload bytes (the usual EIP-4844 packing, and the bench workload) leave only the digits
+//    0..2 in the top window, so ~2000 entries land in one bucket; adversarial blobs (all scalars equal)
+//    put 4096 entries into each of 20 buckets. These few long-running waves are dispatched first and
+//    overlap with the light blocks of the same launch.
+constexpr int kHeavyBlocks = 2;                       // x 4 waves = 8 heavy buckets in flight per blob
+constexpr int kLightBlocks = kNumBuckets / kAccThreads;
+
 __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine29 *__restrict__ table,
                                                                    const uint32_t *__restrict__ sorted,
                                                                    const uint32_t *__restrict__ bucket_start,
                                                                    const uint32_t *__restrict__ perm,
                                                                    G1Xyzz29 *__restrict__ buckets) {
     const size_t blob = blockIdx.y;
-    const int t = blockIdx.x * kAccThreads + threadIdx.x;  // rank in the population order
-    const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
-    if ((uint32_t)t < pm[kNumBuckets]) return;  // heavy: k_heavy_bucket_accumulate's job
-    const uint32_t b = pm[t];
-    const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
-    const uint32_t begin = bs[b], end = bs[b + 1];
-    const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
-
-    G1Xyzz29 acc = G1Xyzz29::infinity();
-    for (uint32_t k = begin; k < end; k++) {
-        uint32_t e = ent[k];
-        G1Affine29 p = table[e & ~kEntryNegBit];
-        acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
-    }
-    buckets[blob * (size_t)kNumBuckets + b] = acc;
-}
-
-// Heavy buckets: a whole workgroup per bucket, entries strided over the lanes, LDS tree at the end.
-// They appear whenever many scalars share a digit: the top window of blobs whose elements carry 31
-// payload bytes (the common EIP-4844 packing, and the bench workload) holds only the values 0..2, and
-// adversarial blobs (all scalars equal) put 4096 entries into each of 20 buckets.
-constexpr int kHeavyBlocksPerBlob = 8;
-
-__global__ __launch_bounds__(kAccThreads) void k_heavy_bucket_accumulate(const G1Affine29 *__restrict__ table,
-                                                                         const uint32_t *__restrict__ sorted,
-                                                                         const uint32_t *__restrict__ bucket_start,
-                                                                         const uint32_t *__restrict__ perm,
-                                                                         G1Xyzz29 *__restrict__ buckets) {
-    __shared__ G1Xyzz29 sh[kAccThreads];
-    const size_t blob = blockIdx.y;
-    const int tid = threadIdx.x;
     const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
     const uint32_t n_heavy = pm[kNumBuckets];
     const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
     const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
-    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const uint32_t b = pm[h];
-        const uint32_t begin = bs[b], end = bs[b + 1];
-        G1Xyzz29 acc = G1Xyzz29::infinity();
-        for (uint32_t k = begin + tid; k < end; k += kAccThreads) {
-            uint32_t e = ent[k];
-            G1Affine29 p = table[e & ~kEntryNegBit];
-            acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
+
+    if (blockIdx.x < kHeavyBlocks) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t wave = blockIdx.x * (kAccThreads / 64) + (threadIdx.x >> 6);
+        for (uint32_t h = wave; h < n_heavy; h += kHeavyBlocks * (kAccThreads / 64)) {
+            const uint32_t b = pm[h];
+            const uint32_t begin = bs[b], end = bs[b + 1];
+            G1Xyzz29 acc = G1Xyzz29::infinity();
+            for (uint32_t k = begin + lane; k < end; k += 64) {
+                uint32_t e = ent[k];
+                G1Affine29 p = table[e & ~kEntryNegBit];
+                acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                G1Xyzz29 other = wave_shfl_down(acc, d);
+                if (lane < d) acc = xyzz_add(acc, other);
+            }
+            if (lane == 0) buckets[blob * (size_t)kNumBuckets + b] = acc;
         }
-        sh[tid] = acc;
-        __syncthreads();
-        for (int d = kAccThreads / 2; d >= 1; d >>= 1) {
-            if (tid < d) sh[tid] = xyzz_add(sh[tid], sh[tid + d]);
-            __syncthreads();
-        }
-        if (tid == 0) buckets[blob * (size_t)kNumBuckets + b] = sh[0];
-        __syncthreads();
+        return;
     }
+
+    const uint32_t t = (blockIdx.x - kHeavyBlocks) * kAccThreads + threadIdx.x;  // rank in the population order
+    if (t < n_heavy) return;
+    const uint32_t b = pm[t];
+    const uint32_t begin = bs[b], end = bs[b + 1];
+    const G1Affine29i *tab = (const G1Affine29i *)table;
+    G1Xyzz29i acc = G1Xyzz29i::infinity();
+    for (uint32_t k = begin; k < end; k++) {
+        uint32_t e = ent[k];
+        G1Affine29i p = tab[e & ~kEntryNegBit];
+        acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
+    }
+    ((G1Xyzz29i *)buckets)[blob * (size_t)kNumBuckets + b] = acc;
 }
 
 void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, const uint32_t *bucket_start,
                               const uint32_t *perm, G1Xyzz29 *buckets, size_t n_blobs, hipStream_t st) {
-    {
-        ProfScope p("k_bucket_accumulate", st);
-        hipLaunchKernelGGL(k_bucket_accumulate, dim3(kNumBuckets / kAccThreads, (unsigned)n_blobs), dim3(kAccThreads),
-                           0, st, table, sorted, bucket_start, perm, buckets);
-    }
-    {
-        ProfScope p("k_heavy_bucket_accumulate", st);
-        hipLaunchKernelGGL(k_heavy_bucket_accumulate, dim3(kHeavyBlocksPerBlob, (unsigned)n_blobs), dim3(kAccThreads),
-                           0, st, table, sorted, bucket_start, perm, buckets);
-    }
+    ProfScope p("k_bucket_accumulate", st);
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3(kHeavyBlocks + kLightBlocks, (unsigned)n_blobs), dim3(kAccThreads), 0,
+                       st, table, sorted, bucket_start, perm, buckets);
 }
 
 // ------------------------------------------------------------------------------------------------
