@@ -177,6 +177,10 @@ size_t lwkzg_setup_image_bytes(void);
 C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void *stream);
 C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev);
 
+/* Host-only test hook for the verify side: prod_i e(P_i, Q_i) == 1 for up to 4 pairs of ZCash-compressed
+ * points (G1 48 bytes, G2 96 bytes; a pair with a point at infinity contributes 1). No GPU, no settings. */
+C_KZG_RET lwkzg_pairing_product_is_one(bool *ok, const uint8_t *g1_compressed, const uint8_t *g2_compressed, size_t n);
+
 /* Engine introspection / profiling (bench.py). Kernel timings use hipEvents on the launch stream. */
 int lwkzg_device_count(void);
 int lwkzg_set_device(int ordinal);                 /* device used by subsequent load_* calls */

@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_setup_image_bytes", "lwkzg_setup_export_device", "lwkzg_setup_import_device",
     "lwkzg_device_count", "lwkzg_set_device", "lwkzg_version", "lwkzg_last_error",
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
-    "lwkzg_msm_window_bits", "lwkzg_msm_num_windows",
+    "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
 ]
 
 _lib = None
@@ -92,6 +92,7 @@ def lib():
     l.lwkzg_profile_reset.restype = None
     l.lwkzg_profile_report.argtypes = [C.c_char_p, sz]
     l.lwkzg_profile_report.restype = sz
+    l.lwkzg_pairing_product_is_one.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, sz]
     _lib = l
     return l
 
@@ -287,6 +288,15 @@ def g1_lincomb_setup_device(out_ptr, scalars_be_ptr, n_msm, ts, stream=None):
 
 def fr_ntt4096_device(out_ptr, in_ptr, n, inverse, ts, stream=None):
     _check("lwkzg_fr_ntt4096_device", lib().lwkzg_fr_ntt4096_device(out_ptr, in_ptr, n, 1 if inverse else 0, ts.ref(), stream))
+
+
+def pairing_product_is_one(g1_compressed, g2_compressed):
+    """prod e(P_i, Q_i) == 1 for concatenated compressed points (host-only test hook)."""
+    n = len(g1_compressed) // 48
+    assert len(g1_compressed) == 48 * n and len(g2_compressed) == 96 * n
+    ok = C.c_bool(False)
+    _check("lwkzg_pairing_product_is_one", lib().lwkzg_pairing_product_is_one(C.byref(ok), g1_compressed, g2_compressed, n))
+    return bool(ok.value)
 
 
 def setup_image_bytes():

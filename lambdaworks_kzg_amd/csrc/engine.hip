@@ -376,6 +376,139 @@ C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const
     return C_KZG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// verify-side helpers: host buffers in and out, kernels in between
+
+static C_KZG_RET first_status(Ctx *c, const int32_t *d_status, size_t n, hipStream_t st) {
+    std::vector<int32_t> h(n);
+    LWK_HIP(hipMemcpyAsync(h.data(), d_status, n * 4, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; i++)
+        if (h[i] != 0) {
+            set_error("input %zu rejected (status %d)", i, h[i]);
+            return (C_KZG_RET)h[i];
+        }
+    return C_KZG_OK;
+}
+
+C_KZG_RET challenge_eval_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode, uint8_t *z32_out,
+                              uint8_t *y32_out, uint8_t *canon48_out) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    const int le = mode == LWKZG_MODE_CKZG;
+    hipStream_t st = c->stream;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        C_KZG_RET rc = ctx_reserve(c, m);
+        if (rc != C_KZG_OK) return rc;
+        Workspace &w = c->ws;
+        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off * (size_t)kBlobBytes, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
+        LWK_HIP(hipMemcpyAsync(w.comm48, comm48 + 48 * off, m * 48, hipMemcpyHostToDevice, st));
+        LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
+        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, st);
+        coefficients_stage(c, w.blobs, m, mode, w.status, st);
+        launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
+        launch_eval_quotient(w.scalars, w.z, w.scalars2, w.ybytes, le, m, st);
+        launch_fr_mont_to_bytes(w.z, w.zbytes, le, m, st);
+        LWK_HIP(hipMemcpyAsync(z32_out + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipMemcpyAsync(y32_out + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
+        if (canon48_out) LWK_HIP(hipMemcpyAsync(canon48_out + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        rc = first_status(c, w.status, m, st);
+        if (rc != C_KZG_OK) return rc;
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET validate_points_host(Ctx *c, const uint8_t *pts48, size_t n, int mode, uint8_t *canon48_out) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    const int le = mode == LWKZG_MODE_CKZG;
+    hipStream_t st = c->stream;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        C_KZG_RET rc = ctx_reserve(c, m);
+        if (rc != C_KZG_OK) return rc;
+        Workspace &w = c->ws;
+        LWK_HIP(hipMemcpyAsync(w.comm48, pts48 + 48 * off, m * 48, hipMemcpyHostToDevice, st));
+        LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
+        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, st);
+        LWK_HIP(hipMemcpyAsync(canon48_out + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        rc = first_status(c, w.status, m, st);
+        if (rc != C_KZG_OK) return rc;
+    }
+    return C_KZG_OK;
+}
+
+C_KZG_RET lincomb3_host(Ctx *c, const uint8_t *proofs48, const uint8_t *comms48, const uint8_t *sc_r, const uint8_t *sc_rz,
+                        size_t n, uint8_t sums[3][96], int infs[3]) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t nblk = (n + 255) / 256;
+    uint8_t *d_pts = nullptr, *d_sc = nullptr, *d_aff = nullptr;
+    G1Xyzz *d_part = nullptr;
+    int32_t *d_inf = nullptr;
+    C_KZG_RET rc = C_KZG_ERROR;
+    std::vector<uint8_t> h_aff(96 * nblk);
+    std::vector<int32_t> h_inf(nblk);
+    do {
+        if (hipMalloc((void **)&d_pts, 48 * n) != hipSuccess || hipMalloc((void **)&d_sc, 32 * n) != hipSuccess ||
+            hipMalloc((void **)&d_part, nblk * sizeof(G1Xyzz)) != hipSuccess ||
+            hipMalloc((void **)&d_aff, 96 * nblk) != hipSuccess || hipMalloc((void **)&d_inf, 4 * nblk) != hipSuccess) {
+            set_error("hipMalloc failed in lincomb3_host");
+            rc = C_KZG_MALLOC;
+            break;
+        }
+        const uint8_t *pts[3] = {proofs48, proofs48, comms48};
+        const uint8_t *scs[3] = {sc_r, sc_rz, sc_r};
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; k++) {
+            ok = hipMemcpyAsync(d_pts, pts[k], 48 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
+                 hipMemcpyAsync(d_sc, scs[k], 32 * n, hipMemcpyHostToDevice, st) == hipSuccess;
+            if (!ok) break;
+            launch_lincomb_terms(d_pts, d_sc, d_part, n, st);
+            launch_xyzz_to_affine_be(d_part, d_aff, d_inf, nblk, st);
+            ok = hipMemcpyAsync(h_aff.data(), d_aff, 96 * nblk, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(h_inf.data(), d_inf, 4 * nblk, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess;
+            if (!ok) break;
+            // the handful of per-block partial sums are added on the host
+            G1Xyzz acc = G1Xyzz::infinity();
+            for (size_t b = 0; b < nblk; b++) {
+                if (h_inf[b]) continue;
+                uint32_t raw[12];
+                G1Affine a;
+                raw_from_be<12>(raw, &h_aff[96 * b]);
+                a.x = fe_from_raw<FpParams>(raw);
+                raw_from_be<12>(raw, &h_aff[96 * b + 48]);
+                a.y = fe_from_raw<FpParams>(raw);
+                acc = xyzz_madd(acc, a);
+            }
+            infs[k] = acc.is_inf() ? 1 : 0;
+            memset(sums[k], 0, 96);
+            if (!infs[k]) {
+                G1Affine a = xyzz_to_affine(acc);
+                uint32_t raw[12];
+                fe_to_raw<FpParams>(raw, a.x);
+                raw_to_be<12>(sums[k], raw);
+                fe_to_raw<FpParams>(raw, a.y);
+                raw_to_be<12>(sums[k] + 48, raw);
+            }
+        }
+        if (!ok) {
+            set_error("lincomb3_host: device work failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        rc = C_KZG_OK;
+    } while (0);
+    if (d_pts) hipFree(d_pts);
+    if (d_sc) hipFree(d_sc);
+    if (d_part) hipFree(d_part);
+    if (d_aff) hipFree(d_aff);
+    if (d_inf) hipFree(d_inf);
+    return rc;
+}
+
 }  // namespace lwk
 
 // =================================================================================================

@@ -245,6 +245,20 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
                        z_mont, (uint4 *)quot_raw, y_out, le);
 }
 
+// Montgomery Fr -> 32 bytes in the requested byte order, one lane each (z of a batch going back to the host)
+__global__ __launch_bounds__(64) void k_fr_mont_to_bytes(const Fr *__restrict__ in, uint8_t *__restrict__ out, int le,
+                                                         size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    fe_to_raw<FrParams>(s, in[i]);
+    if (le) raw_to_le<8>(out + 32 * i, s); else raw_to_be<8>(out + 32 * i, s);
+}
+void launch_fr_mont_to_bytes(const Fr *in, uint8_t *out, int le, size_t n, hipStream_t st) {
+    ProfScope p("k_fr_mont_to_bytes", st);
+    hipLaunchKernelGGL(k_fr_mont_to_bytes, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in, out, le, n);
+}
+
 __global__ __launch_bounds__(64) void k_z_from_bytes(const uint8_t *__restrict__ zb, Fr *__restrict__ z_mont,
                                                      int32_t *__restrict__ status, int le, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -10,14 +10,11 @@
 // check. Here the sign bit is honoured, which is the only reading under which verification against
 // [tau]G2 is meaningful; for a setup file the reference handles correctly both agree.
 #include "engine.h"
+#include "fp2.h"
 
 #include <string.h>
 
 namespace lwk {
-
-struct Fp2 {
-    Fp c0, c1;  // c0 + c1 * i, i^2 = -1
-};
 
 static inline Fp2 fp2_add(const Fp2 &a, const Fp2 &b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
 static inline Fp2 fp2_sub(const Fp2 &a, const Fp2 &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }

@@ -43,6 +43,9 @@ void launch_g1_decompress(const uint8_t *in48, G1Affine *out, int32_t *status, s
 void launch_g1_from_blst(const uint64_t *blst_p1, G1Affine *out, int32_t *status, size_t n, hipStream_t st);
 // affine Montgomery -> reference blst_p1 layout (g1_point_to_blst_p1, /root/reference/src/srs.rs:131-153)
 void launch_g1_to_blst(const G1Affine *in, const int32_t *status, uint64_t *blst_p1, size_t n, hipStream_t st);
+// sum_i [k_i] P_i over caller points (validated canonical compressed bytes): per-block partial sums
+void launch_lincomb_terms(const uint8_t *points48, const uint8_t *scalars_be, G1Xyzz *partial, size_t n, hipStream_t st);
+void launch_xyzz_to_affine_be(const G1Xyzz *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 // T[j][i] = 2^(13 j) P_i
 void launch_build_table(const G1Affine *points, G1Affine29 *table, hipStream_t st);
 
@@ -57,6 +60,7 @@ void launch_bitrev_permute(const Fr *in, Fr *out, size_t n_blobs, hipStream_t st
 void launch_fr_be_to_mont(const uint8_t *in_be, Fr *out, size_t n_elems, hipStream_t st);
 void launch_fr_mont_to_be(const Fr *in, uint8_t *out_be, size_t n_elems, hipStream_t st);
 void launch_raw_to_be(const uint32_t *raw, uint8_t *out_be, size_t n_elems, hipStream_t st);
+void launch_fr_mont_to_bytes(const Fr *in, uint8_t *out, int le, size_t n, hipStream_t st);
 // y = p(z) and q = (p - y)/(x - z) per blob (Polynomial::evaluate + ruffini_division, call sites
 // /root/reference/src/lib.rs:320,329,389,394). coeffs_raw/quot_raw: canonical limbs. y_out: 32 bytes,
 // big-endian (le = 0) or little-endian (le = 1); may be NULL.
@@ -72,5 +76,6 @@ void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, in
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
                                  hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st);
+void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 
 }  // namespace lwk

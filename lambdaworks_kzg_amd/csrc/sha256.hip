@@ -106,6 +106,58 @@ void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, 
     hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blobs, canon48, z_mont, le, n);
 }
 
+// host SHA-256 for the one batch-level hash of verify_blob_kzg_proof_batch (compute_r_powers,
+// /root/reference/src/utils.rs:166-206): a few hundred KB once per call, not worth a launch
+static const uint32_t kShaKHost[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static void sha256_block_host(uint32_t h[8], const uint8_t *b) {
+    auto ror = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + kShaKHost[i] + w[i];
+        uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len) {
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) sha256_block_host(h, msg + i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - i;
+    for (size_t k = 0; k < rem; k++) tail[k] = msg[i + k];
+    tail[rem] = 0x80;
+    size_t tl = rem + 9 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha256_block_host(h, tail);
+    if (tl == 128) sha256_block_host(h, tail + 64);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(h[k] >> 24);
+        out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(h[k] >> 8);
+        out[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
 // decompress_g1_point (incl. [r]P subgroup check) then compress_g1_point again, as
 // compute_blob_kzg_proof + compute_challenge do (/root/reference/src/lib.rs:372-375, src/utils.rs:138).
 __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__restrict__ comm48,

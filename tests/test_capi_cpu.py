@@ -83,3 +83,21 @@ def test_fails_loudly_without_gpu(K):
     with pytest.raises(K.KzgError) as e:
         K.TrustedSetup.from_file(SETUP_PATH)
     assert e.value.rc == K.C_KZG_ERROR and "no CPU fallback" in str(e.value)
+
+
+def test_host_pairing_product(K, oracle, oracle_setup):
+    """verify side, host only: e(G, [tau]G2) * e(-[tau]G, G2) == 1 for the tau = 1337 setup, and negatives."""
+    from lambdaworks_kzg_amd import capi
+    g1, g2 = oracle_setup.g1_compressed(), oracle_setup.g2_compressed()
+    G, tG, H, tH = g1[:48], g1[48:96], g2[:96], g2[96:192]
+
+    def negc(c):
+        b = bytearray(c)
+        b[0] ^= 0x20          # flip the ZCash sign bit: -P
+        return bytes(b)
+
+    assert capi.pairing_product_is_one(G + negc(tG), tH + H) is True
+    assert capi.pairing_product_is_one(G + negc(G), tH + H) is False
+    assert capi.pairing_product_is_one(oracle.g1_generator_mul(5) + negc(oracle.g1_generator_mul(5 * 1337)), tH + H) is True
+    assert capi.pairing_product_is_one(G, H) is False
+    assert capi.pairing_product_is_one(bytes([0xc0]) + bytes(47), H) is True      # e(O, Q) = 1
