@@ -46,6 +46,19 @@ def _cpu_worker(args):
     return time.perf_counter() - t0, outs
 
 
+def usable_cores():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota
+    (the GPU boxes expose 256 hardware threads but a quota of 16 CPUs)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(gpu_outputs):
     """Time the oracle on the host: all cores, one blob stream per process. Bounded sample."""
     import multiprocessing as mp
@@ -57,7 +70,7 @@ def cpu_baseline(gpu_outputs):
         lib_path = os.path.join(ROOT, "oracle", "liboracle_kzg.so")
         if not os.path.exists(lib_path):
             lib_path = O.build()
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     # one thread first: calibrates the per-blob cost and is itself the reference's configuration
     t1, o1 = _cpu_worker((lib_path, 0, 4))
     per_blob = t1 / 4
@@ -97,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BLOBS_PER_GPU, help="blobs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op", default="commit", choices=["commit", "blob_proof"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,12 +129,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    K.set_device(local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a real N-GPU node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    K.set_device(dev_index)
     K.set_mode(K.MODE_REFERENCE)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # trusted setup: rank 0 parses + validates + builds the fixed-base table, one RCCL broadcast delivers it
     t_load0 = time.perf_counter()
@@ -188,6 +206,13 @@ def main():
         nwin, entries = K.lib().lwkzg_msm_num_windows(), None
         adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
         mads_per_launch = msms_per_launch * adds_per_msm * 10 * 288
+        traffic = None
+        try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size only
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("batch_blobs_per_launch") == n and args.op == "commit":
+                traffic = pmc["kernels"][dom]["traffic_bytes"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "blob_to_kzg_commitment ops/sec (4096-elem blobs)" if args.op == "commit" else "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
             "value": value,
@@ -206,7 +231,10 @@ def main():
                        "blobs_per_gpu_per_step": n, "mode": "reference (big-endian monomial)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes per launch at the L2's memory side from rocprofv3 FETCH_SIZE (raw) + WRITE_SIZE, "
+                                         "separate passes (profiles/pmc_traffic.json); mostly Infinity-Cache-served re-reads of "
+                                         "the 9.2 MB fixed-base table, see DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": msms_per_launch * ALGO_BYTES_PER_MSM,
                          "avg_launch_ms": avg_ms,
                          "note": "integer-ALU bound, not HBM bound (about 600 int-ops per algorithmic byte): see int_mad",

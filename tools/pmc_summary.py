@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs as
+MI355X_MICROARCH.md prescribes) into profiles/pmc_traffic.json, which bench.py reads to fill
+roofline.traffic.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python tools/pmc_summary.py out/fetch_counter_collection.csv out/write_counter_collection.csv rNN
+
+Units: the counters are in KiB. gfx950 correction (guide, section HBM): FETCH_SIZE tallies 128-byte
+requests at 64 bytes for wide coalesced streams, i.e. reads exactly half; for this kernel's per-lane
+112-byte gathers the factor is uncalibrated, so both the raw and the doubled read side are recorded and
+`traffic_bytes` uses the raw read side (a lower bound). Infinity-Cache hits appear to be counted: this is
+traffic at the L2's memory side, not necessarily HBM.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("lwk::", "")
+        agg[name].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    fetch, write, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    f, w = per_kernel(fetch), per_kernel(write)
+    out = {"round": tag, "batch_blobs_per_launch": 1024, "unit": "bytes per launch (average)", "kernels": {}}
+    for k in sorted(set(f) | set(w)):
+        if not k.startswith("k_"):
+            continue
+        fr, wr = f.get(k, 0.0), w.get(k, 0.0)
+        out["kernels"][k] = {"fetch_raw": fr, "fetch_doubled": 2 * fr, "write": wr, "traffic_bytes": fr + wr}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "pmc_traffic.json")
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
+    for k, v in out["kernels"].items():
+        print("  %-26s fetch %.3e  write %.3e" % (k, v["fetch_raw"], v["write"]))
+
+
+if __name__ == "__main__":
+    main()
