@@ -202,10 +202,13 @@ def main():
         msms_per_launch = n
         achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
-        # integer picture: 8M+2S per mixed add, 288 32x32 multiply-adds per Montgomery product (12-limb CIOS)
-        nwin, entries = K.lib().lwkzg_msm_num_windows(), None
+        # integer picture: a mixed add is 8 Montgomery products (392 v_mad_u64_u32 each on 14x29-bit limbs) and
+        # 2 squares (301 each); peak = v_mad_u64_u32 issue rate measured by tools/ubench.hip on MI355X
+        # (profiles/r01_ubench_instruction_rates.jsonl: 2.93e13 lane-mads/s at 8 waves/SIMD)
+        nwin = K.lib().lwkzg_msm_num_windows()
         adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
-        mads_per_launch = msms_per_launch * adds_per_msm * 10 * 288
+        mads_per_launch = msms_per_launch * adds_per_msm * (8 * 392 + 2 * 301)
+        INT_MAD_PEAK = 2.93e13
         traffic = None
         try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size only
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -239,7 +242,9 @@ def main():
                          "avg_launch_ms": avg_ms,
                          "note": "integer-ALU bound, not HBM bound (about 600 int-ops per algorithmic byte): see int_mad",
                          "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
-                                     "achieved_Gmad_per_s": mads_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}},
+                                     "achieved_Gmad_per_s": mads_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                                     "peak_Gmad_per_s": INT_MAD_PEAK / 1e9,
+                                     "frac": (mads_per_launch / (avg_ms * 1e-3) / INT_MAD_PEAK) if avg_ms > 0 else 0.0}},
             "kernels": kernels,
             "setup_load_s": t_load,
         }

@@ -290,10 +290,22 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
     const uint32_t begin = bs[b], end = bs[b + 1];
     const G1Affine29i *tab = (const G1Affine29i *)table;
     G1Xyzz29i acc = G1Xyzz29i::infinity();
-    for (uint32_t k = begin; k < end; k++) {
-        uint32_t e = ent[k];
+    if (begin < end) {
+        // software pipeline: the next entry's index and its table point are in flight while the current
+        // mixed addition (about 4k v_mad_u64_u32) executes; entry -> point is a dependent gather
+        uint32_t e = ent[begin];
         G1Affine29i p = tab[e & ~kEntryNegBit];
-        acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
+        for (uint32_t k = begin; k < end; k++) {
+            uint32_t e_next = e;
+            G1Affine29i p_next = p;
+            if (k + 1 < end) {
+                e_next = ent[k + 1];
+                p_next = tab[e_next & ~kEntryNegBit];
+            }
+            acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
+            e = e_next;
+            p = p_next;
+        }
     }
     ((G1Xyzz29i *)buckets)[blob * (size_t)kNumBuckets + b] = acc;
 }
@@ -308,7 +320,7 @@ void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, c
 // ------------------------------------------------------------------------------------------------
 // bucket reduction: S = sum_{k=1..NB} k * B_k per blob
 
-constexpr int kRedThreads = 256;
+constexpr int kRedThreads = 128;
 constexpr int kBucketsPerRedThread = kNumBuckets / kRedThreads;  // 16
 static_assert((kBucketsPerRedThread & (kBucketsPerRedThread - 1)) == 0, "chunk must be a power of two");
 
