@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BLOBS_PER_GPU, help="blobs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op", default="commit", choices=["commit", "blob_proof"])
+    ap.add_argument("--mode", default="reference", choices=["reference", "ckzg"],
+                    help="reference = lambdaworks_kzg semantics (default, the headline); ckzg = c-kzg-4844 semantics (adds the inverse NTT)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
 
@@ -133,7 +135,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     K.set_device(dev_index)
-    K.set_mode(K.MODE_REFERENCE)
+    K.set_mode(K.MODE_REFERENCE if args.mode == "reference" else K.MODE_CKZG)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -149,7 +151,7 @@ def main():
 
     n = args.batch
     first = rank * n                       # shard: blob k of the job lives on GPU floor(k / n)
-    host = np.frombuffer(B.synthetic_batch(first, n), dtype=np.uint8)
+    host = np.frombuffer(B.synthetic_batch(first, n, big_endian=(args.mode == "reference")), dtype=np.uint8)
     d_blobs = torch.from_numpy(host.copy()).to(dev)
     d_out = torch.empty(48 * n, dtype=torch.uint8, device=dev)
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -231,7 +233,7 @@ def main():
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
             "config": {"workload": "BASELINE configs[1]: single-GPU G1 Pippenger MSM, 4096 scalars, batch=%d synthetic blobs "
                                    "per GPU per step, device-resident, bit-exact vs CPU" % n,
-                       "blobs_per_gpu_per_step": n, "mode": "reference (big-endian monomial)", "op": args.op,
+                       "blobs_per_gpu_per_step": n, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -248,7 +250,7 @@ def main():
             "kernels": kernels,
             "setup_load_s": t_load,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "reference":
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
             res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)])
         print(json.dumps(res), flush=True)

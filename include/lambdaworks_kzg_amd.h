@@ -181,6 +181,10 @@ C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev);
  * points (G1 48 bytes, G2 96 bytes; a pair with a point at infinity contributes 1). No GPU, no settings. */
 C_KZG_RET lwkzg_pairing_product_is_one(bool *ok, const uint8_t *g1_compressed, const uint8_t *g2_compressed, size_t n);
 
+/* Host-only test hook: digests[i] = SHA-256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blobs[i] | commitments[i]),
+ * the compute_challenge message (src/utils.rs:120-144), as the host-pointer proof entry points compute it. */
+C_KZG_RET lwkzg_challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *commitments48, size_t n);
+
 /* Engine introspection / profiling (bench.py). Kernel timings use hipEvents on the launch stream. */
 int lwkzg_device_count(void);
 int lwkzg_set_device(int ordinal);                 /* device used by subsequent load_* calls */

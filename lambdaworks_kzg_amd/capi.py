@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_device_count", "lwkzg_set_device", "lwkzg_version", "lwkzg_last_error",
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
+    "lwkzg_challenge_digests_host",
 ]
 
 _lib = None
@@ -93,6 +94,7 @@ def lib():
     l.lwkzg_profile_report.argtypes = [C.c_char_p, sz]
     l.lwkzg_profile_report.restype = sz
     l.lwkzg_pairing_product_is_one.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, sz]
+    l.lwkzg_challenge_digests_host.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz]
     _lib = l
     return l
 
@@ -297,6 +299,14 @@ def pairing_product_is_one(g1_compressed, g2_compressed):
     ok = C.c_bool(False)
     _check("lwkzg_pairing_product_is_one", lib().lwkzg_pairing_product_is_one(C.byref(ok), g1_compressed, g2_compressed, n))
     return bool(ok.value)
+
+
+def challenge_digests_host(blobs, commitments):
+    n = len(commitments) // 48
+    assert len(blobs) == n * BYTES_PER_BLOB
+    out = C.create_string_buffer(32 * max(n, 1))
+    _check("lwkzg_challenge_digests_host", lib().lwkzg_challenge_digests_host(out, blobs, commitments, n))
+    return [out.raw[32 * i:32 * i + 32] for i in range(n)]
 
 
 def setup_image_bytes():

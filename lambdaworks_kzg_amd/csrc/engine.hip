@@ -805,10 +805,31 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         C_KZG_RET rc = ctx_reserve(c, m);
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;
-        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
-        LWK_HIP(hipMemcpyAsync(w.comm48, commitments + off, m * 48, hipMemcpyHostToDevice, c->stream));
-        rc = blob_proof_batch_device(c, w.out48, w.blobs, w.comm48, m, mode, c->stream, w.status);
-        if (rc != C_KZG_OK) return rc;
+        hipStream_t st = c->stream;
+        const int le = mode == LWKZG_MODE_CKZG;
+        const uint8_t *h_blobs = (const uint8_t *)(blobs + off), *h_comm = (const uint8_t *)(commitments + off);
+        LWK_HIP(hipMemcpyAsync(w.blobs, h_blobs, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
+        LWK_HIP(hipMemcpyAsync(w.comm48, h_comm, m * 48, hipMemcpyHostToDevice, st));
+        LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
+        // GPU: validate the commitments (lib.rs:372-375) and parse the blobs ...
+        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, st);
+        coefficients_stage(c, w.blobs, m, mode, w.status, st);
+        std::vector<uint8_t> h_canon(m * 48), h_dig(m * 32);
+        LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        // ... while the host threads hash (the blobs are in host memory here; one GPU lane would need ~7 ms per
+        // 131 KB message, a core with SHA extensions ~0.1 ms). The digests assume the commitment bytes are already
+        // canonical, which the GPU's re-compression confirms or refutes below.
+        challenge_digests_host(h_dig.data(), h_blobs, h_comm, m);
+        LWK_HIP(hipStreamSynchronize(st));
+        if (memcmp(h_canon.data(), h_comm, m * 48) == 0) {
+            LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
+            launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
+        } else {
+            // a non-canonical but valid encoding (or an invalid point, reported through status): hash on the GPU
+            launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
+        }
+        launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+        msm_stages(c, w.scalars2, w.out48, m, st);
         std::vector<uint8_t> h_out(m * 48);
         LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
         rc = collect_status(c, w.status, m, off, first_bad);

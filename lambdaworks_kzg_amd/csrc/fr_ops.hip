@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void k_z_from_bytes(const uint8_t *__restrict__
     uint32_t s[8];
     if (le) {
         raw_from_le<8>(s, zb + 32 * i);
-        if (raw_geq<8>(s, FrParams::MOD)) status[i] = kStatusBadArgs;
+        if (status && raw_geq<8>(s, FrParams::MOD)) status[i] = kStatusBadArgs;  // status == NULL: reduce silently (digests)
     } else {
         raw_from_be<8>(s, zb + 32 * i);
     }

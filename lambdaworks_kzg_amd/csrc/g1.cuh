@@ -221,12 +221,55 @@ LWK_HD G1Xyzz xyzz_mul_affine(const G1Affine &p, const uint32_t *k) {
     return acc;
 }
 
-// check_point_is_in_subgroup, /root/reference/src/compression.rs:22-27: [r]P == O
-LWK_HD bool g1_in_subgroup(const G1Affine &p) {
+// check_point_is_in_subgroup, /root/reference/src/compression.rs:22-27, as the reference computes it:
+// [r]P == O by a 255-bit double-and-add. Kept as the definition (and used by tests); the production
+// paths use the equivalent endomorphism test below, which is three times shorter.
+LWK_HD bool g1_in_subgroup_by_order(const G1Affine &p) {
     uint32_t r[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) r[i] = FrParams::MOD[i];
     return xyzz_mul_affine<8>(p, r).is_inf();
+}
+
+// [|z|]T for the curve parameter |z| = 0xd201000000010000 (bits 63, 62, 60, 57, 48, 16), T in XYZZ
+template <class X>
+LWK_HD X xyzz_mul_by_z(const X &t) {
+    X acc = t;  // bit 63
+    for (int i = 62; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if (i == 62 || i == 60 || i == 57 || i == 48 || i == 16) acc = xyzz_add(acc, t);
+    }
+    return acc;
+}
+
+// Same accept/reject as [r]P == O for every point of E(Fp), by the endomorphism phi(x, y) = (beta x, y),
+// which acts on G1 as multiplication by lambda = -z^2 (lambda^2 + lambda + 1 = r-multiple, since
+// r = z^4 - z^2 + 1):  P in G1  <=>  [z^2]P + phi(P) == O   (M. Scott, "A note on group membership tests for
+// G1, G2 and GT on BLS pairing-friendly curves", 2021; the test blst uses). 126 doublings + 10 additions
+// instead of 255 + ~128. X is the XYZZ type to compute in; (px, py) affine, beta in the same field.
+template <class X, class FX, class FY, class FB>
+LWK_HD bool g1_in_subgroup_endo(const FX &px, const FY &py, const FB &beta) {
+    X p = X::from_affine(px, py);
+    X q = xyzz_mul_by_z(xyzz_mul_by_z(p));  // [z^2]P  (z < 0, squared)
+    if (q.is_inf()) return false;           // P has small order dividing z^2: not in G1 (r is prime, r !| z^2)
+    // q == -phi(P) = (beta x, -y)  <=>  X_q == beta x ZZ_q  and  Y_q == -y ZZZ_q
+    auto dx = q.x - (beta * px) * q.zz;
+    auto sy = q.y + py * q.zzz;
+    return dx.is_zero() && sy.is_zero();
+}
+
+// beta = 0x5f19672fdf76ce51ba69c6076a0f77eaddb3a93be6f89688de17d813620a00022e01fffffffefffe (canonical limbs)
+LWK_HD void g1_beta_raw(uint32_t raw[12]) {
+    const uint32_t b[12] = {0xfffefffeu, 0x2e01ffffu, 0x620a0002u, 0xde17d813u, 0xe6f89688u, 0xddb3a93bu,
+                            0x6a0f77eau, 0xba69c607u, 0xdf76ce51u, 0x5f19672fu, 0x00000000u, 0x00000000u};
+#pragma unroll
+    for (int i = 0; i < 12; i++) raw[i] = b[i];
+}
+
+LWK_HD bool g1_in_subgroup(const G1Affine &p) {
+    uint32_t raw[12];
+    g1_beta_raw(raw);
+    return g1_in_subgroup_endo<G1Xyzz>(p.x, p.y, fe_from_raw<FpParams>(raw));
 }
 
 // compress_g1_point, /root/reference/src/compression.rs:33-60 (ZCash format):

@@ -77,5 +77,7 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
                                  hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st);
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
+// sha256_host.hip: digests[i] = SHA-256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blobs[i] | comms[i]) on host threads
+void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n);
 
 }  // namespace lwk

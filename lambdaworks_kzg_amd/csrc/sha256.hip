@@ -158,26 +158,59 @@ void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len) {
     }
 }
 
-// decompress_g1_point (incl. [r]P subgroup check) then compress_g1_point again, as
-// compute_blob_kzg_proof + compute_challenge do (/root/reference/src/lib.rs:372-375, src/utils.rs:138).
+// decompress_g1_point (incl. the subgroup check) then compress_g1_point again, as compute_blob_kzg_proof +
+// compute_challenge do (/root/reference/src/lib.rs:372-375, src/utils.rs:138). One lane per point, all in the
+// 29-bit-limb field: square root (p = 3 mod 4), root selection by the sign flag, endomorphism subgroup
+// test. Re-compressing an affine point needs no inversion: the canonical bytes are x (reduced) + flags.
 __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__restrict__ comm48,
                                                              uint8_t *__restrict__ canon48, int32_t *__restrict__ status,
                                                              int bad_code, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t b[48];
+    uint8_t b[48], o[48];
     for (int k = 0; k < 48; k++) b[k] = comm48[48 * i + k];
-    G1Affine p;
-    p.x = Fp::zero();
-    p.y = Fp::zero();
-    int rc = g1_decompress_nocheck(p, b);
-    uint8_t o[48];
-    if (rc == 0) {
-        if (!g1_in_subgroup(p)) rc = 2;
-        else g1_compress_affine(o, p);
-    } else if (rc == 1) {
-        for (int k = 0; k < 48; k++) o[k] = 0;
-        o[0] = 0xc0;
+    for (int k = 0; k < 48; k++) o[k] = 0;
+    const uint8_t prefix = b[0] >> 5;
+    int rc = 0;
+    if (!(prefix & 4)) {
+        rc = 2;  // not flagged compressed
+    } else if (prefix & 2) {
+        o[0] = 0xc0;  // infinity; remaining input bits are not inspected (compression.rs:73-75)
+    } else {
+        b[0] &= 0x1f;
+        uint32_t raw[12];
+        raw_from_be<12>(raw, b);
+        F29<2> x = f29_from_raw32(raw);  // x >= p is reduced, as upstream from_bytes_be is believed to
+        uint32_t four[12] = {4};
+        F29<2> y2 = (sqr(x) * x + f29_from_raw32(four)) * F29<1>::one();  // the product by R mod p reduces < 4p back to < 2p
+        const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+        F29<2> y = f29_pow<12>(y2, e);  // y2^((p+1)/4)
+        if (!(sqr(y) - y2).is_zero()) {
+            rc = 2;  // x^3 + 4 is not a square: not on the curve
+        } else {
+            uint32_t ry[12], half[12], one[12] = {1};
+            f29_to_raw32(ry, y);
+            // y is the greater root  <=>  y > (p - 1) / 2
+            raw_sub<12>(half, FpParams::MOD, one);
+#pragma unroll
+            for (int k = 0; k < 11; k++) half[k] = (half[k] >> 1) | (half[k + 1] << 31);
+            half[11] >>= 1;
+            bool y_greater = !raw_geq<12>(half, ry);
+            bool want_greater = (prefix & 1) != 0;  // select_sqrt_value_from_third_bit
+            auto ysel = cneg(y, want_greater != y_greater);
+            uint32_t braw[12];
+            g1_beta_raw(braw);
+            if (!g1_in_subgroup_endo<G1Xyzz29>(x, ysel, f29_from_raw32(braw))) {
+                rc = 2;
+            } else {
+                uint32_t rx[12];
+                f29_to_raw32(rx, x);
+                raw_to_be<12>(o, rx);
+                o[0] |= 0x80;
+                if (want_greater) o[0] |= 0x20;
+            }
+        }
     }
     if (rc == 2) {
         status[i] = bad_code;

@@ -1,0 +1,165 @@
+// sha256_host.hip -- Fiat-Shamir hashing on the host for the host-pointer proof entry points.
+//
+// compute_challenge (/root/reference/src/utils.rs:120-154) hashes 131,152 bytes per blob. SHA-256 is
+// strictly sequential per message: one GPU lane needs ~7 ms for it (k_challenge, issue-bound), a CPU
+// core with SHA extensions ~0.1 ms. When the blobs are in host memory anyway (the reference's C ABI),
+// the digests are computed here, one std::thread per slice of the batch, while the GPU validates the
+// commitments and parses the blobs; the device-resident entry points keep using k_challenge.
+#include <immintrin.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "plan.h"
+
+namespace lwk {
+
+void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);  // portable, sha256.hip
+
+namespace {
+
+const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// SHA extensions: state kept as (ABEF, CDGH), four rounds per _mm_sha256rnds2_epu32 pair
+__attribute__((target("sha,sse4.1,ssse3"))) void compress_shani(uint32_t state[8], const uint8_t *data, size_t nblocks) {
+    const __m128i shuf = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i tmp = _mm_loadu_si128((const __m128i *)&state[0]);
+    __m128i st1 = _mm_loadu_si128((const __m128i *)&state[4]);
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);       // CDAB
+    st1 = _mm_shuffle_epi32(st1, 0x1B);       // EFGH
+    __m128i st0 = _mm_alignr_epi8(tmp, st1, 8);   // ABEF
+    st1 = _mm_blend_epi16(st1, tmp, 0xF0);        // CDGH
+    while (nblocks--) {
+        __m128i save0 = st0, save1 = st1;
+        __m128i m0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(data + 0)), shuf);
+        __m128i m1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(data + 16)), shuf);
+        __m128i m2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(data + 32)), shuf);
+        __m128i m3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(data + 48)), shuf);
+        __m128i msg;
+#define RND4(mk, k)                                                              \
+    msg = _mm_add_epi32(mk, _mm_loadu_si128((const __m128i *)&K256[k]));         \
+    st1 = _mm_sha256rnds2_epu32(st1, st0, msg);                                  \
+    msg = _mm_shuffle_epi32(msg, 0x0E);                                          \
+    st0 = _mm_sha256rnds2_epu32(st0, st1, msg);
+#define SCHED(a, b, c, d) /* a = next four words from a, b, c, d (oldest .. newest) */ \
+    a = _mm_sha256msg1_epu32(a, b);                                              \
+    a = _mm_add_epi32(a, _mm_alignr_epi8(d, c, 4));                              \
+    a = _mm_sha256msg2_epu32(a, d);
+        RND4(m0, 0)
+        RND4(m1, 4)
+        RND4(m2, 8)
+        RND4(m3, 12)
+        for (int k = 16; k < 64; k += 16) {
+            SCHED(m0, m1, m2, m3)
+            RND4(m0, k)
+            SCHED(m1, m2, m3, m0)
+            RND4(m1, k + 4)
+            SCHED(m2, m3, m0, m1)
+            RND4(m2, k + 8)
+            SCHED(m3, m0, m1, m2)
+            RND4(m3, k + 12)
+        }
+#undef RND4
+#undef SCHED
+        st0 = _mm_add_epi32(st0, save0);
+        st1 = _mm_add_epi32(st1, save1);
+        data += 64;
+    }
+    tmp = _mm_shuffle_epi32(st0, 0x1B);       // FEBA
+    st1 = _mm_shuffle_epi32(st1, 0xB1);       // DCHG
+    st0 = _mm_blend_epi16(tmp, st1, 0xF0);    // DCBA
+    st1 = _mm_alignr_epi8(st1, tmp, 8);       // HGFE
+    _mm_storeu_si128((__m128i *)&state[0], st0);
+    _mm_storeu_si128((__m128i *)&state[4], st1);
+}
+
+bool have_shani() {
+    static int v = -1;
+    if (v < 0) v = (__builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3")) ? 1 : 0;
+    return v == 1;
+}
+
+// digest of header(32) | blob(131072) | commitment(48), the compute_challenge message
+void challenge_digest(uint8_t out[32], const uint8_t *blob, const uint8_t *comm48) {
+    static const uint8_t header[32] = {'F', 'S', 'B', 'L', 'O', 'B', 'V', 'E', 'R', 'I', 'F', 'Y', '_', 'V', '1', '_',
+                                       0x00, 0x10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!have_shani()) {
+        std::vector<uint8_t> m(32 + kBlobBytes + 48);
+        memcpy(m.data(), header, 32);
+        memcpy(m.data() + 32, blob, kBlobBytes);
+        memcpy(m.data() + 32 + kBlobBytes, comm48, 48);
+        sha256_host(out, m.data(), m.size());
+        return;
+    }
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint8_t blk[64];
+    memcpy(blk, header, 32);
+    memcpy(blk + 32, blob, 32);
+    compress_shani(h, blk, 1);
+    compress_shani(h, blob + 32, (kBlobBytes - 64) / 64);       // 2047 whole blocks straight from the blob
+    memcpy(blk, blob + kBlobBytes - 32, 32);
+    memcpy(blk + 32, comm48, 32);
+    compress_shani(h, blk, 1);
+    memset(blk, 0, 64);
+    memcpy(blk, comm48 + 32, 16);
+    blk[16] = 0x80;
+    const uint64_t bits = (uint64_t)(32 + kBlobBytes + 48) * 8;
+    for (int k = 0; k < 8; k++) blk[63 - k] = (uint8_t)(bits >> (8 * k));
+    compress_shani(h, blk, 1);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(h[k] >> 24);
+        out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(h[k] >> 8);
+        out[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
+unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    // respect a cgroup CPU quota (containers expose every hardware thread but allow far fewer)
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32];
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long long quota = atoll(q);
+            unsigned lim = (unsigned)((quota + period - 1) / period);
+            if (lim >= 1 && lim < n) n = lim;
+        }
+        fclose(f);
+    }
+    return n > 32 ? 32 : n;
+}
+
+}  // namespace
+
+// digests[i] = SHA-256(header | blobs[i] | comms[i]) for i < n, spread over the host threads
+void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n) {
+    unsigned nt = host_threads();
+    if (nt > n) nt = (unsigned)n;
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) {
+        size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        th.emplace_back([=]() {
+            for (size_t i = lo; i < hi; i++)
+                challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i);
+        });
+    }
+    for (auto &t : th) t.join();
+}
+
+}  // namespace lwk

@@ -267,6 +267,13 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     return pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
 }
 
+// test hook: the host-side Fiat-Shamir digests (SHA extensions when the CPU has them), no GPU
+C_KZG_RET lwkzg_challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *commitments48, size_t n) {
+    if (!digests32 || !blobs || !commitments48) return C_KZG_BADARGS;
+    challenge_digests_host(digests32, blobs, commitments48, n);
+    return C_KZG_OK;
+}
+
 // test hook: prod e(P_i, Q_i) == 1 on compressed inputs, host only (no GPU, no settings)
 C_KZG_RET lwkzg_pairing_product_is_one(bool *ok, const uint8_t *g1_compressed, const uint8_t *g2_compressed, size_t n) {
     if (!ok || n > 4) return C_KZG_BADARGS;

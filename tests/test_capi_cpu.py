@@ -101,3 +101,16 @@ def test_host_pairing_product(K, oracle, oracle_setup):
     assert capi.pairing_product_is_one(oracle.g1_generator_mul(5) + negc(oracle.g1_generator_mul(5 * 1337)), tH + H) is True
     assert capi.pairing_product_is_one(G, H) is False
     assert capi.pairing_product_is_one(bytes([0xc0]) + bytes(47), H) is True      # e(O, Q) = 1
+
+
+def test_host_fiat_shamir_digests_match_hashlib(K):
+    """the host-pointer proof entry points hash on the host (SHA extensions when present): same bytes as hashlib"""
+    import hashlib
+    import blobs as B
+    from lambdaworks_kzg_amd import capi
+    blobs = [B.synthetic_blob(i) for i in range(5)] + [B.make_blob("all_ff")]
+    comms = [bytes([0x80 + i]) + bytes(range(47)) for i in range(len(blobs))]
+    got = capi.challenge_digests_host(b"".join(blobs), b"".join(comms))
+    for b, c, g in zip(blobs, comms, got):
+        msg = b"FSBLOBVERIFY_V1_" + (4096).to_bytes(8, "little") + (0).to_bytes(8, "little") + b + c
+        assert g == hashlib.sha256(msg).digest()

@@ -1,0 +1,14 @@
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests/golden')
+import blobs as B
+import lambdaworks_kzg_amd as K
+ts = K.TrustedSetup.from_file('tests/golden/trusted_setup.txt')
+for n in (1, 16, 256):
+    data = B.synthetic_batch(0, n)
+    K.blob_to_kzg_commitment_batch(data, ts)
+    t = time.perf_counter(); comms = K.blob_to_kzg_commitment_batch(data, ts); tc = time.perf_counter() - t
+    cm = b"".join(comms)
+    K.compute_blob_kzg_proof_batch(data, cm, ts)
+    t = time.perf_counter(); pr = K.compute_blob_kzg_proof_batch(data, cm, ts); tp = time.perf_counter() - t
+    t = time.perf_counter(); ok = K.verify_blob_kzg_proof_batch(data, cm, b"".join(pr), n, ts); tv = time.perf_counter() - t
+    print("host API n=%d: commit %.2f ms (%.0f/s)  blob_proof %.2f ms (%.0f/s)  verify_batch %.2f ms ok=%s" % (n, tc*1e3, n/tc, tp*1e3, n/tp, tv*1e3, ok))
