@@ -320,12 +320,14 @@ void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, c
 // ------------------------------------------------------------------------------------------------
 // bucket reduction: S = sum_{k=1..NB} k * B_k per blob
 
-constexpr int kRedThreads = 128;
-constexpr int kBucketsPerRedThread = kNumBuckets / kRedThreads;  // 16
-static_assert((kBucketsPerRedThread & (kBucketsPerRedThread - 1)) == 0, "chunk must be a power of two");
+// Two instantiations: 64 lanes x 64 buckets (fewest additions in total: throughput, large batches) and
+// 512 lanes x 8 buckets (shortest dependent chain: latency, small batches).
 
+template <int kRedThreads>
 __global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz29 *__restrict__ buckets,
                                                                G1Xyzz29 *__restrict__ sums) {
+    constexpr int kBucketsPerRedThread = kNumBuckets / kRedThreads;
+    static_assert((kBucketsPerRedThread & (kBucketsPerRedThread - 1)) == 0, "chunk must be a power of two");
     __shared__ G1Xyzz29 sh[kRedThreads];
     const int t = threadIdx.x;
     const size_t blob = blockIdx.x;
@@ -370,9 +372,25 @@ __global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz29 *_
     }
 }
 
+static int reduce_lanes_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("LWKZG_REDUCE_LANES");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 void launch_bucket_reduce(const G1Xyzz29 *buckets, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st) {
     ProfScope p("k_bucket_reduce", st);
-    hipLaunchKernelGGL(k_bucket_reduce, dim3((unsigned)n_blobs), dim3(kRedThreads), 0, st, buckets, sums);
+    int lanes = reduce_lanes_override();
+    if (lanes == 0) lanes = n_blobs <= 256 ? 512 : 64;
+    if (lanes >= 512)
+        hipLaunchKernelGGL(k_bucket_reduce<512>, dim3((unsigned)n_blobs), dim3(512), 0, st, buckets, sums);
+    else if (lanes >= 128)
+        hipLaunchKernelGGL(k_bucket_reduce<128>, dim3((unsigned)n_blobs), dim3(128), 0, st, buckets, sums);
+    else
+        hipLaunchKernelGGL(k_bucket_reduce<64>, dim3((unsigned)n_blobs), dim3(64), 0, st, buckets, sums);
 }
 
 // ------------------------------------------------------------------------------------------------
