@@ -166,6 +166,14 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
 C_KZG_RET lwkzg_g1_lincomb_setup_device(void *out48_dev, const void *scalars_be_dev, size_t n_msm, const KZGSettings *s,
                                         void *stream);
 
+/* Long MSM over the setup tiled end to end: out = sum_k scalars[k] * g1[k mod 4096], n_terms a positive multiple of
+ * 4096 (e.g. 2^20), scalars big-endian 32-byte, device-resident; out = 48 bytes compressed (device pointer).
+ * One fixed-base 4096-term MSM per tile plus one final sum. */
+C_KZG_RET lwkzg_g1_msm_tiled_device(void *out48_dev, const void *scalars_be_dev, size_t n_terms, const KZGSettings *s,
+                                    void *stream);
+/* Host helper for sharded long MSMs: out = sum of n compressed G1 points (48 bytes each; infinity allowed). */
+C_KZG_RET lwkzg_g1_sum_compressed(uint8_t out48[48], const uint8_t *points48, size_t n);
+
 /* Batched Fr transform on device-resident data: n vectors of 4096 big-endian 32-byte elements,
  * natural order in and out; inverse != 0 scales by 4096^-1. */
 C_KZG_RET lwkzg_fr_ntt4096_device(void *out_dev, const void *in_dev, size_t n, int inverse, const KZGSettings *s,

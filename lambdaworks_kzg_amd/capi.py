@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_device_count", "lwkzg_set_device", "lwkzg_version", "lwkzg_last_error",
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
-    "lwkzg_challenge_digests_host",
+    "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
 ]
 
 _lib = None
@@ -95,6 +95,8 @@ def lib():
     l.lwkzg_profile_report.restype = sz
     l.lwkzg_pairing_product_is_one.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, sz]
     l.lwkzg_challenge_digests_host.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    l.lwkzg_g1_msm_tiled_device.argtypes = [vp, vp, sz, ps, vp]
+    l.lwkzg_g1_sum_compressed.argtypes = [C.c_char_p, C.c_char_p, sz]
     _lib = l
     return l
 
@@ -286,6 +288,17 @@ def compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts, str
 
 def g1_lincomb_setup_device(out_ptr, scalars_be_ptr, n_msm, ts, stream=None):
     _check("lwkzg_g1_lincomb_setup_device", lib().lwkzg_g1_lincomb_setup_device(out_ptr, scalars_be_ptr, n_msm, ts.ref(), stream))
+
+
+def g1_msm_tiled_device(out_ptr, scalars_be_ptr, n_terms, ts, stream=None):
+    _check("lwkzg_g1_msm_tiled_device", lib().lwkzg_g1_msm_tiled_device(out_ptr, scalars_be_ptr, n_terms, ts.ref(), stream))
+
+
+def g1_sum_compressed(points48):
+    n = len(points48) // 48
+    out = C.create_string_buffer(48)
+    _check("lwkzg_g1_sum_compressed", lib().lwkzg_g1_sum_compressed(out, points48, n))
+    return out.raw
 
 
 def fr_ntt4096_device(out_ptr, in_ptr, n, inverse, ts, stream=None):

@@ -138,7 +138,7 @@ C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
     WS_ALLOC(bucket_start, cap * (size_t)(kNumBuckets + 1) * 4);
     WS_ALLOC(perm, cap * (size_t)(kNumBuckets + 1) * 4);
     WS_ALLOC(buckets, cap * (size_t)kNumBuckets * sizeof(G1Xyzz29));
-    WS_ALLOC(sums, cap * sizeof(G1Xyzz29));
+    WS_ALLOC(sums, (cap + 1) * sizeof(G1Xyzz29));  // + one slot for the running total of a tiled MSM
     WS_ALLOC(out48, cap * 48);
     WS_ALLOC(comm48, cap * 48);
     WS_ALLOC(canon48, cap * 48);
@@ -925,6 +925,36 @@ C_KZG_RET lwkzg_g1_lincomb_setup_device(void *out48_dev, const void *scalars_be_
         launch_parse_be_reduce((const uint8_t *)scalars_be_dev + off * (size_t)kBlobBytes, c->ws.scalars, m * kBlobElems, st);
         msm_scalars_raw_device(c, (uint8_t *)out48_dev + 48 * off, c->ws.scalars, m, st);
     }
+    return C_KZG_OK;
+}
+
+// sum_k s_k * g1[k mod 4096] for n_terms = tiles * 4096 scalars (BASELINE config "2^20-point MSM, tiled
+// trusted setup"): one 4096-term fixed-base MSM per tile, then one sum of the tile results.
+C_KZG_RET lwkzg_g1_msm_tiled_device(void *out48_dev, const void *scalars_be_dev, size_t n_terms, const KZGSettings *s,
+                                    void *stream) {
+    if (n_terms == 0 || n_terms % kBlobElems != 0) {
+        set_error("lwkzg_g1_msm_tiled_device: n_terms must be a positive multiple of 4096");
+        return C_KZG_BADARGS;
+    }
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const size_t tiles = n_terms / kBlobElems;
+    C_KZG_RET rc = ctx_reserve(c, tiles);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    G1Xyzz29 *total = w.sums + w.cap;  // the extra slot behind the per-tile sums
+    for (size_t off = 0; off < tiles; off += kMaxChunk) {
+        size_t m = tiles - off < kMaxChunk ? tiles - off : kMaxChunk;
+        launch_parse_be_reduce((const uint8_t *)scalars_be_dev + off * (size_t)kBlobBytes, w.scalars, m * kBlobElems, st);
+        launch_digit_sort(w.scalars, w.sorted, w.bucket_start, w.perm, m, st);
+        launch_bucket_accumulate(c->table, w.sorted, w.bucket_start, w.perm, w.buckets, m, st);
+        launch_bucket_reduce(w.buckets, w.sums, m, st);
+        launch_sum_points(w.sums, m, total, off != 0, st);
+    }
+    launch_finalize_compress(total, (uint8_t *)out48_dev, 1, st);
     return C_KZG_OK;
 }
 

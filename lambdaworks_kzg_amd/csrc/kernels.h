@@ -31,6 +31,8 @@ void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *
 void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, const uint32_t *bucket_start,
                               const uint32_t *perm, G1Xyzz29 *buckets, size_t n_blobs, hipStream_t st);
 void launch_bucket_reduce(const G1Xyzz29 *buckets, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st);
+// total (+)= sum of n points (tiled MSM partial results)
+void launch_sum_points(const G1Xyzz29 *in, size_t n, G1Xyzz29 *total, int accumulate, hipStream_t st);
 // sums -> 48-byte compressed points (compress_g1_point, /root/reference/src/compression.rs:33-60)
 void launch_finalize_compress(const G1Xyzz29 *sums, uint8_t *out48, size_t n, hipStream_t st);
 

@@ -394,6 +394,31 @@ void launch_bucket_reduce(const G1Xyzz29 *buckets, G1Xyzz29 *sums, size_t n_blob
 }
 
 // ------------------------------------------------------------------------------------------------
+// sum of n partial results (tiled MSM: one 4096-term MSM per tile of a longer scalar vector)
+
+constexpr int kSumThreads = 256;
+
+__global__ __launch_bounds__(kSumThreads) void k_sum_points(const G1Xyzz29 *__restrict__ in, size_t n,
+                                                            G1Xyzz29 *__restrict__ total, int accumulate) {
+    __shared__ G1Xyzz29 sh[kSumThreads];
+    const int t = threadIdx.x;
+    G1Xyzz29 acc = G1Xyzz29::infinity();
+    for (size_t i = t; i < n; i += kSumThreads) acc = xyzz_add(acc, in[i]);
+    sh[t] = acc;
+    __syncthreads();
+    for (int d = kSumThreads / 2; d >= 1; d >>= 1) {
+        if (t < d) sh[t] = xyzz_add(sh[t], sh[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) total[0] = accumulate ? xyzz_add(total[0], sh[0]) : sh[0];
+}
+
+void launch_sum_points(const G1Xyzz29 *in, size_t n, G1Xyzz29 *total, int accumulate, hipStream_t st) {
+    ProfScope p("k_sum_points", st);
+    hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(kSumThreads), 0, st, in, n, total, accumulate);
+}
+
+// ------------------------------------------------------------------------------------------------
 // finalize: affine + ZCash compression, one lane per result
 
 __global__ __launch_bounds__(64) void k_finalize_compress(const G1Xyzz29 *__restrict__ sums, uint8_t *__restrict__ out48,

@@ -267,6 +267,26 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     return pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
 }
 
+// sum of compressed points on the host (gathering the per-GPU partial sums of a sharded long MSM: SURVEY 8e,
+// "one gather of 8 points + 7 host additions")
+C_KZG_RET lwkzg_g1_sum_compressed(uint8_t out48[48], const uint8_t *points48, size_t n) {
+    if (!out48 || (!points48 && n)) return C_KZG_BADARGS;
+    G1Xyzz acc = G1Xyzz::infinity();
+    for (size_t i = 0; i < n; i++) {
+        G1Affine p;
+        p.x = Fp::zero();
+        p.y = Fp::zero();
+        int rc = g1_decompress_nocheck(p, points48 + 48 * i);
+        if (rc == 2) {
+            set_error("lwkzg_g1_sum_compressed: point %zu is not a valid compressed G1 point", i);
+            return C_KZG_BADARGS;
+        }
+        if (rc == 0) acc = xyzz_madd(acc, p);
+    }
+    g1_compress(out48, acc);
+    return C_KZG_OK;
+}
+
 // test hook: the host-side Fiat-Shamir digests (SHA extensions when the CPU has them), no GPU
 C_KZG_RET lwkzg_challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *commitments48, size_t n) {
     if (!digests32 || !blobs || !commitments48) return C_KZG_BADARGS;

@@ -64,3 +64,24 @@ def gather_shards(local, n_items, item_bytes, group=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([parts[r][: counts[r] * item_bytes] for r in range(world)])
+
+
+def msm_tiled_sharded(scalars_be, n_terms, ts, device, group=None):
+    """BASELINE config "2^20-point G1 MSM (tiled trusted setup), 1->8 GPUs": sum_k s_k * g1[k mod 4096].
+    `scalars_be` is THIS rank's shard: a uint8 device tensor holding a whole number of 4096-scalar tiles
+    (shard_range over the tiles). Each GPU produces one partial sum; the only exchange is an all_gather of
+    the 48-byte compressed partial sums, added on the host. Returns the 48-byte result."""
+    tiles_here = scalars_be.numel() // (32 * 4096)
+    out = torch.empty(48, dtype=torch.uint8, device=device)
+    if tiles_here:
+        capi.g1_msm_tiled_device(out.data_ptr(), scalars_be.data_ptr(), tiles_here * 4096, ts)
+        torch.cuda.synchronize(device)
+    else:
+        out.zero_()
+        out[0] = 0xC0     # the empty sum: point at infinity
+    if group is None and not dist.is_initialized():
+        return bytes(out.cpu().numpy().tobytes())
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(out) for _ in range(world)]
+    dist.all_gather(parts, out, group=group)
+    return capi.g1_sum_compressed(b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts))

@@ -398,3 +398,36 @@ def test_verify_blob_kzg_proof_batch_ckzg_vectors(K, gpu_setup, vectors):
             assert K.verify_blob_kzg_proof_batch(b"".join(blobs), b"".join(cms), b"".join(prs), k, gpu_setup) is c["output"], c["case"]
         n += 1
     assert n >= 10
+
+
+def test_tiled_long_msm_2_pow_20(K, gpu_setup, oracle):
+    """BASELINE configs[4]: 2^20-term MSM over the setup tiled 256x; closed form [sum_k s_k tau^(k mod 4096)] G.
+    Also the sharded form: per-shard partial sums added on the host give the same bytes."""
+    import numpy as np
+    import torch
+    from lambdaworks_kzg_amd import capi
+    from lambdaworks_kzg_amd.dist import shard_range
+    tiles = 256
+    data = B.synthetic_batch(5000, tiles)                      # 2^20 canonical 248-bit scalars, big-endian
+    d_sc = _dev(data)
+    d_out = torch.empty(48, dtype=torch.uint8, device="cuda")
+    capi.g1_msm_tiled_device(d_out.data_ptr(), d_sc.data_ptr(), tiles * 4096, gpu_setup)
+    torch.cuda.synchronize()
+    got = _host(d_out)
+    acc = 0
+    pw = [pow(TAU, i, R) for i in range(4096)]
+    arr = np.frombuffer(data, dtype=np.uint8).reshape(tiles, 4096, 32)
+    for t in range(tiles):
+        sc = B.blob_scalars(arr[t].tobytes())
+        acc = (acc + sum(s * p for s, p in zip(sc, pw))) % R
+    assert got == oracle.g1_generator_mul(acc)
+    # 8-way sharding of the tiles
+    parts = []
+    for r in range(8):
+        st, cnt = shard_range(tiles, 8, r)
+        sub = _dev(data[st * B.BYTES_PER_BLOB:(st + cnt) * B.BYTES_PER_BLOB])
+        capi.g1_msm_tiled_device(d_out.data_ptr(), sub.data_ptr(), cnt * 4096, gpu_setup)
+        torch.cuda.synchronize()
+        parts.append(_host(d_out))
+    assert capi.g1_sum_compressed(b"".join(parts)) == got
+    assert capi.g1_sum_compressed(b"") == bytes([0xc0]) + bytes(47)
