@@ -71,14 +71,16 @@ C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const
 C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st);
 
 // verify-side helpers (host pointers in and out; GPU work inside; engine.hip)
-// z_i = challenge(blob_i, C_i), y_i = p_i(z_i) in the mode's byte order; canon48_out (optional) receives the
-// validated, re-compressed commitments. Invalid input -> the mode's error code.
-C_KZG_RET challenge_eval_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode, uint8_t *z32_out,
-                              uint8_t *y32_out, uint8_t *canon48_out);
-C_KZG_RET validate_points_host(Ctx *c, const uint8_t *pts48, size_t n, int mode, uint8_t *canon48_out);
-// sums[0] = sum r_i P_i, sums[1] = sum rz_i P_i, sums[2] = sum r_i C_i as affine big-endian x|y (+ infinity flags)
-C_KZG_RET lincomb3_host(Ctx *c, const uint8_t *proofs48, const uint8_t *comms48, const uint8_t *sc_r, const uint8_t *sc_rz,
-                        size_t n, uint8_t sums[3][96], int infs[3]);
+// device-side scratch of one batch verification (points kept between its two GPU phases)
+struct VerifyBuffers {
+    G1Affine29 *pts_c = nullptr, *pts_p = nullptr;
+    int32_t *kind_c = nullptr, *kind_p = nullptr;
+    ~VerifyBuffers();
+};
+C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
+                              int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb);
+C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n,
+                               uint8_t sums[3][96], int infs[3]);
 
 // G2 / pairing side (g2_pairing.hip, host only)
 bool g2_fill_values(g2_t *out65, const uint8_t *g2_bytes, size_t n2);

@@ -391,122 +391,106 @@ static C_KZG_RET first_status(Ctx *c, const int32_t *d_status, size_t n, hipStre
     return C_KZG_OK;
 }
 
-C_KZG_RET challenge_eval_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode, uint8_t *z32_out,
-                              uint8_t *y32_out, uint8_t *canon48_out) {
+VerifyBuffers::~VerifyBuffers() {
+    if (pts_c) hipFree(pts_c);
+    if (pts_p) hipFree(pts_p);
+    if (kind_c) hipFree(kind_c);
+    if (kind_p) hipFree(kind_p);
+}
+
+// Everything per blob of a batch verification, in one pass over the blobs: validate C_i and pi_i (keeping the
+// decompressed points on the device for the linear combinations), z_i = challenge(blob_i, C_i), y_i = p_i(z_i).
+// The Fiat-Shamir digests are computed by host threads while the GPU validates and parses (the blobs are host
+// memory here); the GPU hash is the fallback for non-canonical commitment encodings.
+C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
+                              int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb) {
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     const int le = mode == LWKZG_MODE_CKZG;
+    const int bad = le ? kStatusBadArgs : kStatusError;
     hipStream_t st = c->stream;
+    LWK_HIP(hipMalloc((void **)&vb.pts_c, n * sizeof(G1Affine29)));
+    LWK_HIP(hipMalloc((void **)&vb.kind_c, n * 4));
+    if (proofs48) {
+        LWK_HIP(hipMalloc((void **)&vb.pts_p, n * sizeof(G1Affine29)));
+        LWK_HIP(hipMalloc((void **)&vb.kind_p, n * 4));
+    }
+    std::vector<uint8_t> dig(32 * (n < kMaxChunk ? n : kMaxChunk));
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         C_KZG_RET rc = ctx_reserve(c, m);
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;
-        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off * (size_t)kBlobBytes, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
-        LWK_HIP(hipMemcpyAsync(w.comm48, comm48 + 48 * off, m * 48, hipMemcpyHostToDevice, st));
+        const uint8_t *hb = blobs + off * (size_t)kBlobBytes, *hc = comm48 + 48 * off;
+        LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
+        LWK_HIP(hipMemcpyAsync(w.comm48, hc, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
-        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, st);
+        launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
+        LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        if (proofs48) {
+            LWK_HIP(hipMemcpyAsync(w.comm48, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, st));
+            launch_validate_commitments(w.comm48, w.out48, w.status, bad, m, st, vb.pts_p + off, vb.kind_p + off);
+            LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, st));
+        }
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
-        launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
+        challenge_digests_host(dig.data(), hb, hc, m);
+        LWK_HIP(hipStreamSynchronize(st));
+        if (memcmp(canon_c + 48 * off, hc, m * 48) == 0) {
+            LWK_HIP(hipMemcpyAsync(w.zbytes, dig.data(), m * 32, hipMemcpyHostToDevice, st));
+            launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);
+        } else {
+            launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
+        }
         launch_eval_quotient(w.scalars, w.z, w.scalars2, w.ybytes, le, m, st);
         launch_fr_mont_to_bytes(w.z, w.zbytes, le, m, st);
-        LWK_HIP(hipMemcpyAsync(z32_out + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
-        LWK_HIP(hipMemcpyAsync(y32_out + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
-        if (canon48_out) LWK_HIP(hipMemcpyAsync(canon48_out + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipMemcpyAsync(z32 + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
         rc = first_status(c, w.status, m, st);
         if (rc != C_KZG_OK) return rc;
     }
     return C_KZG_OK;
 }
 
-C_KZG_RET validate_points_host(Ctx *c, const uint8_t *pts48, size_t n, int mode, uint8_t *canon48_out) {
-    std::lock_guard<std::mutex> lk(c->mu);
-    LWK_HIP(hipSetDevice(c->device));
-    const int le = mode == LWKZG_MODE_CKZG;
-    hipStream_t st = c->stream;
-    for (size_t off = 0; off < n; off += kMaxChunk) {
-        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        C_KZG_RET rc = ctx_reserve(c, m);
-        if (rc != C_KZG_OK) return rc;
-        Workspace &w = c->ws;
-        LWK_HIP(hipMemcpyAsync(w.comm48, pts48 + 48 * off, m * 48, hipMemcpyHostToDevice, st));
-        LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
-        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, st);
-        LWK_HIP(hipMemcpyAsync(canon48_out + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
-        rc = first_status(c, w.status, m, st);
-        if (rc != C_KZG_OK) return rc;
-    }
-    return C_KZG_OK;
-}
-
-C_KZG_RET lincomb3_host(Ctx *c, const uint8_t *proofs48, const uint8_t *comms48, const uint8_t *sc_r, const uint8_t *sc_rz,
-                        size_t n, uint8_t sums[3][96], int infs[3]) {
+// sums[0] = sum r_i pi_i, sums[1] = sum r_i z_i pi_i, sums[2] = sum r_i C_i on the points verify_prepare_host kept
+C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n,
+                               uint8_t sums[3][96], int infs[3]) {
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nblk = (n + 255) / 256;
-    uint8_t *d_pts = nullptr, *d_sc = nullptr, *d_aff = nullptr;
-    G1Xyzz *d_part = nullptr;
+    uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
+    G1Xyzz29 *d_part = nullptr;
     int32_t *d_inf = nullptr;
-    C_KZG_RET rc = C_KZG_ERROR;
-    std::vector<uint8_t> h_aff(96 * nblk);
-    std::vector<int32_t> h_inf(nblk);
-    do {
-        if (hipMalloc((void **)&d_pts, 48 * n) != hipSuccess || hipMalloc((void **)&d_sc, 32 * n) != hipSuccess ||
-            hipMalloc((void **)&d_part, nblk * sizeof(G1Xyzz)) != hipSuccess ||
-            hipMalloc((void **)&d_aff, 96 * nblk) != hipSuccess || hipMalloc((void **)&d_inf, 4 * nblk) != hipSuccess) {
-            set_error("hipMalloc failed in lincomb3_host");
-            rc = C_KZG_MALLOC;
-            break;
-        }
-        const uint8_t *pts[3] = {proofs48, proofs48, comms48};
-        const uint8_t *scs[3] = {sc_r, sc_rz, sc_r};
-        bool ok = true;
-        for (int k = 0; k < 3 && ok; k++) {
-            ok = hipMemcpyAsync(d_pts, pts[k], 48 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
-                 hipMemcpyAsync(d_sc, scs[k], 32 * n, hipMemcpyHostToDevice, st) == hipSuccess;
-            if (!ok) break;
-            launch_lincomb_terms(d_pts, d_sc, d_part, n, st);
-            launch_xyzz_to_affine_be(d_part, d_aff, d_inf, nblk, st);
-            ok = hipMemcpyAsync(h_aff.data(), d_aff, 96 * nblk, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipMemcpyAsync(h_inf.data(), d_inf, 4 * nblk, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipStreamSynchronize(st) == hipSuccess;
-            if (!ok) break;
-            // the handful of per-block partial sums are added on the host
-            G1Xyzz acc = G1Xyzz::infinity();
-            for (size_t b = 0; b < nblk; b++) {
-                if (h_inf[b]) continue;
-                uint32_t raw[12];
-                G1Affine a;
-                raw_from_be<12>(raw, &h_aff[96 * b]);
-                a.x = fe_from_raw<FpParams>(raw);
-                raw_from_be<12>(raw, &h_aff[96 * b + 48]);
-                a.y = fe_from_raw<FpParams>(raw);
-                acc = xyzz_madd(acc, a);
-            }
-            infs[k] = acc.is_inf() ? 1 : 0;
-            memset(sums[k], 0, 96);
-            if (!infs[k]) {
-                G1Affine a = xyzz_to_affine(acc);
-                uint32_t raw[12];
-                fe_to_raw<FpParams>(raw, a.x);
-                raw_to_be<12>(sums[k], raw);
-                fe_to_raw<FpParams>(raw, a.y);
-                raw_to_be<12>(sums[k] + 48, raw);
-            }
-        }
-        if (!ok) {
-            set_error("lincomb3_host: device work failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-        rc = C_KZG_OK;
-    } while (0);
-    if (d_pts) hipFree(d_pts);
-    if (d_sc) hipFree(d_sc);
+    uint8_t h_aff[3 * 96];
+    int32_t h_inf[3];
+    bool ok = hipMalloc((void **)&d_r, 32 * n) == hipSuccess && hipMalloc((void **)&d_rz, 32 * n) == hipSuccess &&
+              hipMalloc((void **)&d_part, (3 * nblk + 3) * sizeof(G1Xyzz29)) == hipSuccess &&
+              hipMalloc((void **)&d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&d_inf, 3 * 4) == hipSuccess;
+    if (ok) ok = hipMemcpyAsync(d_r, sc_r, 32 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
+                 hipMemcpyAsync(d_rz, sc_rz, 32 * n, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok) {
+        launch_lincomb3(vb.pts_p, vb.kind_p, vb.pts_c, vb.kind_c, d_r, d_rz, d_part, n, st);
+        G1Xyzz29 *totals = d_part + 3 * nblk;
+        for (int k = 0; k < 3; k++) launch_sum_points(d_part + k * nblk, nblk, totals + k, 0, st);
+        launch_xyzz29_to_affine_be(totals, d_aff, d_inf, 3, st);
+        ok = hipMemcpyAsync(h_aff, d_aff, sizeof h_aff, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipMemcpyAsync(h_inf, d_inf, sizeof h_inf, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (d_r) hipFree(d_r);
+    if (d_rz) hipFree(d_rz);
     if (d_part) hipFree(d_part);
     if (d_aff) hipFree(d_aff);
     if (d_inf) hipFree(d_inf);
-    return rc;
+    if (!ok) {
+        set_error("lincomb3_device_host: device work failed: %s", hipGetErrorString(hipGetLastError()));
+        return C_KZG_ERROR;
+    }
+    for (int k = 0; k < 3; k++) {
+        memcpy(sums[k], h_aff + 96 * k, 96);
+        infs[k] = h_inf[k];
+    }
+    return C_KZG_OK;
 }
 
 }  // namespace lwk

@@ -45,9 +45,6 @@ void launch_g1_decompress(const uint8_t *in48, G1Affine *out, int32_t *status, s
 void launch_g1_from_blst(const uint64_t *blst_p1, G1Affine *out, int32_t *status, size_t n, hipStream_t st);
 // affine Montgomery -> reference blst_p1 layout (g1_point_to_blst_p1, /root/reference/src/srs.rs:131-153)
 void launch_g1_to_blst(const G1Affine *in, const int32_t *status, uint64_t *blst_p1, size_t n, hipStream_t st);
-// sum_i [k_i] P_i over caller points (validated canonical compressed bytes): per-block partial sums
-void launch_lincomb_terms(const uint8_t *points48, const uint8_t *scalars_be, G1Xyzz *partial, size_t n, hipStream_t st);
-void launch_xyzz_to_affine_be(const G1Xyzz *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 // T[j][i] = 2^(13 j) P_i
 void launch_build_table(const G1Affine *points, G1Affine29 *table, hipStream_t st);
 
@@ -76,7 +73,13 @@ void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, in
 // z = sha256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blob | commitment) as Fr
 // (compute_challenge, /root/reference/src/utils.rs:120-154).
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                                 hipStream_t st);
+                                 hipStream_t st, G1Affine29 *aff_out = nullptr, int32_t *kind_out = nullptr);
+// verify side: three variable-base linear combinations in one launch (setup.hip).
+//   set 0 = sum r_i P_i, set 1 = sum rz_i P_i (P = proofs), set 2 = sum r_i C_i (C = commitments);
+// per-block partial sums to partial[set * nblk + block]
+void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *comms, const int32_t *comm_kind,
+                     const uint8_t *sc_r_be, const uint8_t *sc_rz_be, G1Xyzz29 *partial, size_t n, hipStream_t st);
+void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st);
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 // sha256_host.hip: digests[i] = SHA-256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blobs[i] | comms[i]) on host threads

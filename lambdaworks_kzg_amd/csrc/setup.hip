@@ -114,30 +114,31 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine *__restrict__
     }
 }
 
-// Variable-base linear combination sum_i [k_i] P_i (g1_lincomb over caller points, the reference's
-// three size-n MSMs in verify_kzg_proof_batch, /root/reference/src/lib.rs:679-685). n is the batch size
-// of a verification (tens to a few thousand), so: one lane per term does its own double-and-add, the
-// workgroup sums its 256 results in LDS, and the few per-block partial sums go back to the host.
-// Points arrive as validated, canonical compressed bytes (infinity allowed).
 constexpr int kLincombThreads = 256;
 
-__global__ __launch_bounds__(kLincombThreads) void k_lincomb_terms(const uint8_t *__restrict__ points48,
-                                                                   const uint8_t *__restrict__ scalars_be,
-                                                                   G1Xyzz *__restrict__ partial, size_t n) {
-    __shared__ G1Xyzz sh[kLincombThreads];
-    const int tid = threadIdx.x;
-    size_t i = (size_t)blockIdx.x * kLincombThreads + tid;
-    G1Xyzz acc = G1Xyzz::infinity();
-    if (i < n) {
-        uint8_t b[48];
-        for (int k = 0; k < 48; k++) b[k] = points48[48 * i + k];
-        G1Affine p;
-        p.x = Fp::zero();
-        p.y = Fp::zero();
-        if (g1_decompress_nocheck(p, b) == 0) {
-            uint32_t k[8];
-            raw_from_be<8>(k, scalars_be + 32 * i);
-            acc = xyzz_mul_affine<8>(p, k);
+// The three linear combinations of verify_kzg_proof_batch (/root/reference/src/lib.rs:679-685) in ONE launch, on points
+// the validation kernel already decompressed into the hot-loop representation: one lane per term does a
+// 255-bit double-and-add, the workgroup sums its 256 results in LDS.
+__global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *__restrict__ proofs,
+                                                              const int32_t *__restrict__ proof_kind,
+                                                              const G1Affine29 *__restrict__ comms,
+                                                              const int32_t *__restrict__ comm_kind,
+                                                              const uint8_t *__restrict__ sc_r, const uint8_t *__restrict__ sc_rz,
+                                                              G1Xyzz29 *__restrict__ partial, size_t n) {
+    __shared__ G1Xyzz29 sh[kLincombThreads];
+    const int tid = threadIdx.x, set = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * kLincombThreads + tid;
+    const G1Affine29 *pts = set == 2 ? comms : proofs;
+    const int32_t *kind = set == 2 ? comm_kind : proof_kind;
+    const uint8_t *sc = set == 1 ? sc_rz : sc_r;
+    G1Xyzz29 acc = G1Xyzz29::infinity();
+    if (i < n && kind[i] == 0) {
+        G1Affine29 p = pts[i];
+        uint32_t k[8];
+        raw_from_be<8>(k, sc + 32 * i);
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = xyzz_dbl(acc);
+            if ((k[bit >> 5] >> (bit & 31)) & 1) acc = xyzz_madd(acc, p.x, p.y);
         }
     }
     sh[tid] = acc;
@@ -146,22 +147,22 @@ __global__ __launch_bounds__(kLincombThreads) void k_lincomb_terms(const uint8_t
         if (tid < d) sh[tid] = xyzz_add(sh[tid], sh[tid + d]);
         __syncthreads();
     }
-    if (tid == 0) partial[blockIdx.x] = sh[0];
+    if (tid == 0) partial[(size_t)set * gridDim.x + blockIdx.x] = sh[0];
 }
 
-void launch_lincomb_terms(const uint8_t *points48, const uint8_t *scalars_be, G1Xyzz *partial, size_t n,
-                          hipStream_t st) {
-    ProfScope p("k_lincomb_terms", st);
+void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *comms, const int32_t *comm_kind,
+                     const uint8_t *sc_r_be, const uint8_t *sc_rz_be, G1Xyzz29 *partial, size_t n, hipStream_t st) {
+    ProfScope p("k_lincomb3", st);
     unsigned grid = (unsigned)((n + kLincombThreads - 1) / kLincombThreads);
-    hipLaunchKernelGGL(k_lincomb_terms, dim3(grid), dim3(kLincombThreads), 0, st, points48, scalars_be, partial, n);
+    hipLaunchKernelGGL(k_lincomb3, dim3(grid, 3), dim3(kLincombThreads), 0, st, proofs, proof_kind, comms, comm_kind,
+                       sc_r_be, sc_rz_be, partial, n);
 }
 
-// XYZZ partial sums -> affine big-endian (x | y, 96 B) + infinity flag, one lane each
-__global__ __launch_bounds__(64) void k_xyzz_to_affine_be(const G1Xyzz *__restrict__ in, uint8_t *__restrict__ out96,
-                                                          int32_t *__restrict__ inf, size_t n) {
+__global__ __launch_bounds__(64) void k_xyzz29_to_affine_be(const G1Xyzz29 *__restrict__ in, uint8_t *__restrict__ out96,
+                                                            int32_t *__restrict__ inf, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    G1Xyzz p = in[i];
+    G1Xyzz29 p = in[i];
     uint8_t *o = out96 + 96 * i;
     if (p.is_inf()) {
         inf[i] = 1;
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(64) void k_xyzz_to_affine_be(const G1Xyzz *__restri
     raw_to_be<12>(o + 48, raw);
 }
 
-void launch_xyzz_to_affine_be(const G1Xyzz *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st) {
-    ProfScope p("k_xyzz_to_affine_be", st);
-    hipLaunchKernelGGL(k_xyzz_to_affine_be, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in, out96, inf, n);
+void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st) {
+    ProfScope p("k_xyzz29_to_affine_be", st);
+    hipLaunchKernelGGL(k_xyzz29_to_affine_be, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in, out96, inf, n);
 }
 
 void launch_build_table(const G1Affine *points, G1Affine29 *table, hipStream_t st) {

@@ -162,11 +162,17 @@ void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len) {
 // compute_challenge do (/root/reference/src/lib.rs:372-375, src/utils.rs:138). One lane per point, all in the
 // 29-bit-limb field: square root (p = 3 mod 4), root selection by the sign flag, endomorphism subgroup
 // test. Re-compressing an affine point needs no inversion: the canonical bytes are x (reduced) + flags.
+// aff_out / kind_out (optional): the validated point in the hot-loop representation and 0 = affine,
+// 1 = infinity, 2 = invalid, for the verify side's linear combinations.
 __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__restrict__ comm48,
                                                              uint8_t *__restrict__ canon48, int32_t *__restrict__ status,
-                                                             int bad_code, size_t n) {
+                                                             int bad_code, size_t n, G1Affine29 *__restrict__ aff_out,
+                                                             int32_t *__restrict__ kind_out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    G1Affine29 aff;
+    aff.x = F29<2>::zero();
+    aff.y = F29<2>::zero();
     uint8_t b[48], o[48];
     for (int k = 0; k < 48; k++) b[k] = comm48[48 * i + k];
     for (int k = 0; k < 48; k++) o[k] = 0;
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
         rc = 2;  // not flagged compressed
     } else if (prefix & 2) {
         o[0] = 0xc0;  // infinity; remaining input bits are not inspected (compression.rs:73-75)
+        rc = 1;
     } else {
         b[0] &= 0x1f;
         uint32_t raw[12];
@@ -209,6 +216,8 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
                 raw_to_be<12>(o, rx);
                 o[0] |= 0x80;
                 if (want_greater) o[0] |= 0x20;
+                aff.x = x;
+                aff.y = ysel * F29<1>::one();  // back to < 2p
             }
         }
     }
@@ -217,13 +226,15 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
         for (int k = 0; k < 48; k++) o[k] = 0;
     }
     for (int k = 0; k < 48; k++) canon48[48 * i + k] = o[k];
+    if (aff_out) aff_out[i] = aff;
+    if (kind_out) kind_out[i] = rc;
 }
 
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                                 hipStream_t st) {
+                                 hipStream_t st, G1Affine29 *aff_out, int32_t *kind_out) {
     ProfScope p("k_validate_commitments", st);
     hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, comm48, canon48, status,
-                       bad_code, n);
+                       bad_code, n, aff_out, kind_out);
 }
 
 }  // namespace lwk

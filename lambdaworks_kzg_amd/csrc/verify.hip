@@ -169,8 +169,9 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     }
     Ctx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
-    uint8_t zb[32], yb[32];
-    C_KZG_RET rc = challenge_eval_host(ctx, blob->bytes, commitment_bytes->bytes, 1, mode, zb, yb, nullptr);
+    uint8_t zb[32], yb[32], canon[48];
+    VerifyBuffers vb;
+    C_KZG_RET rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb);
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
     if (mode == LWKZG_MODE_CKZG) {
         if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return C_KZG_BADARGS; }
@@ -197,12 +198,12 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     const bool le = mode == LWKZG_MODE_CKZG;
 
     std::vector<uint8_t> zs(32 * n), ys(32 * n), canon_c(48 * n), canon_p(48 * n);
-    // per blob on the GPU: validate C_i and pi_i (decompress + subgroup check + canonical recompression),
-    // z_i = challenge(blob_i, C_i), y_i = p_i(z_i)
-    C_KZG_RET rc = challenge_eval_host(ctx, (const uint8_t *)blobs, (const uint8_t *)commitments_bytes, n, mode,
-                                       zs.data(), ys.data(), canon_c.data());
-    if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
-    rc = validate_points_host(ctx, (const uint8_t *)proofs_bytes, n, mode, canon_p.data());
+    // per blob on the GPU: validate C_i and pi_i (decompress + subgroup check + canonical recompression; the
+    // decompressed points stay on the device), z_i = challenge(blob_i, C_i), y_i = p_i(z_i)
+    VerifyBuffers vb;
+    C_KZG_RET rc = verify_prepare_host(ctx, (const uint8_t *)blobs, (const uint8_t *)commitments_bytes,
+                                       (const uint8_t *)proofs_bytes, n, mode, zs.data(), ys.data(), canon_c.data(),
+                                       canon_p.data(), vb);
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
 
     // r (utils.rs:166-206). z and y enter in the mode's byte order, as to_bytes_be / c-kzg's bytes_from_bls_field do
@@ -245,7 +246,7 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     // three variable-base linear combinations on the GPU (g1_lincomb, lib.rs:679-685)
     uint8_t sums[3][96];
     int infs[3];
-    rc = lincomb3_host(ctx, canon_p.data(), canon_c.data(), sc_r.data(), sc_rz.data(), n, sums, infs);
+    rc = lincomb3_device_host(ctx, vb, sc_r.data(), sc_rz.data(), n, sums, infs);
     if (rc != C_KZG_OK) return C_KZG_ERROR;
     auto load = [&](int k) {
         if (infs[k]) return G1Xyzz::infinity();
