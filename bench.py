@@ -201,7 +201,10 @@ def main():
         dom = "k_bucket_accumulate"
         k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
         avg_ms = k["total_ms"] / max(1, k["launches"])
-        msms_per_launch = n
+        # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
+        # the units one launch processes = blobs per step / launches per step
+        launches_per_step = max(1, round(k["launches"] / max(1, args.steps)))
+        msms_per_launch = n / launches_per_step
         achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
         # integer picture: a mixed add is 8 Montgomery products (392 v_mad_u64_u32 each on 14x29-bit limbs) and
@@ -241,7 +244,10 @@ def main():
                                          "separate passes (profiles/pmc_traffic.json); mostly Infinity-Cache-served re-reads of "
                                          "the 9.2 MB fixed-base table, see DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": msms_per_launch * ALGO_BYTES_PER_MSM,
-                         "avg_launch_ms": avg_ms,
+                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+                         "concurrency_note": "the %d launches of a step run concurrently on separate streams, each on a share of "
+                                             "the CUs: per-launch rates are per share; multiply by %d for the rate while both run"
+                                             % (launches_per_step, launches_per_step) if launches_per_step > 1 else "one launch per step",
                          "note": "integer-ALU bound, not HBM bound (about 600 int-ops per algorithmic byte): see int_mad",
                          "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
                                      "achieved_Gmad_per_s": mads_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,

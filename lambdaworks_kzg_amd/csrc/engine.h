@@ -10,6 +10,7 @@ namespace lwk {
 
 constexpr uint64_t kCtxMagic = 0x4c574b5a47414d44ull;  // "LWKZGAMD"
 constexpr size_t kMaxChunk = 1024;                      // blobs per launch set
+constexpr int kMaxSplit = 8;                            // sub-batches (streams) a launch set may be cut into
 
 void set_error(const char *fmt, ...);
 const char *get_error();
@@ -49,6 +50,8 @@ struct Ctx {
     uint64_t magic;
     int device;
     hipStream_t stream;
+    hipStream_t aux[kMaxSplit];     // sub-batch streams of commit_batch_device
+    hipEvent_t ev_fork, ev_join[kMaxSplit];
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
     G1Affine29 *table;  // kTablePoints, hot-loop representation
     Fr *tw_fwd, *tw_inv;

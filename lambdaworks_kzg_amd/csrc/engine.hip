@@ -161,6 +161,11 @@ static void ctx_destroy(Ctx *c) {
     dev_free(c->tw_fwd);
     dev_free(c->tw_inv);
     if (c->stream) hipStreamDestroy(c->stream);
+    for (int k = 0; k < kMaxSplit; k++) {
+        if (c->aux[k]) hipStreamDestroy(c->aux[k]);
+        if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     free(c->fs.expanded_roots_of_unity);
     free(c->fs.reverse_roots_of_unity);
     free(c->fs.roots_of_unity);
@@ -189,12 +194,22 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->magic = kCtxMagic;
     c->device = g_default_device;
     c->stream = nullptr;
+    c->ev_fork = nullptr;
+    for (int k = 0; k < kMaxSplit; k++) {
+        c->aux[k] = nullptr;
+        c->ev_join[k] = nullptr;
+    }
     c->points = nullptr;
     c->table = nullptr;
     c->tw_fwd = c->tw_inv = nullptr;
     c->owns_fs_tables = true;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int k = 0; k < kMaxSplit && e == hipSuccess; k++) {
+        e = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&c->points, (size_t)kBlobElems * sizeof(G1Affine));
     if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine29));
     if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
@@ -296,23 +311,44 @@ Ctx *ctx_of(const KZGSettings *s) {
 // ------------------------------------------------------------------------------------------------
 // pipelines (device-resident, asynchronous)
 
-static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st) {
+// `base` = first workspace slot (in blobs) this launch set may use: sub-batches running on different streams
+// work in disjoint slices of the same workspace.
+static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0) {
     Workspace &w = c->ws;
-    launch_digit_sort(scalars_raw, w.sorted, w.bucket_start, w.perm, n, st);
-    launch_bucket_accumulate(c->table, w.sorted, w.bucket_start, w.perm, w.buckets, n, st);
-    launch_bucket_reduce(w.buckets, w.sums, n, st);
-    launch_finalize_compress(w.sums, out48, n, st);
+    uint32_t *sorted = w.sorted + base * (size_t)kMaxEntries;
+    uint32_t *bstart = w.bucket_start + base * (size_t)(kNumBuckets + 1);
+    uint32_t *perm = w.perm + base * (size_t)(kNumBuckets + 1);
+    G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
+    G1Xyzz29 *sums = w.sums + base;
+    launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
+    launch_bucket_accumulate(c->table, sorted, bstart, perm, buckets, n, st);
+    launch_bucket_reduce(buckets, sums, n, st);
+    launch_finalize_compress(sums, out48, n, st);
 }
 
-// blob bytes -> canonical monomial coefficients in ws.scalars
-static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st) {
+// blob bytes -> canonical monomial coefficients in ws.scalars (slots base .. base + n)
+static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st,
+                               size_t base = 0) {
     Workspace &w = c->ws;
+    uint32_t *scalars = w.scalars + base * (size_t)kBlobElems * 8;
     if (mode == LWKZG_MODE_REFERENCE) {
-        launch_parse_be_reduce(blobs, w.scalars, n * kBlobElems, st);
+        launch_parse_be_reduce(blobs, scalars, n * kBlobElems, st);
     } else {
-        launch_parse_le_canonical(blobs, w.fr, status, n, st);
-        launch_ntt4096(w.fr, (Fr *)w.scalars, c->tw_inv, 1, n, st);
+        Fr *fr = w.fr + base * (size_t)kBlobElems;
+        launch_parse_le_canonical(blobs, fr, status, n, st);
+        launch_ntt4096(fr, (Fr *)scalars, c->tw_inv, 1, n, st);
     }
+}
+
+static int split_ways() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("LWKZG_SPLIT");
+        v = e ? atoi(e) : 2;
+        if (v < 1) v = 1;
+        if (v > kMaxSplit) v = kMaxSplit;
+    }
+    return v;
 }
 
 C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st) {
@@ -323,6 +359,9 @@ C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars
     return C_KZG_OK;
 }
 
+// One chunk of the commitment pipeline. Large chunks are cut into sub-batches that run on the context's
+// auxiliary streams: the latency-shaped tails of one sub-batch (bucket reduction, inversion, the last waves of
+// the accumulation) then overlap with the ALU-bound accumulation of the next instead of idling most SIMDs.
 C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size_t n, int mode, hipStream_t st,
                               int32_t *status) {
     C_KZG_RET rc = ctx_reserve(c, n);
@@ -331,8 +370,22 @@ C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         int32_t *stt = status ? status + off : c->ws.status;
         LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
-        coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
-        msm_stages(c, c->ws.scalars, out48 + 48 * off, m, st);
+        const int ways = m >= 256 ? split_ways() : 1;
+        if (ways == 1) {
+            coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
+            msm_stages(c, c->ws.scalars, out48 + 48 * off, m, st);
+            continue;
+        }
+        LWK_HIP(hipEventRecord(c->ev_fork, st));
+        for (int k = 0; k < ways; k++) {
+            size_t lo = m * k / ways, hi = m * (k + 1) / ways;
+            hipStream_t sk = c->aux[k];
+            LWK_HIP(hipStreamWaitEvent(sk, c->ev_fork, 0));
+            coefficients_stage(c, blobs + (off + lo) * (size_t)kBlobBytes, hi - lo, mode, stt + lo, sk, lo);
+            msm_stages(c, c->ws.scalars + lo * (size_t)kBlobElems * 8, out48 + 48 * (off + lo), hi - lo, sk, lo);
+            LWK_HIP(hipEventRecord(c->ev_join[k], sk));
+            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[k], 0));
+        }
     }
     return C_KZG_OK;
 }
