@@ -217,7 +217,7 @@ def main():
         traffic = None
         try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size only
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("batch_blobs_per_launch") == n and args.op == "commit":
+            if pmc.get("batch_blobs_per_launch") == msms_per_launch and args.op == "commit":
                 traffic = pmc["kernels"][dom]["traffic_bytes"]
         except Exception:
             traffic = None
@@ -252,7 +252,9 @@ def main():
                          "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
                                      "achieved_Gmad_per_s": mads_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                                      "peak_Gmad_per_s": INT_MAD_PEAK / 1e9,
-                                     "frac": (mads_per_launch / (avg_ms * 1e-3) / INT_MAD_PEAK) if avg_ms > 0 else 0.0}},
+                                     "frac": (mads_per_launch / (avg_ms * 1e-3) / INT_MAD_PEAK) if avg_ms > 0 else 0.0,
+                                     # all multiply-adds of a step over the step's wall time (every kernel, all streams):
+                                     "frac_whole_step": mads_per_launch * launches_per_step / (elapsed / args.steps) / INT_MAD_PEAK}},
             "kernels": kernels,
             "setup_load_s": t_load,
         }

@@ -5,7 +5,7 @@ roofline.traffic.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    python tools/pmc_summary.py out/fetch_counter_collection.csv out/write_counter_collection.csv rNN
+    python tools/pmc_summary.py out/fetch_counter_collection.csv out/write_counter_collection.csv rNN [blobs_per_launch]
 
 Units: the counters are in KiB. gfx950 correction (guide, section HBM): FETCH_SIZE tallies 128-byte
 requests at 64 bytes for wide coalesced streams, i.e. reads exactly half; for this kernel's per-lane
@@ -30,8 +30,9 @@ def per_kernel(path):
 
 def main():
     fetch, write, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    blobs_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 512   # bench default: 1024 blobs per step in 2 launches
     f, w = per_kernel(fetch), per_kernel(write)
-    out = {"round": tag, "batch_blobs_per_launch": 1024, "unit": "bytes per launch (average)", "kernels": {}}
+    out = {"round": tag, "batch_blobs_per_launch": blobs_per_launch, "unit": "bytes per launch (average)", "kernels": {}}
     for k in sorted(set(f) | set(w)):
         if not k.startswith("k_"):
             continue
