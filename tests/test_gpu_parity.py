@@ -431,3 +431,41 @@ def test_tiled_long_msm_2_pow_20(K, gpu_setup, oracle):
         parts.append(_host(d_out))
     assert capi.g1_sum_compressed(b"".join(parts)) == got
     assert capi.g1_sum_compressed(b"") == bytes([0xc0]) + bytes(47)
+
+
+def test_load_free_cycles_and_two_settings(K, oracle, oracle_setup):
+    """load/free repeatedly (no leaked device state), and two live settings objects used alternately"""
+    import torch
+    from conftest import SETUP_PATH
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        ts = K.TrustedSetup.from_file(SETUP_PATH)
+        assert K.blob_to_kzg_commitment(B.synthetic_blob(1), ts) == tau_closed_form(oracle, B.blob_scalars(B.synthetic_blob(1)))
+        ts.free()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)      # nothing substantial left behind
+    a, b = K.TrustedSetup.from_file(SETUP_PATH), K.TrustedSetup.from_bytes(oracle_setup.g1_compressed(), oracle_setup.g2_compressed())
+    blob = B.synthetic_blob(2)
+    assert K.blob_to_kzg_commitment(blob, a) == K.blob_to_kzg_commitment(blob, b)
+    a.free()
+    assert K.blob_to_kzg_commitment(blob, b) == tau_closed_form(oracle, B.blob_scalars(blob))
+    b.free()
+
+
+def test_adversarial_blobs_closed_form(K, gpu_setup, oracle):
+    """digit patterns that stress the bucket machinery: all scalars equal (20 buckets of 4096 entries), two values
+    alternating, a single non-zero scalar, scalars whose every window is the signed-digit boundary"""
+    c = 13
+    boundary = sum((1 << (c - 1)) << (c * j) for j in range(19))        # every window = 2^(c-1)
+    boundary1 = sum(((1 << (c - 1)) + 1) << (c * j) for j in range(19))  # every window = 2^(c-1)+1 -> negative digits + carries
+    sets = [[R - 1] * 4096,
+            [5, R - 5] * 2048,
+            [0] * 1234 + [R - 2] + [0] * 2861,
+            [boundary % R] * 4096,
+            [boundary1 % R] * 4096,
+            [(1 << 247) | 1] * 4096,
+            list(range(1, 4097))]
+    blobs = [b"".join(s.to_bytes(32, "big") for s in ss) for ss in sets]
+    got = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
+    for ss, g in zip(sets, got):
+        assert g == tau_closed_form(oracle, ss)
