@@ -469,3 +469,22 @@ def test_adversarial_blobs_closed_form(K, gpu_setup, oracle):
     got = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
     for ss, g in zip(sets, got):
         assert g == tau_closed_form(oracle, ss)
+
+
+def test_ckzg_mode_random_blobs_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+    """c-kzg semantics on random canonical little-endian blobs (not only the formula blobs of the vectors):
+    commitment, blob proof and point proof against the oracle, then verification."""
+    K.set_mode(K.MODE_CKZG)
+    blobs = [B.synthetic_blob(300 + i, big_endian=False) for i in range(3)]
+    comms = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
+    proofs = K.compute_blob_kzg_proof_batch(b"".join(blobs), b"".join(comms), gpu_setup)
+    rnd = random.Random(17)
+    for b, c, p in zip(blobs, comms, proofs):
+        assert oracle.blob_to_kzg_commitment(b, oracle_setup, oracle.MODE_C) == (0, c)
+        assert oracle.compute_blob_kzg_proof(b, c, oracle_setup, oracle.MODE_C) == (0, p)
+        z = rnd.randrange(R).to_bytes(32, "little")
+        pr, y = K.compute_kzg_proof(b, z, gpu_setup)
+        assert oracle.compute_kzg_proof(b, z, oracle_setup, oracle.MODE_C) == (0, pr, y)
+        assert K.verify_kzg_proof(c, z, y, pr, gpu_setup) is True
+        assert K.verify_blob_kzg_proof(b, c, p, gpu_setup) is True
+    assert K.verify_blob_kzg_proof_batch(b"".join(blobs), b"".join(comms), b"".join(proofs), 3, gpu_setup) is True
