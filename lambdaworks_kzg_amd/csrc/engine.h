@@ -57,7 +57,6 @@ struct Ctx {
     Fr *tw_fwd, *tw_inv;
     Workspace ws;
     std::mutex mu;
-    bool owns_fs_tables;
 };
 
 Ctx *ctx_of(const KZGSettings *s);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise

@@ -202,7 +202,6 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->points = nullptr;
     c->table = nullptr;
     c->tw_fwd = c->tw_inv = nullptr;
-    c->owns_fs_tables = true;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

@@ -82,11 +82,7 @@ inline bool f12is_one(const Fp12 &a) {
            f2is_zero(a.c1.c1) && f2is_zero(a.c1.c2);
 }
 
-// little-endian 32-bit limbs of big public exponents
-struct BigExp {
-    uint32_t l[48];
-    int n;
-};
+// big public exponents below are little-endian arrays of 32-bit limbs
 
 // o = a * b (schoolbook), limbs little-endian
 void big_mul(uint32_t *o, const uint32_t *a, int na, const uint32_t *b, int nb) {
@@ -176,7 +172,6 @@ void init_consts() {
     uint32_t num[48];
     memcpy(num, p4, sizeof num);
     big_sub(num, 48, p2, 24);
-    uint32_t one[1] = {1};
     {
         u64 c = 1;
         for (int i = 0; i < 48 && c; i++) {
@@ -185,7 +180,6 @@ void init_consts() {
             c >>= 32;
         }
     }
-    (void)one;
     big_div(g_c.hard, num, 48, r, 8);
     g_c.hard_n = 48;
     // e6 = (p^2 - 1) / 6
@@ -297,8 +291,6 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
         t[i] = q[i];
     }
     Fp12 f = f12one();
-    Fp three_inv2;  // unused placeholder to keep the structure obvious
-    (void)three_inv2;
     for (int bit = 62; bit >= 0; bit--) {
         f = f * f;
         for (int i = 0; i < n; i++) {
