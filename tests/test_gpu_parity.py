@@ -488,3 +488,31 @@ def test_ckzg_mode_random_blobs_vs_oracle(K, gpu_setup, oracle, oracle_setup):
         assert K.verify_kzg_proof(c, z, y, pr, gpu_setup) is True
         assert K.verify_blob_kzg_proof(b, c, p, gpu_setup) is True
     assert K.verify_blob_kzg_proof_batch(b"".join(blobs), b"".join(comms), b"".join(proofs), 3, gpu_setup) is True
+
+
+def test_c_consumer_links_and_matches_oracle(K, oracle, oracle_setup, tmp_path):
+    """A plain C program (gcc, the public header, -llambdaworks_kzg) drives the nine symbols like the reference's
+    fuzz harnesses do; its output is compared with the oracle."""
+    import os
+    import subprocess
+    from conftest import ROOT, SETUP_PATH
+    lib_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "lib")
+    exe = str(tmp_path / "harness")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_harness.c"), "-o", exe, "-L", lib_dir, "-llambdaworks_kzg",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    blob = B.synthetic_blob(77)
+    bpath = tmp_path / "blob.bin"
+    bpath.write_bytes(blob)
+    env = dict(os.environ)
+    env.pop("LWKZG_MODE", None)
+    out = subprocess.check_output([exe, SETUP_PATH, str(bpath)], env=env, timeout=300).decode().split("\n")
+    kv = dict(l.split(" ", 1) for l in out if " " in l)
+    rc, cm = oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_R)
+    assert kv["commitment"] == cm.hex()
+    assert kv["blob_proof"] == oracle.compute_blob_kzg_proof(blob, cm, oracle_setup, oracle.MODE_R)[1].hex()
+    z = (2).to_bytes(32, "big")
+    rc, pr, y = oracle.compute_kzg_proof(blob, z, oracle_setup, oracle.MODE_R)
+    assert kv["proof"] == pr.hex() and kv["y"] == y.hex()
+    assert kv["verify_blob"] == "1" and kv["verify"] == "1" and kv["verify_wrong_y"] == "0"
+    assert kv["g1_0_x_limb0"] == "17f1d3a73197d794"
