@@ -516,3 +516,19 @@ def test_c_consumer_links_and_matches_oracle(K, oracle, oracle_setup, tmp_path):
     assert kv["proof"] == pr.hex() and kv["y"] == y.hex()
     assert kv["verify_blob"] == "1" and kv["verify"] == "1" and kv["verify_wrong_y"] == "0"
     assert kv["g1_0_x_limb0"] == "17f1d3a73197d794"
+
+
+def test_noncanonical_infinity_commitment_takes_gpu_hash_fallback(K, gpu_setup, oracle, oracle_setup):
+    """decompress_g1_point does not inspect the remaining bits of an infinity encoding (compression.rs:73-75) and
+    compute_challenge hashes the RE-compressed point (utils.rs:138): a commitment 0xc0 | junk must hash as c0 00..00.
+    On the host-pointer path this is the case where the host digest (made from the caller's bytes) is discarded and
+    the GPU hash over the canonical bytes is used."""
+    blob = B.synthetic_blob(55)
+    junk = bytes([0xc0]) + bytes(range(1, 48))
+    got = K.compute_blob_kzg_proof(blob, junk, gpu_setup)
+    assert oracle.compute_blob_kzg_proof(blob, junk, oracle_setup, oracle.MODE_R) == (0, got)
+    assert got == K.compute_blob_kzg_proof(blob, bytes([0xc0]) + bytes(47), gpu_setup)
+    # mixed batch: one canonical, one not
+    c0 = K.blob_to_kzg_commitment(blob, gpu_setup)
+    both = K.compute_blob_kzg_proof_batch(blob + blob, c0 + junk, gpu_setup)
+    assert both[1] == got and oracle.compute_blob_kzg_proof(blob, c0, oracle_setup, oracle.MODE_R) == (0, both[0])
