@@ -72,3 +72,30 @@ def test_world_size_2_broadcast_and_gather(n_items):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, True), (1, True, True)]
+
+
+def _verify_worker(rank, world, port, bad_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the per-shard verdict is injected: the AND across ranks is what this test covers
+        verdict = D.verify_blob_kzg_proof_batch_sharded(b"", b"", b"", 3, None, _verify=lambda *a: rank != bad_rank)
+        q.put((rank, verdict))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank", [-1, 1])
+def test_sharded_batch_verification_ands_the_shard_verdicts(bad_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, bad_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, bad_rank < 0), (1, bad_rank < 0)]
