@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <map>
+#include <thread>
 #include <vector>
 
 namespace lwk {
@@ -399,11 +400,21 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         int32_t *stt = status ? status + off : w.status;
         const uint8_t *bl = blobs + off * (size_t)kBlobBytes;
+        const uint8_t *cm = comm48 + 48 * off;
         LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
-        // lib.rs:372-375: the commitment is decompressed (and subgroup-checked) first
-        launch_validate_commitments(comm48 + 48 * off, w.canon48, stt, le ? kStatusBadArgs : kStatusError, m, st);
+        // lib.rs:372-375: the commitment is decompressed (and subgroup-checked) first. Validation (a long scalar
+        // multiplication per lane) and hashing (131 KB per lane) are both latency-shaped and independent as long as
+        // the caller's bytes are the canonical encoding, which they are except for exotic encodings of infinity:
+        // hash optimistically from the caller's bytes on `st` while an auxiliary stream validates, then redo only
+        // the lanes whose canonical bytes differ.
+        LWK_HIP(hipEventRecord(c->ev_fork, st));
+        LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+        launch_validate_commitments(cm, w.canon48, stt, le ? kStatusBadArgs : kStatusError, m, c->aux[0]);
+        LWK_HIP(hipEventRecord(c->ev_join[0], c->aux[0]));
         coefficients_stage(c, bl, m, mode, stt, st);
-        launch_challenge(bl, w.canon48, w.z, le, m, st);
+        launch_challenge(bl, cm, w.z, le, m, st);
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        launch_challenge(bl, w.canon48, w.z, le, m, st, cm);
         launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
         msm_stages(c, w.scalars2, out48 + 48 * off, m, st);
     }
@@ -844,28 +855,42 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         hipStream_t st = c->stream;
         const int le = mode == LWKZG_MODE_CKZG;
         const uint8_t *h_blobs = (const uint8_t *)(blobs + off), *h_comm = (const uint8_t *)(commitments + off);
+        // host threads start hashing at once (the blobs are in host memory here; one GPU lane would need ~7 ms per
+        // 131 KB message, a core with SHA extensions ~0.1 ms) and run beside the pageable H2D copy, which blocks
+        // this thread for a few milliseconds. The digests assume the caller's commitment bytes are the canonical
+        // encoding; the validation's re-compression confirms or refutes that below.
+        std::vector<uint8_t> h_canon(m * 48), h_dig(m * 32);
+        std::thread hasher([&]() { challenge_digests_host(h_dig.data(), h_blobs, h_comm, m); });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } joiner{hasher};
         LWK_HIP(hipMemcpyAsync(w.blobs, h_blobs, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemcpyAsync(w.comm48, h_comm, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
-        // GPU: validate the commitments (lib.rs:372-375) and parse the blobs ...
-        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, st);
+        // GPU, auxiliary stream: validate the commitments (lib.rs:372-375) -- a long per-lane scalar multiplication
+        // whose verdict and canonical bytes are only needed at the very end.
+        LWK_HIP(hipEventRecord(c->ev_fork, st));
+        LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+        launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, c->aux[0]);
+        LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, c->aux[0]));
+        LWK_HIP(hipEventRecord(c->ev_join[0], c->aux[0]));
+        // GPU, main stream: parse the blobs, then the digests as soon as the host threads have them
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
-        std::vector<uint8_t> h_canon(m * 48), h_dig(m * 32);
-        LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, st));
-        // ... while the host threads hash (the blobs are in host memory here; one GPU lane would need ~7 ms per
-        // 131 KB message, a core with SHA extensions ~0.1 ms). The digests assume the commitment bytes are already
-        // canonical, which the GPU's re-compression confirms or refutes below.
-        challenge_digests_host(h_dig.data(), h_blobs, h_comm, m);
-        LWK_HIP(hipStreamSynchronize(st));
-        if (memcmp(h_canon.data(), h_comm, m * 48) == 0) {
-            LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
-            launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
-        } else {
-            // a non-canonical but valid encoding (or an invalid point, reported through status): hash on the GPU
-            launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
-        }
+        hasher.join();
+        LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
+        launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
         msm_stages(c, w.scalars2, w.out48, m, st);
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        LWK_HIP(hipStreamSynchronize(st));
+        if (memcmp(h_canon.data(), h_comm, m * 48) != 0) {
+            // a non-canonical but valid encoding somewhere in the chunk (or an invalid point, reported through
+            // status): redo the chunk with the hash taken over the canonical bytes on the GPU
+            launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
+            launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+            msm_stages(c, w.scalars2, w.out48, m, st);
+        }
         std::vector<uint8_t> h_out(m * 48);
         LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
         rc = collect_status(c, w.status, m, off, first_bad);

@@ -71,12 +71,26 @@ __device__ __forceinline__ uint4 challenge_chunk(int q, const uint4 *blob, const
     return make_uint4(0u, 0u, 0u, 0u);
 }
 
+// only_if_differs_from (optional): the fix-up pass of the optimistic pipeline -- z was already computed from
+// these (caller-supplied) commitment bytes while the validation kernel ran; lanes whose canonical bytes are
+// identical have nothing to redo and exit at once.
 __global__ __launch_bounds__(64) void k_challenge(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
-                                                  Fr *__restrict__ z_mont, int le, size_t n) {
+                                                  Fr *__restrict__ z_mont, int le, size_t n,
+                                                  const uint8_t *__restrict__ only_if_differs_from) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 *blob = (const uint4 *)(blobs + (size_t)kBlobBytes * i);
     const uint4 *comm = (const uint4 *)(canon48 + 48 * i);
+    if (only_if_differs_from) {
+        const uint4 *raw = (const uint4 *)(only_if_differs_from + 48 * i);
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint4 a = comm[k], b = raw[k];
+            same = same && a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+        }
+        if (same) return;
+    }
     uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
     constexpr int kBlocks = (2 + kBlobBytes / 16 + 3 + 3) / 4;  // 2050
     for (int blk = 0; blk < kBlocks; blk++) {
@@ -101,9 +115,11 @@ __global__ __launch_bounds__(64) void k_challenge(const uint8_t *__restrict__ bl
     z_mont[i] = fe_from_raw<FrParams>(s);  // reduced mod r
 }
 
-void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st) {
-    ProfScope p("k_challenge", st);
-    hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blobs, canon48, z_mont, le, n);
+void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
+                      const uint8_t *only_if_differs_from) {
+    ProfScope p(only_if_differs_from ? "k_challenge_fixup" : "k_challenge", st);
+    hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blobs, canon48, z_mont, le, n,
+                       only_if_differs_from);
 }
 
 // host SHA-256 for the one batch-level hash of verify_blob_kzg_proof_batch (compute_r_powers,
