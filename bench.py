@@ -4,12 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (blob bytes -> 48-byte commitments: parse, digit sort, bucket
-accumulate, bucket reduce, compress) over one batch of synthetic 4096-element blobs that is already
+A "step" is one pass of the hot path (blob bytes -> 48-byte commitments: parse, fixed-base MSM, compress;
+the MSM is the direct-table kernel when the table fits in HBM, else digit sort + bucket accumulate + bucket
+reduce) over one batch of synthetic 4096-element blobs that is already
 resident in HBM. Each GPU works on its own shard (weak scaling: 1024 blobs per GPU per step); the only
 collective is the one broadcast of the prepared trusted setup before the timed region.
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (k_bucket_accumulate) against HBM as
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (k_direct_accumulate / k_bucket_accumulate) against HBM as
 the north star mandates AND gives the integer-multiply picture, because the kernel is integer-ALU bound
 (DESIGN.md section 5). `cpu_baseline` times the CPU oracle (a restatement of the reference's algorithm,
 NOT the reference binary, which cannot be built here) on this box's host cores.
@@ -112,6 +113,9 @@ def main():
     ap.add_argument("--op", default="commit", choices=["commit", "blob_proof"])
     ap.add_argument("--mode", default="reference", choices=["reference", "ckzg"],
                     help="reference = lambdaworks_kzg semantics (default, the headline); ckzg = c-kzg-4844 semantics (adds the inverse NTT)")
+    ap.add_argument("--direct-bits", default="auto",
+                    help="direct fixed-base table (lwkzg_enable_direct_table): auto = widest of 16/15/14 that fits in HBM, "
+                         "else the bucket path; 0 = bucket path; 14/15/16 = that width or fail")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
 
@@ -157,6 +161,22 @@ def main():
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
     d_comm = None
     ts.reserve(n)
+    # every rank builds its own direct table from the (broadcast) setup points: a few seconds, once, outside the timed region
+    t_tab0 = time.perf_counter()
+    direct_bits = 0
+    if args.direct_bits == "auto":
+        for bits in (16, 15, 14):
+            try:
+                ts.enable_direct_table(bits)
+                direct_bits = bits
+                break
+            except capi.KzgError as e:
+                if e.rc != capi.C_KZG_MALLOC:
+                    raise
+    elif int(args.direct_bits) != 0:
+        ts.enable_direct_table(int(args.direct_bits))
+        direct_bits = int(args.direct_bits)
+    t_table = time.perf_counter() - t_tab0
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -198,7 +218,7 @@ def main():
     if rank == 0:
         total_blobs = n * world * args.steps
         value = total_blobs / elapsed
-        dom = "k_bucket_accumulate"
+        dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
         k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
         avg_ms = k["total_ms"] / max(1, k["launches"])
         # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
@@ -210,14 +230,27 @@ def main():
         # integer picture: a mixed add is 8 Montgomery products (392 v_mad_u64_u32 each on 14x29-bit limbs) and
         # 2 squares (301 each); peak = v_mad_u64_u32 issue rate measured by tools/ubench.hip on MI355X
         # (profiles/r01_ubench_instruction_rates.jsonl: 2.93e13 lane-mads/s at 8 waves/SIMD)
-        nwin = K.lib().lwkzg_msm_num_windows()
-        adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
+        if direct_bits:
+            nwin = K.lib().lwkzg_direct_num_windows(direct_bits)
+            adds_per_msm = 4096 * nwin * (1 - 2.0 ** -direct_bits)
+        else:
+            nwin = K.lib().lwkzg_msm_num_windows()
+            adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
+        GATHER_PEAK_ROWS = 1.31e10     # tools/gather_bench.hip on MI355X: random 112-byte rows/s out of a 128-200 GiB table
+        gather = None
+        if direct_bits and avg_ms > 0:
+            rows = msms_per_launch * adds_per_msm
+            gather = {"rows_per_launch": rows, "bytes_per_launch": rows * 112,
+                      "achieved_rows_per_s": rows / (avg_ms * 1e-3), "peak_rows_per_s": GATHER_PEAK_ROWS,
+                      "frac": rows / (avg_ms * 1e-3) / GATHER_PEAK_ROWS,
+                      "note": "the direct path really reads one random 112-byte table row per mixed addition from HBM "
+                              "(table far larger than every cache); ceiling measured by tools/gather_bench.hip"}
         mads_per_launch = msms_per_launch * adds_per_msm * (8 * 392 + 2 * 301)
         INT_MAD_PEAK = 2.93e13
         traffic = None
         try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size only
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("batch_blobs_per_launch") == msms_per_launch and args.op == "commit":
+            if pmc.get("batch_blobs_per_launch") == msms_per_launch and args.op == "commit" and pmc.get("direct_bits", 0) == direct_bits:
                 traffic = pmc["kernels"][dom]["traffic_bytes"]
         except Exception:
             traffic = None
@@ -236,13 +269,15 @@ def main():
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
             "config": {"workload": "BASELINE configs[1]: single-GPU G1 Pippenger MSM, 4096 scalars, batch=%d synthetic blobs "
                                    "per GPU per step, device-resident, bit-exact vs CPU" % n,
-                       "blobs_per_gpu_per_step": n, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
+                       "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes per launch at the L2's memory side from rocprofv3 FETCH_SIZE (raw) + WRITE_SIZE, "
-                                         "separate passes (profiles/pmc_traffic.json); mostly Infinity-Cache-served re-reads of "
-                                         "the 9.2 MB fixed-base table, see DESIGN.md section 4",
+                                         "separate passes (profiles/pmc_traffic.json); " +
+                                         ("random 112-byte row gathers out of the direct table, see DESIGN.md section 4" if direct_bits else
+                                          "mostly Infinity-Cache-served re-reads of the 9.2 MB fixed-base table, see DESIGN.md section 4"),
+                         "gather": gather,
                          "algorithmic_bytes_per_launch": msms_per_launch * ALGO_BYTES_PER_MSM,
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "concurrency_note": "the %d launches of a step run concurrently on separate streams, each on a share of "
@@ -257,6 +292,9 @@ def main():
                                      "frac_whole_step": mads_per_launch * launches_per_step / (elapsed / args.steps) / INT_MAD_PEAK}},
             "kernels": kernels,
             "setup_load_s": t_load,
+            "msm_path": ("direct table, %d-bit windows, %d windows, %.0f GB resident" % (
+                direct_bits, nwin, capi.direct_table_bytes(direct_bits) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
+            "direct_table_build_s": t_table if direct_bits else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "reference":
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""

@@ -160,6 +160,18 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void 
                                                     size_t n, const KZGSettings *s, void *stream, int32_t *status_dev);
 C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
 
+/* Opt-in "direct" fixed-base MSM for this settings object: trade HBM capacity for arithmetic. With every
+ * multiple d * 2^(window_bits * j) * P_i of every setup point resident (68 GB for window_bits = 14, 135 GB
+ * for 15, 240 GB for 16), the 4096-term MSM behind every entry point above becomes 4096 * ceil(255 /
+ * window_bits) gathered mixed additions: no digit sort, no buckets, no bucket reduction. Results are
+ * bit-identical to the default path. window_bits = 0 frees the table and returns to the default path.
+ * Returns C_KZG_MALLOC (engine unchanged, default path still usable) when the table does not fit, C_KZG_BADARGS for
+ * other widths. Replaces nothing in the reference: lambdaworks' pippenger::msm (call sites src/lib.rs:242,270,329,394)
+ * has no precomputation at all. */
+C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits);
+int lwkzg_direct_table_bits(const KZGSettings *s);   /* 0 = default path, 14/15/16 = direct table live, -1 = bad settings */
+int lwkzg_direct_num_windows(int window_bits);       /* additions per scalar on the direct path (0 for other widths) */
+
 /* General G1 multi-scalar multiplication against the first `npoints` setup points:
  * scalars_dev = n_msm x npoints x 32 bytes (big-endian, reduced mod r), out = n_msm x 48 bytes compressed.
  * (reference: g1_lincomb, src/lib.rs:234-243, over srs.powers_main_group.) */

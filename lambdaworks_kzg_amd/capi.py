@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
+    "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows",
 ]
 
 _lib = None
@@ -80,6 +81,9 @@ def lib():
     l.lwkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_reserve.argtypes = [ps, sz]
+    l.lwkzg_enable_direct_table.argtypes = [ps, ci]
+    l.lwkzg_direct_table_bits.argtypes = [ps]
+    l.lwkzg_direct_num_windows.argtypes = [ci]
     l.lwkzg_g1_lincomb_setup_device.argtypes = [vp, vp, sz, ps, vp]
     l.lwkzg_fr_ntt4096_device.argtypes = [vp, vp, sz, ci, ps, vp]
     l.lwkzg_setup_image_bytes.restype = sz
@@ -118,6 +122,15 @@ _libc = C.CDLL(None)
 _libc.fopen.restype = C.c_void_p
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 _libc.fclose.argtypes = [C.c_void_p]
+
+
+def direct_table_bytes(window_bits):
+    """HBM footprint of the direct table of that width (112-byte rows)."""
+    nw = lib().lwkzg_direct_num_windows(window_bits)
+    if nw == 0:
+        return 0
+    top = 255 - window_bits * (nw - 1)
+    return ((nw - 1) * 4096 * (1 << (window_bits - 1)) + 4096 * (1 << top)) * 112
 
 
 def set_mode(mode):
@@ -187,6 +200,13 @@ class TrustedSetup:
 
     def reserve(self, n):
         _check("lwkzg_reserve", lib().lwkzg_reserve(self.ref(), n))
+
+    def enable_direct_table(self, window_bits):
+        """Opt in to (14 / 15 / 16) or out of (0) the giant-table MSM; raises KzgError(C_KZG_MALLOC) if it does not fit."""
+        _check("lwkzg_enable_direct_table", lib().lwkzg_enable_direct_table(self.ref(), window_bits))
+
+    def direct_table_bits(self):
+        return lib().lwkzg_direct_table_bits(self.ref())
 
     def free(self):
         if self._loaded:

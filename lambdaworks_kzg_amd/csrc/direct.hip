@@ -1,0 +1,300 @@
+// direct.hip -- "direct" fixed-base MSM: no buckets at all, paid for with HBM capacity.
+//
+// The MI355X has 288 GB of HBM3E and the SRS never changes. With every multiple d * 2^(C j) * P_i
+// (d = 1 .. 2^(C-1)) of every setup point precomputed in affine form, a 4096-term MSM is nothing but the
+// sum of one table row per (scalar, window): 4096 * ceil(255 / C) mixed additions -- 65,536 for C = 16,
+// 69,632 for C = 15 -- with no digit sort, no bucket array and no bucket reduction (the bucket path of
+// msm.hip spends 81,920 additions plus ~15 % on sort + reduction). The table is 4096 * 16 * 32768 * 112 B =
+// 240 GB for C = 16, 135 GB for C = 15, 68 GB for C = 14; its rows are gathered at random, 112 contiguous
+// bytes per lane, which HBM sustains at 1.3e10 rows/s for tables of this size (tools/gather_bench.hip),
+// twice what the arithmetic can consume. It is opt-in (lwkzg_enable_direct_table): the default engine keeps
+// the 9 MB bucket-path table so that several settings objects can coexist.
+//
+// Replaces, like msm.hip, lambdaworks_math::msm::pippenger::msm as reached from KZG::commit / KZG::open
+// (call sites /root/reference/src/lib.rs:242,270,329,394).
+#include <stdlib.h>
+#include "kernels.h"
+
+namespace lwk {
+
+template <int C>
+struct DirectPlan {
+    static constexpr int NW = (255 + C - 1) / C;          // windows; the top one is unsigned and takes the carry
+    static constexpr int H = 1 << (C - 1);                // rows per (signed window, point): d = 1 .. 2^(C-1)
+    static constexpr int WTOP = 255 - C * (NW - 1);       // bits in the top window (scalars are < r < 2^255)
+    static constexpr int HTOP = 1 << WTOP;                // rows per (top window, point): d = 1 .. 2^WTOP
+    static constexpr size_t TOP_BASE = (size_t)(NW - 1) * kBlobElems * H;
+    static constexpr size_t ENTRIES = TOP_BASE + (size_t)kBlobElems * HTOP;
+};
+
+size_t direct_table_entries(int bits) {
+    switch (bits) {
+        case 14: return DirectPlan<14>::ENTRIES;
+        case 15: return DirectPlan<15>::ENTRIES;
+        case 16: return DirectPlan<16>::ENTRIES;
+        default: return 0;
+    }
+}
+int direct_num_windows(int bits) {
+    switch (bits) {
+        case 14: return DirectPlan<14>::NW;
+        case 15: return DirectPlan<15>::NW;
+        case 16: return DirectPlan<16>::NW;
+        default: return 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// table build, step 1: Q[j][i] = 2^(C j) P_i in affine hot-loop form (one lane per point)
+
+LWK_HD G1Affine29 xyzz29_to_affine29(const G1Xyzz29 &p) {
+    auto i = f29_inv(p.zz * p.zzz);
+    auto izz = i * p.zzz;
+    auto izzz = i * p.zz;
+    G1Affine29 r;
+    r.x = p.x * izz;
+    r.y = p.y * izzz;
+    return r;
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void k_direct_qbase(const G1Affine *__restrict__ points, G1Affine29 *__restrict__ qbase) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kBlobElems) return;
+    G1Affine29 a = affine_to_29(points[i]);
+    qbase[i] = a;
+    G1Xyzz29 cur = G1Xyzz29::from_affine(a.x, a.y);
+    for (int j = 1; j < DirectPlan<C>::NW; j++) {
+        for (int d = 0; d < C; d++) cur = xyzz_dbl(cur);
+        qbase[(size_t)j * kBlobElems + i] = xyzz29_to_affine29(cur);  // never infinity: P has prime order r
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// table build, step 2: all multiples. One lane per chunk of kChunk consecutive multiples of one Q:
+//   forward  : walk (s0 + m) Q in XYZZ; park each point and the running product of its ZZ*ZZZ in lane-private
+//              scratch (five 56-byte values per row, interleaved across lanes so the accesses coalesce)
+//   invert   : ONE field inversion per chunk (Montgomery's trick)
+//   backward : peel the individual inverses off the running product and emit the affine rows.
+// About 25 field products per row; the scratch traffic (560 B per row) is what the build time is made of.
+
+constexpr int kChunk = 64;
+
+template <int M>  // rows per (window, point) pair in this launch
+__global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restrict__ qbase_win0, G1Affine29 *__restrict__ out_win0,
+                                                      size_t n_pairs, F29<2> *__restrict__ scratch, size_t n_threads) {
+    constexpr int K = M < kChunk ? M : kChunk;
+    constexpr size_t kChunksPerPair = M / K;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_work = n_pairs * kChunksPerPair;
+    // scratch rows: [m][5][lane] -> X, Y, ZZ, ZZZ (weakly reduced to < 2p) and the prefix product
+    auto slot = [&](int m, int f) -> F29<2> & { return scratch[((size_t)m * 5 + f) * n_threads + gid]; };
+    for (size_t w = gid; w < n_work; w += n_threads) {
+        const size_t pair = w / kChunksPerPair;
+        const uint32_t s0 = (uint32_t)(w % kChunksPerPair) * K + 1;
+        const G1Affine29 q = qbase_win0[pair];
+        // cur = [s0] Q
+        G1Xyzz29 cur = G1Xyzz29::infinity();
+        for (int bit = 16; bit >= 0; bit--) {
+            cur = xyzz_dbl(cur);
+            if ((s0 >> bit) & 1) cur = xyzz_madd(cur, q.x, q.y);
+        }
+        F29<2> pref = F29<2>::one();
+        const F29<1> one = F29<1>::one();
+        for (int m = 0; m < K; m++) {
+            F29<2> t = cur.zz * cur.zzz;
+            pref = (m == 0) ? t : F29<2>(pref * t);
+            slot(m, 0) = cur.x * one;  // X < 14p -> < 2p (same residue)
+            slot(m, 1) = cur.y * one;
+            slot(m, 2) = cur.zz;
+            slot(m, 3) = cur.zzz;
+            slot(m, 4) = pref;
+            if (m < K - 1) cur = xyzz_madd(cur, q.x, q.y);
+        }
+        F29<2> inv = f29_inv(pref);
+        G1Affine29 *rows = out_win0 + pair * (size_t)M + (s0 - 1);
+        for (int m = K - 1; m >= 0; m--) {
+            F29<2> zz = slot(m, 2), zzz = slot(m, 3);
+            F29<2> tinv = (m > 0) ? F29<2>(inv * slot(m - 1, 4)) : inv;  // 1 / (ZZ ZZZ) of row m
+            inv = inv * (zz * zzz);                                      // inverse of the prefix product up to row m - 1
+            G1Affine29 r;
+            r.x = slot(m, 0) * (tinv * zzz);  // X / ZZ
+            r.y = slot(m, 1) * (tinv * zz);   // Y / ZZZ
+            rows[m] = r;
+        }
+    }
+}
+
+template <int C>
+static hipError_t build_direct_table_t(const G1Affine *points, G1Affine29 *table, hipStream_t st) {
+    typedef DirectPlan<C> P;
+    G1Affine29 *qbase = nullptr;
+    F29<2> *scratch = nullptr;
+    const size_t n_threads = 256 * 1024;  // lanes in flight during the build (4.7 GB of scratch)
+    hipError_t e = hipMalloc((void **)&qbase, (size_t)P::NW * kBlobElems * sizeof(G1Affine29));
+    if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)kChunk * 5 * n_threads * sizeof(F29<2>));
+    if (e == hipSuccess) {
+        {
+            ProfScope p("k_direct_qbase", st);
+            hipLaunchKernelGGL(k_direct_qbase<C>, dim3(kBlobElems / 64), dim3(64), 0, st, points, qbase);
+        }
+        {
+            ProfScope p("k_direct_build", st);
+            hipLaunchKernelGGL((k_direct_build<P::H>), dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase, table,
+                               (size_t)(P::NW - 1) * kBlobElems, scratch, n_threads);
+            hipLaunchKernelGGL((k_direct_build<P::HTOP>), dim3((unsigned)(n_threads / 256)), dim3(256), 0, st,
+                               qbase + (size_t)(P::NW - 1) * kBlobElems, table + P::TOP_BASE, (size_t)kBlobElems, scratch,
+                               n_threads);
+        }
+        e = hipStreamSynchronize(st);
+    }
+    if (qbase) hipFree(qbase);
+    if (scratch) hipFree(scratch);
+    return e;
+}
+
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st) {
+    switch (bits) {
+        case 14: return build_direct_table_t<14>(points, table, st);
+        case 15: return build_direct_table_t<15>(points, table, st);
+        case 16: return build_direct_table_t<16>(points, table, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the MSM: every lane owns a strided set of scalars of one blob, turns each into <= NW table rows on the fly
+// (signed C-bit digits, top window unsigned), gathers the row while the previous mixed addition runs, and keeps
+// its partial sum in VGPRs; the workgroup folds its 256 partial sums by wave shuffles + one LDS hop.
+
+constexpr int kDirThreads = 256;
+
+template <int C>
+__global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
+                                                                   const uint4 *__restrict__ scalars,
+                                                                   G1Xyzz29 *__restrict__ partials, int scalars_per_lane) {
+    typedef DirectPlan<C> P;
+    __shared__ uint32_t limbs[8 * kDirThreads];   // the lane's current scalar, for run-time window indexing
+    __shared__ G1Xyzz29 wave_sum[kDirThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t blob = blockIdx.y;
+    const int lanes_per_blob = gridDim.x * kDirThreads;
+    const int first = blockIdx.x * kDirThreads + tid;
+    const uint4 *sc = scalars + blob * (size_t)kBlobElems * 2;
+    const G1Affine29i *tab = (const G1Affine29i *)table;
+
+    int q = 0, j = 0;
+    uint32_t carry = 0, point = 0;
+    // next non-zero digit of this lane's scalar stream: row address resolved and its gather issued
+    auto advance = [&](bool &valid, uint32_t &neg, G1Affine29i &row) {
+        valid = false;
+        while (q < scalars_per_lane) {
+            if (j == 0) {
+                point = (uint32_t)(first + q * lanes_per_blob);
+                uint4 lo = sc[2 * point], hi = sc[2 * point + 1];
+                limbs[0 * kDirThreads + tid] = lo.x; limbs[1 * kDirThreads + tid] = lo.y;
+                limbs[2 * kDirThreads + tid] = lo.z; limbs[3 * kDirThreads + tid] = lo.w;
+                limbs[4 * kDirThreads + tid] = hi.x; limbs[5 * kDirThreads + tid] = hi.y;
+                limbs[6 * kDirThreads + tid] = hi.z; limbs[7 * kDirThreads + tid] = hi.w;
+                carry = 0;
+            }
+            const int o = j * C, limb = o >> 5, sh = o & 31;
+            uint32_t v = limbs[limb * kDirThreads + tid] >> sh;
+            if (sh + C > 32 && limb + 1 < 8) v |= limbs[(limb + 1) * kDirThreads + tid] << (32 - sh);
+            const bool top = j == P::NW - 1;
+            uint32_t raw = (v & ((top ? (1u << P::WTOP) : (1u << C)) - 1u)) + carry;
+            uint32_t ng = (!top && raw > (uint32_t)P::H) ? 1u : 0u;
+            uint32_t mag = ng ? (1u << C) - raw : raw;
+            carry = ng;
+            size_t idx = top ? P::TOP_BASE + (size_t)point * P::HTOP + (mag - 1)
+                             : ((size_t)j * kBlobElems + point) * P::H + (mag - 1);
+            j++;
+            if (j == P::NW) {
+                j = 0;
+                q++;
+            }
+            if (mag) {
+                valid = true;
+                neg = ng;
+                row = tab[idx];
+                return;
+            }
+        }
+    };
+
+    G1Xyzz29i acc = G1Xyzz29i::infinity();
+    bool cv, nv;
+    uint32_t cn, nn;
+    G1Affine29i cr, nr;
+    advance(cv, cn, cr);
+    while (cv) {
+        advance(nv, nn, nr);
+        acc = xyzz_madd(acc, cr.x, cneg(cr.y, cn != 0));
+        cv = nv;
+        cn = nn;
+        cr = nr;
+    }
+
+    // fold: 64 lanes by shuffles, 4 waves through LDS
+    G1Xyzz29 s = *(G1Xyzz29 *)&acc;
+    for (int d = 32; d >= 1; d >>= 1) {
+        G1Xyzz29 other;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            other.x.l[k] = __shfl_down(s.x.l[k], d, 64);
+            other.y.l[k] = __shfl_down(s.y.l[k], d, 64);
+            other.zz.l[k] = __shfl_down(s.zz.l[k], d, 64);
+            other.zzz.l[k] = __shfl_down(s.zzz.l[k], d, 64);
+        }
+        if (lane < d) s = xyzz_add(s, other);
+    }
+    if (lane == 0) wave_sum[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w2 = 1; w2 < kDirThreads / 64; w2++) s = xyzz_add(s, wave_sum[w2]);
+        partials[blob * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// sums[blob] = sum of its per-block partial sums (only when a blob was spread over several workgroups)
+__global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__ partials, G1Xyzz29 *__restrict__ sums,
+                                                    int per_blob, size_t n_blobs) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blobs) return;
+    G1Xyzz29 s = partials[b * per_blob];
+    for (int k = 1; k < per_blob; k++) s = xyzz_add(s, partials[b * per_blob + k]);
+    sums[b] = s;
+}
+
+template <int C>
+static void launch_direct_t(const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
+                            size_t n_blobs, hipStream_t st) {
+    // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
+    // 16 workgroups so the chip fills and the dependent chain per lane stays short
+    static const int kFill = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 512;
+    int blocks_per_blob = 1;
+    while (blocks_per_blob < 16 && n_blobs * blocks_per_blob < (size_t)kFill) blocks_per_blob <<= 1;
+    const int scalars_per_lane = kBlobElems / (kDirThreads * blocks_per_blob);
+    {
+        ProfScope p("k_direct_accumulate", st);
+        hipLaunchKernelGGL(k_direct_accumulate<C>, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(kDirThreads), 0, st, table,
+                           (const uint4 *)scalars_raw, blocks_per_blob == 1 ? sums : partials, scalars_per_lane);
+    }
+    if (blocks_per_blob > 1) {
+        ProfScope p("k_direct_fold", st);
+        hipLaunchKernelGGL(k_direct_fold, dim3((unsigned)((n_blobs + 63) / 64)), dim3(64), 0, st, partials, sums,
+                           blocks_per_blob, n_blobs);
+    }
+}
+
+void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
+                       size_t n_blobs, hipStream_t st) {
+    switch (bits) {
+        case 14: launch_direct_t<14>(table, scalars_raw, partials, sums, n_blobs, st); break;
+        case 15: launch_direct_t<15>(table, scalars_raw, partials, sums, n_blobs, st); break;
+        case 16: launch_direct_t<16>(table, scalars_raw, partials, sums, n_blobs, st); break;
+        default: break;
+    }
+}
+
+}  // namespace lwk

@@ -54,6 +54,8 @@ struct Ctx {
     hipEvent_t ev_fork, ev_join[kMaxSplit];
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
     G1Affine29 *table;  // kTablePoints, hot-loop representation
+    G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled
+    int direct_bits;           // 14 / 15 / 16 when direct_table is live, else 0
     Fr *tw_fwd, *tw_inv;
     Workspace ws;
     std::mutex mu;

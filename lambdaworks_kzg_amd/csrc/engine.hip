@@ -159,6 +159,7 @@ static void ctx_destroy(Ctx *c) {
     ws_free(c->ws);
     dev_free(c->points);
     dev_free(c->table);
+    dev_free(c->direct_table);
     dev_free(c->tw_fwd);
     dev_free(c->tw_inv);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -202,6 +203,8 @@ static C_KZG_RET ctx_new(Ctx **out) {
     }
     c->points = nullptr;
     c->table = nullptr;
+    c->direct_table = nullptr;
+    c->direct_bits = 0;
     c->tw_fwd = c->tw_inv = nullptr;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
@@ -320,6 +323,11 @@ static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size
     uint32_t *perm = w.perm + base * (size_t)(kNumBuckets + 1);
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
     G1Xyzz29 *sums = w.sums + base;
+    if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
+        launch_direct_msm(c->direct_bits, c->direct_table, scalars_raw, buckets, sums, n, st);
+        launch_finalize_compress(sums, out48, n, st);
+        return;
+    }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
     launch_bucket_accumulate(c->table, sorted, bstart, perm, buckets, n, st);
     launch_bucket_reduce(buckets, sums, n, st);
@@ -950,6 +958,45 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch) {
     std::lock_guard<std::mutex> lk(c->mu);
     return ctx_reserve(c, max_batch);
 }
+
+C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    LWK_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < kMaxSplit; k++) LWK_HIP(hipStreamSynchronize(c->aux[k]));
+    if (window_bits == c->direct_bits) return C_KZG_OK;
+    dev_free(c->direct_table);
+    c->direct_bits = 0;
+    if (window_bits == 0) return C_KZG_OK;
+    const size_t rows = direct_table_entries(window_bits);
+    if (rows == 0) {
+        set_error("lwkzg_enable_direct_table: window_bits must be 0, 14, 15 or 16 (got %d)", window_bits);
+        return C_KZG_BADARGS;
+    }
+    G1Affine29 *t = nullptr;
+    hipError_t e = hipMalloc((void **)&t, rows * sizeof(G1Affine29));
+    if (e == hipSuccess) {
+        e = build_direct_table(window_bits, c->points, t, c->stream);
+        if (e != hipSuccess) hipFree(t);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // an out-of-memory here is an answer, not a sticky failure
+        set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, rows * sizeof(G1Affine29), hipGetErrorString(e));
+        return C_KZG_MALLOC;
+    }
+    c->direct_table = t;
+    c->direct_bits = window_bits;
+    return C_KZG_OK;
+}
+
+int lwkzg_direct_table_bits(const KZGSettings *s) {
+    Ctx *c = ctx_of(s);
+    return c ? c->direct_bits : -1;
+}
+
+int lwkzg_direct_num_windows(int window_bits) { return direct_num_windows(window_bits); }
 
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void *blobs_dev, size_t n, const KZGSettings *s,
                                                     void *stream, int32_t *status_dev) {

@@ -36,6 +36,15 @@ void launch_sum_points(const G1Xyzz29 *in, size_t n, G1Xyzz29 *total, int accumu
 // sums -> 48-byte compressed points (compress_g1_point, /root/reference/src/compression.rs:33-60)
 void launch_finalize_compress(const G1Xyzz29 *sums, uint8_t *out48, size_t n, hipStream_t st);
 
+// ---- direct fixed-base MSM (direct.hip): every multiple d * 2^(bits j) * P_i precomputed, no buckets.
+// bits in {14, 15, 16}; the table has direct_table_entries(bits) rows of 112 bytes (68 / 135 / 240 GB).
+size_t direct_table_entries(int bits);
+int direct_num_windows(int bits);
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st);
+// sums[b] = sum_i scalars[b][i] * P_i. `partials` needs 16 * n_blobs entries when n_blobs < 1024 (unused otherwise).
+void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
+                       size_t n_blobs, hipStream_t st);
+
 // ---- setup (setup.hip)
 // 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check
 void launch_g1_decompress(const uint8_t *in48, G1Affine *out, int32_t *status, size_t n, int subgroup_check,

@@ -6,7 +6,7 @@ import random
 import pytest
 
 import blobs as B
-from conftest import R, TAU, hx, tau_closed_form
+from conftest import R, SETUP_PATH, TAU, hx, tau_closed_form
 
 pytestmark = pytest.mark.gpu
 
@@ -532,3 +532,89 @@ def test_noncanonical_infinity_commitment_takes_gpu_hash_fallback(K, gpu_setup, 
     c0 = K.blob_to_kzg_commitment(blob, gpu_setup)
     both = K.compute_blob_kzg_proof_batch(blob + blob, c0 + junk, gpu_setup)
     assert both[1] == got and oracle.compute_blob_kzg_proof(blob, c0, oracle_setup, oracle.MODE_R) == (0, both[0])
+
+
+# ---- opt-in direct (giant table) MSM: bit-identical to the default path --------------------------------------
+
+@pytest.fixture(scope="module", params=[14, 15, 16])
+def direct_setup(request, K, gpu_setup):
+    import torch
+    ts = K.TrustedSetup.from_file(SETUP_PATH)
+    assert ts.direct_table_bits() == 0
+    try:
+        ts.enable_direct_table(request.param)
+    except K.KzgError as e:
+        ts.free()
+        assert e.rc == K.C_KZG_MALLOC
+        pytest.skip("direct table of width %d does not fit on this device" % request.param)
+    assert ts.direct_table_bits() == request.param
+    yield ts, request.param
+    ts.enable_direct_table(0)
+    assert ts.direct_table_bits() == 0
+    # back on the default path the same object still answers
+    blob = B.synthetic_blob(77)
+    assert K.blob_to_kzg_commitment(blob, ts) == K.blob_to_kzg_commitment(blob, gpu_setup)
+    ts.free()
+    torch.cuda.empty_cache()
+
+
+def test_direct_table_bad_width(K, gpu_setup):
+    with pytest.raises(K.KzgError) as e:
+        gpu_setup.enable_direct_table(13)
+    assert e.value.rc == K.C_KZG_BADARGS
+    assert gpu_setup.direct_table_bits() == 0
+    assert K.lib().lwkzg_direct_num_windows(16) == 16 and K.lib().lwkzg_direct_num_windows(15) == 17
+    assert K.lib().lwkzg_direct_num_windows(14) == 19 and K.lib().lwkzg_direct_num_windows(13) == 0
+
+
+def test_direct_adversarial_digits_closed_form(K, direct_setup, oracle):
+    ts, c = direct_setup
+    nw = (255 + c - 1) // c
+    half = 1 << (c - 1)
+    boundary = sum(half << (c * j) for j in range(nw - 1))            # every signed window = 2^(c-1): last positive row
+    boundary1 = sum((half + 1) << (c * j) for j in range(nw - 1))     # every signed window negative, carries ripple up
+    ones = (1 << (c * (nw - 1))) - 1                                  # all-ones: digits -1 then 0,0,... with a final carry
+    sets = [[R - 1] * 4096,
+            [5, R - 5] * 2048,
+            [0] * 1234 + [R - 2] + [0] * 2861,
+            [0] * 4096,
+            [boundary % R] * 4096,
+            [boundary1 % R] * 4096,
+            [ones % R] * 4096,
+            [(1 << 254) + ones] * 4096 if (1 << 254) + ones < R else [(1 << 254)] * 4096,
+            [(1 << 247) | 1] * 4096,
+            list(range(1, 4097))]
+    blobs = [b"".join(s.to_bytes(32, "big") for s in ss) for ss in sets]
+    got = K.blob_to_kzg_commitment_batch(b"".join(blobs), ts)
+    for ss, g in zip(sets, got):
+        assert g == tau_closed_form(oracle, ss)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 200, 1024])
+def test_direct_commitments_match_default_path(K, direct_setup, gpu_setup, oracle, n):
+    """every launch geometry of the direct kernel (16 .. 1 workgroups per blob) against the bucket path"""
+    ts, _ = direct_setup
+    data = B.synthetic_batch(5000 + n, n)
+    want = K.blob_to_kzg_commitment_batch(data, gpu_setup)
+    got = K.blob_to_kzg_commitment_batch(data, ts)
+    assert got == want
+    blob0 = data[:B.BYTES_PER_BLOB]
+    assert got[0] == tau_closed_form(oracle, B.blob_scalars(blob0))
+
+
+def test_direct_proofs_both_modes_match_default_path(K, direct_setup, gpu_setup, oracle, oracle_setup):
+    ts, _ = direct_setup
+    rnd = random.Random(23)
+    for mode, be, omode in ((K.MODE_REFERENCE, True, oracle.MODE_R), (K.MODE_CKZG, False, oracle.MODE_C)):
+        K.set_mode(mode)
+        blobs = [B.synthetic_blob(900 + i, big_endian=be) for i in range(5)]
+        joined = b"".join(blobs)
+        comms = K.blob_to_kzg_commitment_batch(joined, ts)
+        assert comms == K.blob_to_kzg_commitment_batch(joined, gpu_setup)
+        proofs = K.compute_blob_kzg_proof_batch(joined, b"".join(comms), ts)
+        assert proofs == K.compute_blob_kzg_proof_batch(joined, b"".join(comms), gpu_setup)
+        assert oracle.compute_blob_kzg_proof(blobs[0], comms[0], oracle_setup, omode) == (0, proofs[0])
+        z = rnd.randrange(R).to_bytes(32, "big" if be else "little")
+        pr, y = K.compute_kzg_proof(blobs[1], z, ts)
+        assert oracle.compute_kzg_proof(blobs[1], z, oracle_setup, omode) == (0, pr, y)
+        assert K.verify_blob_kzg_proof_batch(joined, b"".join(comms), b"".join(proofs), 5, ts) is True
