@@ -348,15 +348,17 @@ static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode,
     }
 }
 
-static int split_ways() {
+// sub-batches per launch set. The bucket path gains from two (its sort / reduce / inversion tails hide behind the
+// other half's accumulation); the direct path has no such tails and runs as one launch.
+static int split_ways(bool direct) {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("LWKZG_SPLIT");
-        v = e ? atoi(e) : 2;
-        if (v < 1) v = 1;
+        v = e ? atoi(e) : 0;
+        if (v < 0) v = 0;
         if (v > kMaxSplit) v = kMaxSplit;
     }
-    return v;
+    return v ? v : (direct ? 1 : 2);
 }
 
 C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st) {
@@ -378,7 +380,7 @@ C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         int32_t *stt = status ? status + off : c->ws.status;
         LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
-        const int ways = m >= 256 ? split_ways() : 1;
+        const int ways = m >= 256 ? split_ways(c->direct_table != nullptr) : 1;
         if (ways == 1) {
             coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
             msm_stages(c, c->ws.scalars, out48 + 48 * off, m, st);
