@@ -227,8 +227,8 @@ def main():
         msms_per_launch = n / launches_per_step
         achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
-        # integer picture: a mixed add is 8 Montgomery products (392 v_mad_u64_u32 each on 14x29-bit limbs) and
-        # 2 squares (301 each); peak = v_mad_u64_u32 issue rate measured by tools/ubench.hip on MI355X
+        # integer picture: a mixed add is 6 Montgomery products (392 v_mad_u64_u32 each on 14x29-bit limbs), 2 squares
+        # (301 each) and one fused product pair a*b - c*d with a single reduction (588); peak = v_mad_u64_u32 issue rate measured by tools/ubench.hip on MI355X
         # (profiles/r01_ubench_instruction_rates.jsonl: 2.93e13 lane-mads/s at 8 waves/SIMD)
         if direct_bits:
             nwin = K.lib().lwkzg_direct_num_windows(direct_bits)
@@ -245,7 +245,7 @@ def main():
                       "frac": rows / (avg_ms * 1e-3) / GATHER_PEAK_ROWS,
                       "note": "the direct path really reads one random 112-byte table row per mixed addition from HBM "
                               "(table far larger than every cache); ceiling measured by tools/gather_bench.hip"}
-        mads_per_launch = msms_per_launch * adds_per_msm * (8 * 392 + 2 * 301)
+        mads_per_launch = msms_per_launch * adds_per_msm * (6 * 392 + 2 * 301 + 588)
         INT_MAD_PEAK = 2.93e13
         traffic = None
         try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size only

@@ -276,6 +276,7 @@ LWK_HD Fr operator*(const Fr &a, const Fr &b) { return fe_mul<FrParams>(a, b); }
 LWK_HD Fp sqr(const Fp &a) { return fe_sqr<FpParams>(a); }
 LWK_HD Fr sqr(const Fr &a) { return fe_sqr<FrParams>(a); }
 LWK_HD Fp neg(const Fp &a) { return fe_neg<FpParams>(a); }
+LWK_HD Fp mul_sub(const Fp &a, const Fp &b, const Fp &c, const Fp &d) { return a * b - c * d; }
 LWK_HD Fr neg(const Fr &a) { return fe_neg<FrParams>(a); }
 LWK_HD Fp dbl(const Fp &a) { return fe_dbl<FpParams>(a); }
 LWK_HD Fp inv(const Fp &a) { return fe_inv<FpParams>(a); }

@@ -96,7 +96,7 @@ LWK_HD X xyzz_dbl_affine(const QX &qx, const QY &qy) {
     X r;
     auto x3 = sqr(m) - dbl(s);
     r.x = x3;
-    r.y = m * (s - x3) - w * qy;
+    r.y = mul_sub(m, s - x3, w, qy);
     r.zz = v;
     r.zzz = w;
     return r;
@@ -115,7 +115,7 @@ LWK_HD X xyzz_dbl(const X &p) {
     X r;
     auto x3 = sqr(m) - dbl(s);
     r.x = x3;
-    r.y = m * (s - x3) - w * p.y;
+    r.y = mul_sub(m, s - x3, w, p.y);
     r.zz = v * p.zz;
     r.zzz = w * p.zzz;
     return r;
@@ -139,7 +139,7 @@ LWK_HD X xyzz_madd(const X &acc, const QX &qx, const QY &qy) {
     X r;
     auto x3 = sqr(rr) - ppp - dbl(qq);
     r.x = x3;
-    r.y = rr * (qq - x3) - acc.y * ppp;
+    r.y = mul_sub(rr, qq - x3, acc.y, ppp);
     r.zz = acc.zz * pp;
     r.zzz = acc.zzz * ppp;
     return r;
@@ -168,7 +168,7 @@ LWK_HD X xyzz_add(const X &a, const X &b) {
     X r;
     auto x3 = sqr(rr) - ppp - dbl(qq);
     r.x = x3;
-    r.y = rr * (qq - x3) - s1 * ppp;
+    r.y = mul_sub(rr, qq - x3, s1, ppp);
     r.zz = a.zz * b.zz * pp;
     r.zzz = a.zzz * b.zzz * ppp;
     return r;

@@ -1,9 +1,14 @@
-import sys, time
+"""Wall-clock of the host-pointer C ABI (PCIe included). LWKZG_DIRECT=16|15|14 enables the direct table first."""
+import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests/golden')
 import blobs as B
 import lambdaworks_kzg_amd as K
 ts = K.TrustedSetup.from_file('tests/golden/trusted_setup.txt')
-for n in (1, 16, 256):
+if os.environ.get('LWKZG_DIRECT'):
+    ts.reserve(256)
+    t = time.perf_counter(); ts.enable_direct_table(int(os.environ['LWKZG_DIRECT']))
+    print('direct table (%s bits) built in %.2f s' % (os.environ['LWKZG_DIRECT'], time.perf_counter() - t))
+for n in (1, 16, 256, 1024):
     data = B.synthetic_batch(0, n)
     K.blob_to_kzg_commitment_batch(data, ts)
     t = time.perf_counter(); comms = K.blob_to_kzg_commitment_batch(data, ts); tc = time.perf_counter() - t

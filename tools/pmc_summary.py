@@ -5,7 +5,7 @@ roofline.traffic.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    python tools/pmc_summary.py out/fetch_counter_collection.csv out/write_counter_collection.csv rNN [blobs_per_launch]
+    python tools/pmc_summary.py out/fetch_counter_collection.csv out/write_counter_collection.csv rNN [blobs_per_launch [direct_bits]]
 
 Units: the counters are in KiB. gfx950 correction (guide, section HBM): FETCH_SIZE tallies 128-byte
 requests at 64 bytes for wide coalesced streams, i.e. reads exactly half; for this kernel's per-lane
@@ -17,22 +17,25 @@ import collections
 import csv
 import json
 import os
+import re
 import sys
 
 
 def per_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0].replace("lwk::", "")
+        m = re.search(r"k_[a-z0-9_]+", r["Kernel_Name"])   # "void lwk::k_direct_accumulate<16>(...)" -> k_direct_accumulate
+        name = m.group(0) if m else r["Kernel_Name"]
         agg[name].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
 def main():
     fetch, write, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    blobs_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 512   # bench default: 1024 blobs per step in 2 launches
+    blobs_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 1024  # bench default: 1024 blobs per step, one launch (direct path)
+    direct_bits = int(sys.argv[5]) if len(sys.argv) > 5 else 16         # 0 = the passes ran with --direct-bits 0 (bucket path)
     f, w = per_kernel(fetch), per_kernel(write)
-    out = {"round": tag, "batch_blobs_per_launch": blobs_per_launch, "unit": "bytes per launch (average)", "kernels": {}}
+    out = {"round": tag, "batch_blobs_per_launch": blobs_per_launch, "direct_bits": direct_bits, "unit": "bytes per launch (average)", "kernels": {}}
     for k in sorted(set(f) | set(w)):
         if not k.startswith("k_"):
             continue
