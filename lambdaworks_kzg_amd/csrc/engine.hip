@@ -316,7 +316,7 @@ Ctx *ctx_of(const KZGSettings *s) {
 
 // `base` = first workspace slot (in blobs) this launch set may use: sub-batches running on different streams
 // work in disjoint slices of the same workspace.
-static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0) {
+static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0) {
     Workspace &w = c->ws;
     uint32_t *sorted = w.sorted + base * (size_t)kMaxEntries;
     uint32_t *bstart = w.bucket_start + base * (size_t)(kNumBuckets + 1);
@@ -325,13 +325,16 @@ static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size
     G1Xyzz29 *sums = w.sums + base;
     if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
         launch_direct_msm(c->direct_bits, c->direct_table, scalars_raw, buckets, sums, n, st);
-        launch_finalize_compress(sums, out48, n, st);
-        return;
+        return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
     launch_bucket_accumulate(c->table, sorted, bstart, perm, buckets, n, st);
     launch_bucket_reduce(buckets, sums, n, st);
-    launch_finalize_compress(sums, out48, n, st);
+    return sums;
+}
+
+static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0) {
+    launch_finalize_compress(msm_sums_stage(c, scalars_raw, n, st, base), out48, n, st);
 }
 
 // blob bytes -> canonical monomial coefficients in ws.scalars (slots base .. base + n)
@@ -1059,10 +1062,7 @@ C_KZG_RET lwkzg_g1_msm_tiled_device(void *out48_dev, const void *scalars_be_dev,
     for (size_t off = 0; off < tiles; off += kMaxChunk) {
         size_t m = tiles - off < kMaxChunk ? tiles - off : kMaxChunk;
         launch_parse_be_reduce((const uint8_t *)scalars_be_dev + off * (size_t)kBlobBytes, w.scalars, m * kBlobElems, st);
-        launch_digit_sort(w.scalars, w.sorted, w.bucket_start, w.perm, m, st);
-        launch_bucket_accumulate(c->table, w.sorted, w.bucket_start, w.perm, w.buckets, m, st);
-        launch_bucket_reduce(w.buckets, w.sums, m, st);
-        launch_sum_points(w.sums, m, total, off != 0, st);
+        launch_sum_points(msm_sums_stage(c, w.scalars, m, st), m, total, off != 0, st);
     }
     launch_finalize_compress(total, (uint8_t *)out48_dev, 1, st);
     return C_KZG_OK;

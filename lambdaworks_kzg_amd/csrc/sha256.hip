@@ -71,14 +71,25 @@ __device__ __forceinline__ uint4 challenge_chunk(int q, const uint4 *blob, const
     return make_uint4(0u, 0u, 0u, 0u);
 }
 
+// SHA-256 is sequential per message and a lane issues one instruction every ~4.5 cycles no matter how idle the chip
+// is, so the hash of a batch takes (instructions per lane) x 4.5 cycles however few blobs there are. The kernel
+// therefore splits the per-lane instruction stream over TWO cooperating waves per 64 blobs:
+//   wave 0 (producer): loads + byte-swaps the next 64-byte block, expands the 64-word message schedule, adds the
+//                      round constants, parks W[t] + K[t] in LDS (double-buffered, 16 KB per buffer);
+//   wave 1 (consumer): runs only the 64 rounds (14-15 instructions each) on the words it reads back as 16 x b128.
+// One barrier per block. 7.8 -> ~4 ms per batch.
+//
 // only_if_differs_from (optional): the fix-up pass of the optimistic pipeline -- z was already computed from
 // these (caller-supplied) commitment bytes while the validation kernel ran; lanes whose canonical bytes are
-// identical have nothing to redo and exit at once.
-__global__ __launch_bounds__(64) void k_challenge(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
-                                                  Fr *__restrict__ z_mont, int le, size_t n,
-                                                  const uint8_t *__restrict__ only_if_differs_from) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// identical have nothing to redo, and a workgroup without any lane left exits at once.
+__global__ __launch_bounds__(128) void k_challenge(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
+                                                   Fr *__restrict__ z_mont, int le, size_t n,
+                                                   const uint8_t *__restrict__ only_if_differs_from) {
+    __shared__ uint4 wk[2][16][64];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    size_t i = (size_t)blockIdx.x * 64 + lane;
+    bool active = i < n;
+    if (!active) i = n - 1;  // keeps every address valid; the result is dropped
     const uint4 *blob = (const uint4 *)(blobs + (size_t)kBlobBytes * i);
     const uint4 *comm = (const uint4 *)(canon48 + 48 * i);
     if (only_if_differs_from) {
@@ -89,19 +100,72 @@ __global__ __launch_bounds__(64) void k_challenge(const uint8_t *__restrict__ bl
             uint4 a = comm[k], b = raw[k];
             same = same && a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
         }
-        if (same) return;
+        active = active && !same;
     }
-    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    if (__ballot(active) == 0) return;  // both waves see the same 64 blobs: uniform across the workgroup
+
     constexpr int kBlocks = (2 + kBlobBytes / 16 + 3 + 3) / 4;  // 2050
-    for (int blk = 0; blk < kBlocks; blk++) {
-        uint32_t w[16];
+    uint32_t a = 0x6a09e667u, b = 0xbb67ae85u, c = 0x3c6ef372u, d = 0xa54ff53au, e = 0x510e527fu, f = 0x9b05688cu,
+             g = 0x1f83d9abu, hh = 0x5be0cd19u;
+    uint32_t h0 = a, h1 = b, h2 = c, h3 = d, h4 = e, h5 = f, h6 = g, h7 = hh;
+    uint4 nxt[4];
+    if (role == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            uint4 v = challenge_chunk(4 * blk + c, blob, comm);
-            w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
-        }
-        sha256_compress(h, w);
+        for (int q = 0; q < 4; q++) nxt[q] = challenge_chunk(q, blob, comm);
     }
+    for (int it = 0; it <= kBlocks; it++) {
+        if (role == 0) {
+            if (it < kBlocks) {
+                uint32_t w[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    w[4 * q] = nxt[q].x; w[4 * q + 1] = nxt[q].y; w[4 * q + 2] = nxt[q].z; w[4 * q + 3] = nxt[q].w;
+                }
+                if (it + 1 < kBlocks) {  // the next block's loads fly while this one is expanded
+#pragma unroll
+                    for (int q = 0; q < 4; q++) nxt[q] = challenge_chunk(4 * (it + 1) + q, blob, comm);
+                }
+                uint4(*dst)[64] = wk[it & 1];
+#pragma unroll
+                for (int t = 0; t < 64; t += 4) {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int r = t + u;
+                        if (r >= 16) {
+                            uint32_t w15 = w[(r - 15) & 15], w2 = w[(r - 2) & 15];
+                            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                            w[r & 15] = w[r & 15] + s0 + w[(r - 7) & 15] + s1;
+                        }
+                        o[u] = w[r & 15] + kShaK[r];
+                    }
+                    dst[t >> 2][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        } else if (it > 0) {
+            const uint4(*src)[64] = wk[(it - 1) & 1];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const uint4 v = src[q][lane];
+                const uint32_t wq[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+                    uint32_t ch = (e & f) ^ (~e & g);
+                    uint32_t t1 = hh + S1 + ch + wq[u];
+                    uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+                    uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+                    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+                }
+            }
+            h0 += a; h1 += b; h2 += c; h3 += d; h4 += e; h5 += f; h6 += g; h7 += hh;
+            a = h0; b = h1; c = h2; d = h3; e = h4; f = h5; g = h6; hh = h7;
+        }
+        __syncthreads();
+    }
+    if (role != 1 || !active) return;
+    const uint32_t h[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
     // digest bytes d[0..32) = big-endian h[0..8)
     uint32_t s[8];
     if (le) {
@@ -117,8 +181,9 @@ __global__ __launch_bounds__(64) void k_challenge(const uint8_t *__restrict__ bl
 
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from) {
+    if (n == 0) return;
     ProfScope p(only_if_differs_from ? "k_challenge_fixup" : "k_challenge", st);
-    hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blobs, canon48, z_mont, le, n,
+    hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st, blobs, canon48, z_mont, le, n,
                        only_if_differs_from);
 }
 

@@ -618,3 +618,27 @@ def test_direct_proofs_both_modes_match_default_path(K, direct_setup, gpu_setup,
         pr, y = K.compute_kzg_proof(blobs[1], z, ts)
         assert oracle.compute_kzg_proof(blobs[1], z, oracle_setup, omode) == (0, pr, y)
         assert K.verify_blob_kzg_proof_batch(joined, b"".join(comms), b"".join(proofs), 5, ts) is True
+
+
+def test_direct_tiled_long_msm(K, direct_setup, gpu_setup, oracle):
+    """2^18-term tiled MSM through the direct table == the bucket path == the closed form"""
+    import numpy as np
+    import torch
+    from lambdaworks_kzg_amd import capi
+    ts, _ = direct_setup
+    tiles = 64
+    data = B.synthetic_batch(7000, tiles)
+    d_sc = _dev(data)
+    d_out = torch.empty(48, dtype=torch.uint8, device="cuda")
+    capi.g1_msm_tiled_device(d_out.data_ptr(), d_sc.data_ptr(), tiles * 4096, ts)
+    torch.cuda.synchronize()
+    got = _host(d_out)
+    capi.g1_msm_tiled_device(d_out.data_ptr(), d_sc.data_ptr(), tiles * 4096, gpu_setup)
+    torch.cuda.synchronize()
+    assert _host(d_out) == got
+    pw = [pow(TAU, i, R) for i in range(4096)]
+    arr = np.frombuffer(data, dtype=np.uint8).reshape(tiles, 4096, 32)
+    acc = 0
+    for t in range(tiles):
+        acc = (acc + sum(s * p for s, p in zip(B.blob_scalars(arr[t].tobytes()), pw))) % R
+    assert got == oracle.g1_generator_mul(acc)
