@@ -169,6 +169,23 @@ hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *tabl
 
 constexpr int kDirThreads = 256;
 
+// 64 lanes -> lane 0, by shuffles (no LDS)
+__device__ __forceinline__ G1Xyzz29 wave_fold(G1Xyzz29 s, int lane) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        G1Xyzz29 other;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            other.x.l[k] = __shfl_down(s.x.l[k], d, 64);
+            other.y.l[k] = __shfl_down(s.y.l[k], d, 64);
+            other.zz.l[k] = __shfl_down(s.zz.l[k], d, 64);
+            other.zzz.l[k] = __shfl_down(s.zzz.l[k], d, 64);
+        }
+        if (lane < d) s = xyzz_add(s, other);
+    }
+    return s;
+}
+
+
 template <int C>
 __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
                                                                    const uint4 *__restrict__ scalars,
@@ -236,18 +253,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     }
 
     // fold: 64 lanes by shuffles, 4 waves through LDS
-    G1Xyzz29 s = *(G1Xyzz29 *)&acc;
-    for (int d = 32; d >= 1; d >>= 1) {
-        G1Xyzz29 other;
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-            other.x.l[k] = __shfl_down(s.x.l[k], d, 64);
-            other.y.l[k] = __shfl_down(s.y.l[k], d, 64);
-            other.zz.l[k] = __shfl_down(s.zz.l[k], d, 64);
-            other.zzz.l[k] = __shfl_down(s.zzz.l[k], d, 64);
-        }
-        if (lane < d) s = xyzz_add(s, other);
-    }
+    G1Xyzz29 s = wave_fold(*(G1Xyzz29 *)&acc, lane);
     if (lane == 0) wave_sum[wave] = s;
     __syncthreads();
     if (tid == 0) {
@@ -256,14 +262,15 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     }
 }
 
-// sums[blob] = sum of its per-block partial sums (only when a blob was spread over several workgroups)
+// sums[blob] = sum of its per-block partial sums (only when a blob was spread over several workgroups):
+// one wave per blob, a shuffle tree over the <= 64 partials
 __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__ partials, G1Xyzz29 *__restrict__ sums,
-                                                    int per_blob, size_t n_blobs) {
-    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blobs) return;
-    G1Xyzz29 s = partials[b * per_blob];
-    for (int k = 1; k < per_blob; k++) s = xyzz_add(s, partials[b * per_blob + k]);
-    sums[b] = s;
+                                                    int per_blob) {
+    const size_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    G1Xyzz29 s = lane < per_blob ? partials[b * per_blob + lane] : G1Xyzz29::infinity();
+    s = wave_fold(s, lane);
+    if (lane == 0) sums[b] = s;
 }
 
 template <int C>
@@ -282,8 +289,7 @@ static void launch_direct_t(const G1Affine29 *table, const uint32_t *scalars_raw
     }
     if (blocks_per_blob > 1) {
         ProfScope p("k_direct_fold", st);
-        hipLaunchKernelGGL(k_direct_fold, dim3((unsigned)((n_blobs + 63) / 64)), dim3(64), 0, st, partials, sums,
-                           blocks_per_blob, n_blobs);
+        hipLaunchKernelGGL(k_direct_fold, dim3((unsigned)n_blobs), dim3(64), 0, st, partials, sums, blocks_per_blob);
     }
 }
 
