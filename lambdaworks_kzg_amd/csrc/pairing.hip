@@ -13,6 +13,7 @@
 // anything upstream.
 #include "engine.h"
 #include "fp2.h"
+#include "hostfp.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -21,63 +22,68 @@ namespace lwk {
 
 namespace {
 
-inline Fp2 operator+(const Fp2 &a, const Fp2 &b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
-inline Fp2 operator-(const Fp2 &a, const Fp2 &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
-inline Fp2 operator*(const Fp2 &a, const Fp2 &b) {
-    Fp t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+// the tower over the host representation (hostfp.h); inputs arrive as Fe-based Fp / Fp2 and are repacked at entry
+struct H2 {
+    HFp c0, c1;
+};
+
+inline H2 operator+(const H2 &a, const H2 &b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+inline H2 operator-(const H2 &a, const H2 &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+inline H2 operator*(const H2 &a, const H2 &b) {
+    HFp t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
     return {t0 - t1, (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1};
 }
-inline Fp2 mul_fp(const Fp2 &a, const Fp &s) { return {a.c0 * s, a.c1 * s}; }
-inline Fp2 f2neg(const Fp2 &a) { return {neg(a.c0), neg(a.c1)}; }
-inline Fp2 f2zero() { return {Fp::zero(), Fp::zero()}; }
-inline Fp2 f2one() { return {Fp::one(), Fp::zero()}; }
-inline bool f2is_zero(const Fp2 &a) { return a.c0.is_zero() && a.c1.is_zero(); }
-inline bool f2eq(const Fp2 &a, const Fp2 &b) { return a.c0 == b.c0 && a.c1 == b.c1; }
-inline Fp2 mul_xi(const Fp2 &a) { return {a.c0 - a.c1, a.c0 + a.c1}; }  // * (1 + u)
-inline Fp2 f2inv(const Fp2 &a) {
-    Fp n = inv(sqr(a.c0) + sqr(a.c1));
+inline H2 mul_fp(const H2 &a, const HFp &s) { return {a.c0 * s, a.c1 * s}; }
+inline H2 f2neg(const H2 &a) { return {neg(a.c0), neg(a.c1)}; }
+inline H2 f2zero() { return {HFp::zero(), HFp::zero()}; }
+inline H2 f2one() { return {HFp::one(), HFp::zero()}; }
+inline bool f2is_zero(const H2 &a) { return a.c0.is_zero() && a.c1.is_zero(); }
+inline bool f2eq(const H2 &a, const H2 &b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+inline H2 mul_xi(const H2 &a) { return {a.c0 - a.c1, a.c0 + a.c1}; }  // * (1 + u)
+inline H2 f2inv(const H2 &a) {
+    HFp n = inv(sqr(a.c0) + sqr(a.c1));
     return {a.c0 * n, neg(a.c1 * n)};
 }
 
-struct Fp6 {
-    Fp2 c0, c1, c2;
+struct H6 {
+    H2 c0, c1, c2;
 };
-inline Fp6 operator+(const Fp6 &a, const Fp6 &b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
-inline Fp6 operator-(const Fp6 &a, const Fp6 &b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
-inline Fp6 operator*(const Fp6 &a, const Fp6 &b) {
-    Fp2 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1, t2 = a.c2 * b.c2;
-    Fp6 r;
+inline H6 operator+(const H6 &a, const H6 &b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+inline H6 operator-(const H6 &a, const H6 &b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
+inline H6 operator*(const H6 &a, const H6 &b) {
+    H2 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1, t2 = a.c2 * b.c2;
+    H6 r;
     r.c0 = t0 + mul_xi((a.c1 + a.c2) * (b.c1 + b.c2) - t1 - t2);
     r.c1 = (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1 + mul_xi(t2);
     r.c2 = (a.c0 + a.c2) * (b.c0 + b.c2) - t0 - t2 + t1;
     return r;
 }
-inline Fp6 f6neg(const Fp6 &a) { return {f2neg(a.c0), f2neg(a.c1), f2neg(a.c2)}; }
-inline Fp6 mul_v(const Fp6 &a) { return {mul_xi(a.c2), a.c0, a.c1}; }
-inline Fp6 f6zero() { return {f2zero(), f2zero(), f2zero()}; }
-inline Fp6 f6one() { return {f2one(), f2zero(), f2zero()}; }
-inline Fp6 f6inv(const Fp6 &a) {
-    Fp2 c0 = a.c0 * a.c0 - mul_xi(a.c1 * a.c2);
-    Fp2 c1 = mul_xi(a.c2 * a.c2) - a.c0 * a.c1;
-    Fp2 c2 = a.c1 * a.c1 - a.c0 * a.c2;
-    Fp2 t = f2inv(a.c0 * c0 + mul_xi(a.c2 * c1 + a.c1 * c2));
+inline H6 f6neg(const H6 &a) { return {f2neg(a.c0), f2neg(a.c1), f2neg(a.c2)}; }
+inline H6 mul_v(const H6 &a) { return {mul_xi(a.c2), a.c0, a.c1}; }
+inline H6 f6zero() { return {f2zero(), f2zero(), f2zero()}; }
+inline H6 f6one() { return {f2one(), f2zero(), f2zero()}; }
+inline H6 f6inv(const H6 &a) {
+    H2 c0 = a.c0 * a.c0 - mul_xi(a.c1 * a.c2);
+    H2 c1 = mul_xi(a.c2 * a.c2) - a.c0 * a.c1;
+    H2 c2 = a.c1 * a.c1 - a.c0 * a.c2;
+    H2 t = f2inv(a.c0 * c0 + mul_xi(a.c2 * c1 + a.c1 * c2));
     return {c0 * t, c1 * t, c2 * t};
 }
 
-struct Fp12 {
-    Fp6 c0, c1;
+struct H12 {
+    H6 c0, c1;
 };
-inline Fp12 operator*(const Fp12 &a, const Fp12 &b) {
-    Fp6 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+inline H12 operator*(const H12 &a, const H12 &b) {
+    H6 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
     return {t0 + mul_v(t1), (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1};
 }
-inline Fp12 f12one() { return {f6one(), f6zero()}; }
-inline Fp12 f12conj(const Fp12 &a) { return {a.c0, f6neg(a.c1)}; }
-inline Fp12 f12inv(const Fp12 &a) {
-    Fp6 t = f6inv(a.c0 * a.c0 - mul_v(a.c1 * a.c1));
+inline H12 f12one() { return {f6one(), f6zero()}; }
+inline H12 f12conj(const H12 &a) { return {a.c0, f6neg(a.c1)}; }
+inline H12 f12inv(const H12 &a) {
+    H6 t = f6inv(a.c0 * a.c0 - mul_v(a.c1 * a.c1));
     return {a.c0 * t, f6neg(a.c1 * t)};
 }
-inline bool f12is_one(const Fp12 &a) {
+inline bool f12is_one(const H12 &a) {
     return f2eq(a.c0.c0, f2one()) && f2is_zero(a.c0.c1) && f2is_zero(a.c0.c2) && f2is_zero(a.c1.c0) &&
            f2is_zero(a.c1.c1) && f2is_zero(a.c1.c2);
 }
@@ -150,8 +156,8 @@ T pow_big(const T &a, const T &one, const uint32_t *e, int n, MulF mul) {
 }
 
 struct Consts {
-    Fp2 gamma[6];      // xi^(k (p^2-1)/6), k = 0..5 (they lie in Fp)
-    Fp2 gamma1[6];     // xi^(k (p-1)/6), k = 0..5
+    H2 gamma[6];      // xi^(k (p^2-1)/6), k = 0..5 (they lie in HFp)
+    H2 gamma1[6];     // xi^(k (p-1)/6), k = 0..5
     uint32_t hard[48]; // (p^4 - p^2 + 1) / r
     int hard_n;
     bool ready = false;
@@ -187,9 +193,9 @@ void init_consts() {
     memcpy(e6n, p2, sizeof e6n);
     e6n[0] -= 1;  // p^2 is odd
     big_div(e6, e6n, 24, six, 1);
-    Fp2 xi = {Fp::one(), Fp::one()};
-    auto m2 = [](const Fp2 &a, const Fp2 &b) { return a * b; };
-    Fp2 g1 = pow_big<Fp2>(xi, f2one(), e6, 24, m2);
+    H2 xi = {HFp::one(), HFp::one()};
+    auto m2 = [](const H2 &a, const H2 &b) { return a * b; };
+    H2 g1 = pow_big<H2>(xi, f2one(), e6, 24, m2);
     g_c.gamma[0] = f2one();
     for (int k = 1; k < 6; k++) g_c.gamma[k] = g_c.gamma[k - 1] * g1;
     // e1 = (p - 1) / 6 for the p-power Frobenius
@@ -197,15 +203,15 @@ void init_consts() {
     memcpy(e1n, p, sizeof e1n);
     e1n[0] -= 1;
     big_div(e1, e1n, 12, six, 1);
-    Fp2 h1 = pow_big<Fp2>(xi, f2one(), e1, 12, m2);
+    H2 h1 = pow_big<H2>(xi, f2one(), e1, 12, m2);
     g_c.gamma1[0] = f2one();
     for (int k = 1; k < 6; k++) g_c.gamma1[k] = g_c.gamma1[k - 1] * h1;
     g_c.ready = true;
 }
 
-// a^(p^2): coefficient of v^i w^j (= w^(2i+j)) is scaled by gamma[2i+j]; Fp2 is fixed by x -> x^(p^2)
-Fp12 frob_p2(const Fp12 &a) {
-    Fp12 r;
+// a^(p^2): coefficient of v^i w^j (= w^(2i+j)) is scaled by gamma[2i+j]; H2 is fixed by x -> x^(p^2)
+H12 frob_p2(const H12 &a) {
+    H12 r;
     r.c0.c0 = a.c0.c0;
     r.c0.c1 = a.c0.c1 * g_c.gamma[2];
     r.c0.c2 = a.c0.c2 * g_c.gamma[4];
@@ -215,10 +221,10 @@ Fp12 frob_p2(const Fp12 &a) {
     return r;
 }
 
-// a^p: Fp2 coefficients are conjugated, the coefficient of w^(2i+j) is scaled by gamma1[2i+j]
-Fp12 frob_p(const Fp12 &a) {
-    auto cj = [](const Fp2 &c) { return Fp2{c.c0, neg(c.c1)}; };
-    Fp12 r;
+// a^p: H2 coefficients are conjugated, the coefficient of w^(2i+j) is scaled by gamma1[2i+j]
+H12 frob_p(const H12 &a) {
+    auto cj = [](const H2 &c) { return H2{c.c0, neg(c.c1)}; };
+    H12 r;
     r.c0.c0 = cj(a.c0.c0);
     r.c0.c1 = cj(a.c0.c1) * g_c.gamma1[2];
     r.c0.c2 = cj(a.c0.c2) * g_c.gamma1[4];
@@ -230,8 +236,8 @@ Fp12 frob_p(const Fp12 &a) {
 
 // a^x for the (negative) curve parameter x = -0xd201000000010000, a in the cyclotomic subgroup
 // (where the inverse is the conjugate)
-Fp12 exp_by_x(const Fp12 &a) {
-    Fp12 acc = a;  // bit 63
+H12 exp_by_x(const H12 &a) {
+    H12 acc = a;  // bit 63
     for (int i = 62; i >= 0; i--) {
         acc = acc * acc;
         if (i == 62 || i == 60 || i == 57 || i == 48 || i == 16) acc = acc * a;
@@ -244,35 +250,35 @@ Fp12 exp_by_x(const Fp12 &a) {
 // gives f^(3h) with five exponentiations by x. The result lies in the order-r subgroup and gcd(3, r) = 1,
 // so f^(3h) == 1 exactly when f^h == 1. LWKZG_PAIRING_NAIVE=1 switches to the plain 1268-bit exponentiation
 // (kept as the cross-check the x-chain was validated against).
-bool final_exponentiation_is_one(const Fp12 &f) {
-    Fp12 t = f12conj(f) * f12inv(f);  // f^(p^6 - 1)
+bool final_exponentiation_is_one(const H12 &f) {
+    H12 t = f12conj(f) * f12inv(f);  // f^(p^6 - 1)
     t = frob_p2(t) * t;               // ^(p^2 + 1)
     static int naive = -1;
     if (naive < 0) naive = getenv("LWKZG_PAIRING_NAIVE") ? 1 : 0;
     if (naive) {
-        auto m12 = [](const Fp12 &a, const Fp12 &b) { return a * b; };
-        return f12is_one(pow_big<Fp12>(t, f12one(), g_c.hard, g_c.hard_n, m12));
+        auto m12 = [](const H12 &a, const H12 &b) { return a * b; };
+        return f12is_one(pow_big<H12>(t, f12one(), g_c.hard, g_c.hard_n, m12));
     }
-    Fp12 t0 = exp_by_x(t) * f12conj(t);             // t^(x-1)
-    Fp12 t1 = exp_by_x(t0) * f12conj(t0);           // t^((x-1)^2)
-    Fp12 t2 = exp_by_x(t1) * frob_p(t1);            // ^(x+p)
-    Fp12 t3 = exp_by_x(exp_by_x(t2)) * frob_p2(t2) * f12conj(t2);  // ^(x^2+p^2-1)
+    H12 t0 = exp_by_x(t) * f12conj(t);             // t^(x-1)
+    H12 t1 = exp_by_x(t0) * f12conj(t0);           // t^((x-1)^2)
+    H12 t2 = exp_by_x(t1) * frob_p(t1);            // ^(x+p)
+    H12 t3 = exp_by_x(exp_by_x(t2)) * frob_p2(t2) * f12conj(t2);  // ^(x^2+p^2-1)
     return f12is_one(t3 * t * t * t);
 }
 
 struct G2A {
-    Fp2 x, y;
+    H2 x, y;
 };
 
 // line through T (tangent if double) evaluated at P, scaled by w^3 (killed by the final exponentiation):
 //   l = (lambda x_T - y_T) + (-lambda x_P) v + (y_P) v w
-Fp12 line(const Fp2 &lambda, const G2A &t, const Fp &xp, const Fp &yp) {
-    Fp12 l;
+H12 line(const H2 &lambda, const G2A &t, const HFp &xp, const HFp &yp) {
+    H12 l;
     l.c0.c0 = lambda * t.x - t.y;
     l.c0.c1 = f2neg(mul_fp(lambda, xp));
     l.c0.c2 = f2zero();
     l.c1.c0 = f2zero();
-    l.c1.c1 = {yp, Fp::zero()};
+    l.c1.c1 = {yp, HFp::zero()};
     l.c1.c2 = f2zero();
     return l;
 }
@@ -285,30 +291,33 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
     if (n == 0) return true;
     const u64 z = 0xd201000000010000ull;  // |z|, z < 0
     G2A t[4], q[4];
+    HFp px[4], py[4];
     if (n > 4) return false;
     for (int i = 0; i < n; i++) {
-        q[i] = {qx[i], qy[i]};
+        q[i] = {{HFp::from_fe(qx[i].c0), HFp::from_fe(qx[i].c1)}, {HFp::from_fe(qy[i].c0), HFp::from_fe(qy[i].c1)}};
         t[i] = q[i];
+        px[i] = HFp::from_fe(ps[i].x);
+        py[i] = HFp::from_fe(ps[i].y);
     }
-    Fp12 f = f12one();
+    H12 f = f12one();
     for (int bit = 62; bit >= 0; bit--) {
         f = f * f;
         for (int i = 0; i < n; i++) {
             // tangent: lambda = 3 x^2 / (2 y)
-            Fp2 xx = t[i].x * t[i].x;
-            Fp2 lambda = (xx + xx + xx) * f2inv(t[i].y + t[i].y);
-            f = f * line(lambda, t[i], ps[i].x, ps[i].y);
-            Fp2 x3 = lambda * lambda - t[i].x - t[i].x;
-            Fp2 y3 = lambda * (t[i].x - x3) - t[i].y;
+            H2 xx = t[i].x * t[i].x;
+            H2 lambda = (xx + xx + xx) * f2inv(t[i].y + t[i].y);
+            f = f * line(lambda, t[i], px[i], py[i]);
+            H2 x3 = lambda * lambda - t[i].x - t[i].x;
+            H2 y3 = lambda * (t[i].x - x3) - t[i].y;
             t[i] = {x3, y3};
         }
         if ((z >> bit) & 1) {
             for (int i = 0; i < n; i++) {
                 // chord through T and Q (T != +-Q for points of order r inside the loop)
-                Fp2 lambda = (t[i].y - q[i].y) * f2inv(t[i].x - q[i].x);
-                f = f * line(lambda, t[i], ps[i].x, ps[i].y);
-                Fp2 x3 = lambda * lambda - t[i].x - q[i].x;
-                Fp2 y3 = lambda * (t[i].x - x3) - t[i].y;
+                H2 lambda = (t[i].y - q[i].y) * f2inv(t[i].x - q[i].x);
+                f = f * line(lambda, t[i], px[i], py[i]);
+                H2 x3 = lambda * lambda - t[i].x - q[i].x;
+                H2 y3 = lambda * (t[i].x - x3) - t[i].y;
                 t[i] = {x3, y3};
             }
         }

@@ -31,6 +31,8 @@ int main() {
         f29_to_raw32(pr, a * i1);
         bool ok = true;
         for (int i = 0; i < 12; i++) ok &= r1[i] == r2[i] && pr[i] == ((i == 0 && k != 0) ? 1u : 0u);
+        Fp fa = f29_to_fp(a);
+        ok &= inv(fa) == inv_fermat(fa);   // the 12x32-bit representation's entry point (host pairing, setup kernels)
         if (!ok) { bad++; if (bad < 5) printf("mismatch at case %d\n", k); }
     }
     printf(bad ? "FAIL %d\n" : "ok 3000 inversions match Fermat\n", bad);
