@@ -44,6 +44,19 @@ struct Workspace {
     int32_t *status = nullptr;       // cap
 };
 
+// device-side scratch of one batch verification (points kept between its two GPU phases). The memory belongs to the
+// context (grow-only: hipMalloc / hipFree cost more than the kernels at small n); `hold` keeps other verifications
+// of the same settings object out until this one is done with it.
+struct VerifyBuffers {
+    G1Affine29 *pts_c = nullptr, *pts_p = nullptr;
+    int32_t *kind_c = nullptr, *kind_p = nullptr;
+    uint8_t *proof_in = nullptr;  // compressed proofs as uploaded (validated on an auxiliary stream)
+    uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
+    G1Xyzz29 *d_part = nullptr;
+    int32_t *d_inf = nullptr;
+    std::unique_lock<std::mutex> hold;
+};
+
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {
     FFTSettings fs;
@@ -58,6 +71,9 @@ struct Ctx {
     int direct_bits;           // 14 / 15 / 16 when direct_table is live, else 0
     Fr *tw_fwd, *tw_inv;
     Workspace ws;
+    VerifyBuffers vs;   // verify-side scratch, sized for vs_cap blobs
+    size_t vs_cap;
+    std::mutex verify_mu;
     std::mutex mu;
 };
 
@@ -75,12 +91,6 @@ C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const
 C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st);
 
 // verify-side helpers (host pointers in and out; GPU work inside; engine.hip)
-// device-side scratch of one batch verification (points kept between its two GPU phases)
-struct VerifyBuffers {
-    G1Affine29 *pts_c = nullptr, *pts_p = nullptr;
-    int32_t *kind_c = nullptr, *kind_p = nullptr;
-    ~VerifyBuffers();
-};
 C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
                               int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb);
 C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n,

@@ -152,11 +152,14 @@ C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
     return C_KZG_OK;
 }
 
+static void vs_free(Ctx *c);
+
 static void ctx_destroy(Ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     ws_free(c->ws);
+    vs_free(c);
     dev_free(c->points);
     dev_free(c->table);
     dev_free(c->direct_table);
@@ -205,6 +208,7 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->table = nullptr;
     c->direct_table = nullptr;
     c->direct_bits = 0;
+    c->vs_cap = 0;
     c->tw_fwd = c->tw_inv = nullptr;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
@@ -467,11 +471,45 @@ static C_KZG_RET first_status(Ctx *c, const int32_t *d_status, size_t n, hipStre
     return C_KZG_OK;
 }
 
-VerifyBuffers::~VerifyBuffers() {
-    if (pts_c) hipFree(pts_c);
-    if (pts_p) hipFree(pts_p);
-    if (kind_c) hipFree(kind_c);
-    if (kind_p) hipFree(kind_p);
+static void vs_free(Ctx *c) {
+    VerifyBuffers &v = c->vs;
+    dev_free(v.pts_c);
+    dev_free(v.pts_p);
+    dev_free(v.kind_c);
+    dev_free(v.kind_p);
+    dev_free(v.proof_in);
+    dev_free(v.d_r);
+    dev_free(v.d_rz);
+    dev_free(v.d_aff);
+    dev_free(v.d_part);
+    dev_free(v.d_inf);
+    c->vs_cap = 0;
+}
+
+// grow-only verify scratch for n blobs; the caller holds verify_mu
+static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
+    if (c->vs_cap >= n) return C_KZG_OK;
+    LWK_HIP(hipStreamSynchronize(c->stream));
+    vs_free(c);
+    size_t cap = 64;
+    while (cap < n) cap <<= 1;
+    VerifyBuffers &v = c->vs;
+    const size_t nblk = lincomb3_blocks(cap);
+    bool ok = hipMalloc((void **)&v.pts_c, cap * sizeof(G1Affine29)) == hipSuccess &&
+              hipMalloc((void **)&v.pts_p, cap * sizeof(G1Affine29)) == hipSuccess &&
+              hipMalloc((void **)&v.kind_c, cap * 4) == hipSuccess && hipMalloc((void **)&v.kind_p, cap * 4) == hipSuccess &&
+              hipMalloc((void **)&v.proof_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.d_r, cap * 32) == hipSuccess &&
+              hipMalloc((void **)&v.d_rz, cap * 32) == hipSuccess &&
+              hipMalloc((void **)&v.d_part, (3 * nblk + 3) * sizeof(G1Xyzz29)) == hipSuccess &&
+              hipMalloc((void **)&v.d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&v.d_inf, 3 * 4) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        vs_free(c);
+        set_error("verify scratch for %zu blobs: out of device memory", cap);
+        return C_KZG_MALLOC;
+    }
+    c->vs_cap = cap;
+    return C_KZG_OK;
 }
 
 // Everything per blob of a batch verification, in one pass over the blobs: validate C_i and pi_i (keeping the
@@ -480,16 +518,18 @@ VerifyBuffers::~VerifyBuffers() {
 // memory here); the GPU hash is the fallback for non-canonical commitment encodings.
 C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
                               int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb) {
+    vb.hold = std::unique_lock<std::mutex>(c->verify_mu);  // released when the caller's VerifyBuffers goes away
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     const int le = mode == LWKZG_MODE_CKZG;
     const int bad = le ? kStatusBadArgs : kStatusError;
     hipStream_t st = c->stream;
-    LWK_HIP(hipMalloc((void **)&vb.pts_c, n * sizeof(G1Affine29)));
-    LWK_HIP(hipMalloc((void **)&vb.kind_c, n * 4));
-    if (proofs48) {
-        LWK_HIP(hipMalloc((void **)&vb.pts_p, n * sizeof(G1Affine29)));
-        LWK_HIP(hipMalloc((void **)&vb.kind_p, n * 4));
+    {
+        C_KZG_RET rcv = vs_reserve(c, n);
+        if (rcv != C_KZG_OK) return rcv;
+        const VerifyBuffers &v = c->vs;
+        vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
+        vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
     }
     std::vector<uint8_t> dig(32 * (n < kMaxChunk ? n : kMaxChunk));
     for (size_t off = 0; off < n; off += kMaxChunk) {
@@ -501,14 +541,21 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemcpyAsync(w.comm48, hc, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
+        if (proofs48) {
+            // the proofs' validation (a 2 ms latency-shaped kernel) runs beside the commitments' on an auxiliary stream;
+            // both only ever write the same failure code into status
+            hipStream_t sa = c->aux[0];
+            LWK_HIP(hipEventRecord(c->ev_fork, st));
+            LWK_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+            LWK_HIP(hipMemcpyAsync(vb.proof_in + 48 * off, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, sa));
+            launch_validate_commitments(vb.proof_in + 48 * off, w.out48, w.status, bad, m, sa, vb.pts_p + off, vb.kind_p + off);
+            LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, sa));
+            LWK_HIP(hipEventRecord(c->ev_join[0], sa));
+        }
         launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
         LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
-        if (proofs48) {
-            LWK_HIP(hipMemcpyAsync(w.comm48, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, st));
-            launch_validate_commitments(w.comm48, w.out48, w.status, bad, m, st, vb.pts_p + off, vb.kind_p + off);
-            LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, st));
-        }
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
+        if (proofs48) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         challenge_digests_host(dig.data(), hb, hc, m);
         LWK_HIP(hipStreamSynchronize(st));
         if (memcmp(canon_c + 48 * off, hc, m * 48) == 0) {
@@ -533,15 +580,17 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const size_t nblk = (n + 255) / 256;
-    uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
-    G1Xyzz29 *d_part = nullptr;
-    int32_t *d_inf = nullptr;
+    const size_t nblk = lincomb3_blocks(n);
+    if (!vb.hold.owns_lock() || !vb.d_r) {
+        set_error("lincomb3_device_host: called without a prepared verification");
+        return C_KZG_ERROR;
+    }
+    uint8_t *d_r = vb.d_r, *d_rz = vb.d_rz, *d_aff = vb.d_aff;
+    G1Xyzz29 *d_part = vb.d_part;
+    int32_t *d_inf = vb.d_inf;
     uint8_t h_aff[3 * 96];
     int32_t h_inf[3];
-    bool ok = hipMalloc((void **)&d_r, 32 * n) == hipSuccess && hipMalloc((void **)&d_rz, 32 * n) == hipSuccess &&
-              hipMalloc((void **)&d_part, (3 * nblk + 3) * sizeof(G1Xyzz29)) == hipSuccess &&
-              hipMalloc((void **)&d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&d_inf, 3 * 4) == hipSuccess;
+    bool ok = true;
     if (ok) ok = hipMemcpyAsync(d_r, sc_r, 32 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
                  hipMemcpyAsync(d_rz, sc_rz, 32 * n, hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok) {
@@ -553,11 +602,6 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
              hipMemcpyAsync(h_inf, d_inf, sizeof h_inf, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
     }
-    if (d_r) hipFree(d_r);
-    if (d_rz) hipFree(d_rz);
-    if (d_part) hipFree(d_part);
-    if (d_aff) hipFree(d_aff);
-    if (d_inf) hipFree(d_inf);
     if (!ok) {
         set_error("lincomb3_device_host: device work failed: %s", hipGetErrorString(hipGetLastError()));
         return C_KZG_ERROR;

@@ -86,6 +86,7 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
 // verify side: three variable-base linear combinations in one launch (setup.hip).
 //   set 0 = sum r_i P_i, set 1 = sum rz_i P_i (P = proofs), set 2 = sum r_i C_i (C = commitments);
 // per-block partial sums to partial[set * nblk + block]
+size_t lincomb3_blocks(size_t n);  // workgroups (= partial sums) per set
 void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *comms, const int32_t *comm_kind,
                      const uint8_t *sc_r_be, const uint8_t *sc_rz_be, G1Xyzz29 *partial, size_t n, hipStream_t st);
 void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);

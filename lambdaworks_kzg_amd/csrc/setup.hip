@@ -115,10 +115,45 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine *__restrict__
 }
 
 constexpr int kLincombThreads = 256;
+constexpr int kLincombTerms = kLincombThreads / 2;  // two lanes per term (endomorphism split)
+
+// k = lo + hi * z^2 with z^2 = 0xac45a4010001a4020000000100000000 (the curve parameter squared, 128 bits);
+// k < r = z^4 - z^2 + 1, so both halves fit 128 bits. Bitwise restoring division, once per lane.
+__device__ __forceinline__ void split_by_z2(uint32_t lo[4], uint32_t hi[4], const uint32_t k[8]) {
+    const uint32_t d[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};
+    uint32_t rem[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) hi[i] = 0;
+    for (int bit = 255; bit >= 0; bit--) {
+        const uint32_t top = rem[3] >> 31;
+        rem[3] = (rem[3] << 1) | (rem[2] >> 31);
+        rem[2] = (rem[2] << 1) | (rem[1] >> 31);
+        rem[1] = (rem[1] << 1) | (rem[0] >> 31);
+        rem[0] = (rem[0] << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
+        uint32_t t[4];
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint64_t v = (uint64_t)rem[i] - d[i] - br;
+            t[i] = (uint32_t)v;
+            br = (v >> 32) & 1u;
+        }
+        if (top || !br) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) rem[i] = t[i];
+            if (bit < 128) hi[bit >> 5] |= 1u << (bit & 31);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) lo[i] = rem[i];
+}
 
 // The three linear combinations of verify_kzg_proof_batch (/root/reference/src/lib.rs:679-685) in ONE launch, on points
-// the validation kernel already decompressed into the hot-loop representation: one lane per term does a
-// 255-bit double-and-add, the workgroup sums its 256 results in LDS.
+// the validation kernel already decompressed into the hot-loop representation. A 255-bit double-and-add is a serial
+// chain of ~383 group operations on one lane, so the chain is halved with the curve endomorphism phi(x, y) = (beta x, y),
+// which acts on G1 as multiplication by -z^2:  [k]P = [lo]P + [hi](-phi(P)),  k = lo + hi z^2.  Two lanes per term, a
+// 128-bit double-and-add each (field products inlined: no call boundaries on the chain), then the workgroup sums
+// its 256 results in LDS.
 __global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *__restrict__ proofs,
                                                               const int32_t *__restrict__ proof_kind,
                                                               const G1Affine29 *__restrict__ comms,
@@ -126,22 +161,37 @@ __global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *
                                                               const uint8_t *__restrict__ sc_r, const uint8_t *__restrict__ sc_rz,
                                                               G1Xyzz29 *__restrict__ partial, size_t n) {
     __shared__ G1Xyzz29 sh[kLincombThreads];
-    const int tid = threadIdx.x, set = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * kLincombThreads + tid;
+    const int tid = threadIdx.x, set = blockIdx.y, half = tid & 1;
+    const size_t i = (size_t)blockIdx.x * kLincombTerms + (tid >> 1);
     const G1Affine29 *pts = set == 2 ? comms : proofs;
     const int32_t *kind = set == 2 ? comm_kind : proof_kind;
     const uint8_t *sc = set == 1 ? sc_rz : sc_r;
-    G1Xyzz29 acc = G1Xyzz29::infinity();
+    G1Xyzz29i acc = G1Xyzz29i::infinity();
     if (i < n && kind[i] == 0) {
-        G1Affine29 p = pts[i];
-        uint32_t k[8];
+        G1Affine29i p = ((const G1Affine29i *)pts)[i];
+        uint32_t k[8], lo[4], hi[4];
         raw_from_be<8>(k, sc + 32 * i);
-        for (int bit = 255; bit >= 0; bit--) {
+        split_by_z2(lo, hi, k);
+        if (half) {  // -phi(P) = (beta x, -y)
+            uint32_t braw[12];
+            g1_beta_raw(braw);
+            const F29<2> b = f29_from_raw32(braw);
+            F29<2, true> bi;
+#pragma unroll
+            for (int q = 0; q < 14; q++) bi.l[q] = b.l[q];
+            p.x = p.x * bi;
+            p.y = neg(p.y) * F29<1, true>::one();  // back to the < 2p form the affine slots carry
+#pragma unroll
+            for (int q = 0; q < 4; q++) lo[q] = hi[q];
+        }
+        int bit = 127;
+        while (bit >= 0 && !((lo[bit >> 5] >> (bit & 31)) & 1)) bit--;  // leading zeros: nothing to double yet
+        for (; bit >= 0; bit--) {
             acc = xyzz_dbl(acc);
-            if ((k[bit >> 5] >> (bit & 31)) & 1) acc = xyzz_madd(acc, p.x, p.y);
+            if ((lo[bit >> 5] >> (bit & 31)) & 1) acc = xyzz_madd(acc, p.x, p.y);
         }
     }
-    sh[tid] = acc;
+    sh[tid] = *(G1Xyzz29 *)&acc;
     __syncthreads();
     for (int d = kLincombThreads / 2; d >= 1; d >>= 1) {
         if (tid < d) sh[tid] = xyzz_add(sh[tid], sh[tid + d]);
@@ -150,10 +200,12 @@ __global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *
     if (tid == 0) partial[(size_t)set * gridDim.x + blockIdx.x] = sh[0];
 }
 
+size_t lincomb3_blocks(size_t n) { return (n + kLincombTerms - 1) / kLincombTerms; }
+
 void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *comms, const int32_t *comm_kind,
                      const uint8_t *sc_r_be, const uint8_t *sc_rz_be, G1Xyzz29 *partial, size_t n, hipStream_t st) {
     ProfScope p("k_lincomb3", st);
-    unsigned grid = (unsigned)((n + kLincombThreads - 1) / kLincombThreads);
+    unsigned grid = (unsigned)lincomb3_blocks(n);
     hipLaunchKernelGGL(k_lincomb3, dim3(grid, 3), dim3(kLincombThreads), 0, st, proofs, proof_kind, comms, comm_kind,
                        sc_r_be, sc_rz_be, partial, n);
 }

@@ -9,6 +9,7 @@
 // The reference checks  e(C - [y]G, G2) * e(-pi, [tau]G2 - [z]G2) == 1  (KZG::verify). By bilinearity
 // that is  e(C - [y]G + [z]pi, G2) * e(-pi, [tau]G2) == 1, which needs no G2 arithmetic: the same
 // accept/reject bit with G2 and [tau]G2 taken straight from the setup.
+#include <chrono>
 #include "engine.h"
 #include "fp2.h"
 
@@ -197,6 +198,12 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     if (!ctx) return C_KZG_ERROR;
     const bool le = mode == LWKZG_MODE_CKZG;
 
+    static const bool timing = getenv("LWKZG_TIMING") != nullptr;  // phase wall-clock to stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     std::vector<uint8_t> zs(32 * n), ys(32 * n), canon_c(48 * n), canon_p(48 * n);
     // per blob on the GPU: validate C_i and pi_i (decompress + subgroup check + canonical recompression; the
     // decompressed points stay on the device), z_i = challenge(blob_i, C_i), y_i = p_i(z_i)
@@ -206,6 +213,7 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
                                        canon_p.data(), vb);
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
 
+    const auto t1 = now();
     // r (utils.rs:166-206). z and y enter in the mode's byte order, as to_bytes_be / c-kzg's bytes_from_bls_field do
     std::vector<uint8_t> msg(32 + n * 160);
     memcpy(msg.data(), "RCKZGBATCH___V1_", 16);
@@ -243,6 +251,7 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         ysum = ysum + rp * yf;
         rp = rp * rf;
     }
+    const auto t2 = now();
     // three variable-base linear combinations on the GPU (g1_lincomb, lib.rs:679-685)
     uint8_t sums[3][96];
     int infs[3];
@@ -258,6 +267,7 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         a.y = fe_from_raw<FpParams>(raw);
         return G1Xyzz::from_affine(a.x, a.y);
     };
+    const auto t3 = now();
     G1Xyzz proof_lincomb = load(0), proof_z_lincomb = load(1), c_lincomb = load(2);
     HostPoint g;
     if (!setup_generator(g, s)) return C_KZG_ERROR;
@@ -265,7 +275,12 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     fe_to_raw<FrParams>(ys_raw, ysum);
     G1Xyzz rhs = xyzz_add(c_lincomb, xyzz_neg(scalar_mul(to_xyzz(g), ys_raw)));
     rhs = xyzz_add(rhs, proof_z_lincomb);
-    return pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
+    rc = pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
+    if (timing)
+        fprintf(stderr, "[lambdaworks_kzg_amd] verify batch n=%zu: prepare (H2D, validate, challenge, evaluate) %.2f ms, "
+                        "r powers %.2f ms, lincomb3 %.2f ms, pairing side %.2f ms\n",
+                n, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    return rc;
 }
 
 // sum of compressed points on the host (gathering the per-GPU partial sums of a sharded long MSM: SURVEY 8e,
