@@ -267,7 +267,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery, integer)",
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
-            "config": {"workload": "BASELINE configs[1]: single-GPU G1 Pippenger MSM, 4096 scalars, batch=%d synthetic blobs "
+            "config": {"workload": "BASELINE configs[1]: single-GPU 4096-scalar G1 MSM (blob -> commitment), batch=%d synthetic blobs "
                                    "per GPU per step, device-resident, bit-exact vs CPU" % n,
                        "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},

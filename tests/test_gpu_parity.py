@@ -299,6 +299,10 @@ def test_setup_image_export_import_roundtrip(K, gpu_setup, oracle):
     assert ts2.g2_values_bytes() == gpu_setup.g2_values_bytes()
     blob = B.synthetic_blob(9)
     assert K.blob_to_kzg_commitment(blob, ts2) == tau_closed_form(oracle, B.blob_scalars(blob))
+    # what every rank > 0 of the multi-GPU bench does: build its own direct table from the imported points
+    ts2.enable_direct_table(14)
+    data = B.synthetic_batch(40, 5)
+    assert K.blob_to_kzg_commitment_batch(data, ts2) == K.blob_to_kzg_commitment_batch(data, gpu_setup)
     ts2.free()
 
 
