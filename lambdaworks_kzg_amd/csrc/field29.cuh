@@ -451,7 +451,7 @@ LWK_HD F29<2> f29_pow(const F29<B> &a, const uint32_t *e) {
     return acc;
 }
 
-// Fermat inversion a^(p-2): ~480 dependent products. Kept as the cross-check of f29_inv (tools/inv_check.hip).
+// Fermat inversion a^(p-2): ~480 dependent products. Kept as the cross-check of f29_inv (tools/host_check.hip).
 template <int B>
 LWK_HD F29<2> f29_inv_fermat(const F29<B> &a) {
     uint32_t e[12], two[12];

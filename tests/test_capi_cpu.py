@@ -114,3 +114,18 @@ def test_host_fiat_shamir_digests_match_hashlib(K):
     for b, c, g in zip(blobs, comms, got):
         msg = b"FSBLOBVERIFY_V1_" + (4096).to_bytes(8, "little") + (0).to_bytes(8, "little") + b + c
         assert g == hashlib.sha256(msg).digest()
+
+
+def test_product_arithmetic_host_crosscheck(tmp_path):
+    """The kernels' own field / group sources (LWK_HD), compiled for the host: division-step inversion vs Fermat,
+    29-bit-limb lazy field vs the 32-bit CIOS field, hot-loop XYZZ scalar multiplication vs the CIOS one
+    (tools/host_check.hip). No GPU, no oracle: the product checked against itself along independent routes."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "host_check")
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--cuda-host-only", "-I", os.path.join(ROOT, "lambdaworks_kzg_amd", "csrc"),
+                           os.path.join(ROOT, "tools", "host_check.hip"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert out.startswith("ok:"), out
