@@ -12,7 +12,7 @@ import json
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblambdaworks_kzg.so")
+LIB_PATH = os.environ.get("LWKZG_LIBRARY") or os.path.join(_HERE, "lib", "liblambdaworks_kzg.so")  # override: A/B builds
 
 C_KZG_OK, C_KZG_BADARGS, C_KZG_ERROR, C_KZG_MALLOC = 0, 1, 2, 3
 MODE_REFERENCE, MODE_CKZG = 0, 1

@@ -169,10 +169,12 @@ hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *tabl
 
 constexpr int kDirThreads = 256;
 
-// 64 lanes -> lane 0, by shuffles (no LDS)
-__device__ __forceinline__ G1Xyzz29 wave_fold(G1Xyzz29 s, int lane) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        G1Xyzz29 other;
+// 64 lanes -> lane 0, by shuffles (no LDS). The six additions are a serial chain that every workgroup ends with, and
+// for a handful of blobs they ARE the run time: field products inlined here as in the accumulate loop.
+__device__ __forceinline__ G1Xyzz29 wave_fold(const G1Xyzz29 &in, int lane, int width = 64) {
+    G1Xyzz29i s = *(const G1Xyzz29i *)&in;
+    for (int d = width / 2; d >= 1; d >>= 1) {
+        G1Xyzz29i other;
 #pragma unroll
         for (int k = 0; k < 14; k++) {
             other.x.l[k] = __shfl_down(s.x.l[k], d, 64);
@@ -182,9 +184,8 @@ __device__ __forceinline__ G1Xyzz29 wave_fold(G1Xyzz29 s, int lane) {
         }
         if (lane < d) s = xyzz_add(s, other);
     }
-    return s;
+    return *(G1Xyzz29 *)&s;
 }
-
 
 template <int C>
 __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
@@ -199,6 +200,10 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     const int first = blockIdx.x * kDirThreads + tid;
     const uint4 *sc = scalars + blob * (size_t)kBlobElems * 2;
     const G1Affine29i *tab = (const G1Affine29i *)table;
+    // tiny batches also split the windows of a scalar over gridDim.z workgroups; the signed-digit carry chain is
+    // still walked from window 0 (a few integer ops per window), only the gathers and additions are confined
+    const int wper = (P::NW + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int w_lo = (int)blockIdx.z * wper, w_hi = w_lo + wper;
 
     int q = 0, j = 0;
     uint32_t carry = 0, point = 0;
@@ -230,7 +235,8 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
                 j = 0;
                 q++;
             }
-            if (mag) {
+            const int jw = (j == 0 ? P::NW : j) - 1;  // the window this digit belongs to (j was advanced above)
+            if (mag && jw >= w_lo && jw < w_hi) {
                 valid = true;
                 neg = ng;
                 row = tab[idx];
@@ -256,9 +262,10 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     G1Xyzz29 s = wave_fold(*(G1Xyzz29 *)&acc, lane);
     if (lane == 0) wave_sum[wave] = s;
     __syncthreads();
-    if (tid == 0) {
-        for (int w2 = 1; w2 < kDirThreads / 64; w2++) s = xyzz_add(s, wave_sum[w2]);
-        partials[blob * gridDim.x + blockIdx.x] = s;
+    if (wave == 0) {  // the four wave sums: two more shuffle levels on the first wave
+        G1Xyzz29 t = lane < kDirThreads / 64 ? wave_sum[lane] : G1Xyzz29::infinity();
+        t = wave_fold(t, lane, kDirThreads / 64);
+        if (lane == 0) partials[(blob * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = t;
     }
 }
 
@@ -279,17 +286,19 @@ static void launch_direct_t(const G1Affine29 *table, const uint32_t *scalars_raw
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
     // 16 workgroups so the chip fills and the dependent chain per lane stays short
     static const int kFill = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 512;
-    int blocks_per_blob = 1;
+    int blocks_per_blob = 1, wsplit = 1;
     while (blocks_per_blob < 16 && n_blobs * blocks_per_blob < (size_t)kFill) blocks_per_blob <<= 1;
+    while (wsplit < 4 && n_blobs * blocks_per_blob * wsplit * 8 <= (size_t)kFill) wsplit <<= 1;  // only for a handful of blobs
     const int scalars_per_lane = kBlobElems / (kDirThreads * blocks_per_blob);
+    const int parts = blocks_per_blob * wsplit;
     {
         ProfScope p("k_direct_accumulate", st);
-        hipLaunchKernelGGL(k_direct_accumulate<C>, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(kDirThreads), 0, st, table,
-                           (const uint4 *)scalars_raw, blocks_per_blob == 1 ? sums : partials, scalars_per_lane);
+        hipLaunchKernelGGL(k_direct_accumulate<C>, dim3(blocks_per_blob, (unsigned)n_blobs, wsplit), dim3(kDirThreads), 0, st,
+                           table, (const uint4 *)scalars_raw, parts == 1 ? sums : partials, scalars_per_lane);
     }
-    if (blocks_per_blob > 1) {
+    if (parts > 1) {
         ProfScope p("k_direct_fold", st);
-        hipLaunchKernelGGL(k_direct_fold, dim3((unsigned)n_blobs), dim3(64), 0, st, partials, sums, blocks_per_blob);
+        hipLaunchKernelGGL(k_direct_fold, dim3((unsigned)n_blobs), dim3(64), 0, st, partials, sums, parts);
     }
 }
 
