@@ -167,7 +167,10 @@ hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *tabl
 // (signed C-bit digits, top window unsigned), gathers the row while the previous mixed addition runs, and keeps
 // its partial sum in VGPRs; the workgroup folds its 256 partial sums by wave shuffles + one LDS hop.
 
-constexpr int kDirThreads = 256;
+#ifndef LWK_DIR_THREADS
+#define LWK_DIR_THREADS 256
+#endif
+constexpr int kDirThreads = LWK_DIR_THREADS;
 
 // 64 lanes -> lane 0, by shuffles (no LDS). The six additions are a serial chain that every workgroup ends with, and
 // for a handful of blobs they ARE the run time: field products inlined here as in the accumulate loop.
