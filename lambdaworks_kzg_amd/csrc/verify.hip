@@ -12,6 +12,7 @@
 #include <chrono>
 #include "engine.h"
 #include "fp2.h"
+#include "hostfp.h"
 
 #include <string.h>
 
@@ -35,6 +36,9 @@ Fp fp_from_blst(const blst_fp &v) {
     return fe_from_raw<FpParams>(raw);
 }
 
+// host-side G1 arithmetic runs on the 64-bit-limb field of hostfp.h through g1.cuh's generic formulas
+typedef XyzzT<HFp, HFp, HFp> HXyzz;
+
 struct HostPoint {
     G1Affine a;
     bool inf;
@@ -47,20 +51,33 @@ bool host_g1_decompress(HostPoint &out, const uint8_t in[48]) {
     int rc = g1_decompress_nocheck(out.a, in);
     if (rc == 2) return false;
     out.inf = rc == 1;
-    if (!out.inf && !g1_in_subgroup(out.a)) return false;
-    return true;
+    if (out.inf) return true;
+    uint32_t braw[12];
+    g1_beta_raw(braw);
+    return g1_in_subgroup_endo<HXyzz>(HFp::from_fe(out.a.x), HFp::from_fe(out.a.y), HFp::from_fe(fe_from_raw<FpParams>(braw)));
 }
 
-G1Xyzz to_xyzz(const HostPoint &p) { return p.inf ? G1Xyzz::infinity() : G1Xyzz::from_affine(p.a.x, p.a.y); }
+HXyzz to_xyzz(const HostPoint &p) {
+    return p.inf ? HXyzz::infinity() : HXyzz::from_affine(HFp::from_fe(p.a.x), HFp::from_fe(p.a.y));
+}
 
-G1Xyzz xyzz_neg(const G1Xyzz &p) {
-    G1Xyzz r = p;
+// requires !p.is_inf(); back to the representation the pairing entry point and the device share
+G1Affine h_to_affine(const HXyzz &p) {
+    HFp i = inv(p.zz * p.zzz);
+    G1Affine r;
+    r.x = (p.x * (i * p.zzz)).to_fe();
+    r.y = (p.y * (i * p.zz)).to_fe();
+    return r;
+}
+
+HXyzz xyzz_neg(const HXyzz &p) {
+    HXyzz r = p;
     r.y = neg(p.y);
     return r;
 }
 
-G1Xyzz scalar_mul(const G1Xyzz &p, const uint32_t k[8]) {
-    G1Xyzz acc = G1Xyzz::infinity();
+HXyzz scalar_mul(const HXyzz &p, const uint32_t k[8]) {
+    HXyzz acc = HXyzz::infinity();
     for (int i = 255; i >= 0; i--) {
         acc = xyzz_dbl(acc);
         if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_add(acc, p);
@@ -83,7 +100,7 @@ bool fr_from_bytes(uint32_t raw[8], const uint8_t b[32], int mode) {
 }
 
 // e(lhs, G2) * e(-rhs_point, [tau]G2) == 1 with the G2 points of the settings
-C_KZG_RET pairing_verdict(bool *ok, const G1Xyzz &lhs, const G1Xyzz &pi, const KZGSettings *s) {
+C_KZG_RET pairing_verdict(bool *ok, const HXyzz &lhs, const HXyzz &pi, const KZGSettings *s) {
     if (!s->g2_values) {
         set_error("KZGSettings.g2_values is NULL");
         return C_KZG_ERROR;
@@ -93,13 +110,13 @@ C_KZG_RET pairing_verdict(bool *ok, const G1Xyzz &lhs, const G1Xyzz &pi, const K
     int m = 0;
     const g2_t *g2 = s->g2_values;
     if (!lhs.is_inf()) {
-        ps[m] = xyzz_to_affine(lhs);
+        ps[m] = h_to_affine(lhs);
         qx[m] = {fp_from_blst(g2[0].x.fp[0]), fp_from_blst(g2[0].x.fp[1])};
         qy[m] = {fp_from_blst(g2[0].y.fp[0]), fp_from_blst(g2[0].y.fp[1])};
         m++;
     }
     if (!pi.is_inf()) {
-        ps[m] = xyzz_to_affine(xyzz_neg(pi));
+        ps[m] = h_to_affine(xyzz_neg(pi));
         qx[m] = {fp_from_blst(g2[1].x.fp[0]), fp_from_blst(g2[1].x.fp[1])};
         qy[m] = {fp_from_blst(g2[1].y.fp[0]), fp_from_blst(g2[1].y.fp[1])};
         m++;
@@ -124,7 +141,7 @@ C_KZG_RET verify_core(bool *ok, const HostPoint &c, const uint32_t z[8], const u
         set_error("g1_values[0] is not a curve point");
         return C_KZG_ERROR;
     }
-    G1Xyzz lhs = to_xyzz(c);
+    HXyzz lhs = to_xyzz(c);
     lhs = xyzz_add(lhs, xyzz_neg(scalar_mul(to_xyzz(g), y)));  // C - [y]G
     lhs = xyzz_add(lhs, scalar_mul(to_xyzz(pi), z));            //   + [z]pi
     return pairing_verdict(ok, lhs, to_xyzz(pi), s);
@@ -258,22 +275,22 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     rc = lincomb3_device_host(ctx, vb, sc_r.data(), sc_rz.data(), n, sums, infs);
     if (rc != C_KZG_OK) return C_KZG_ERROR;
     auto load = [&](int k) {
-        if (infs[k]) return G1Xyzz::infinity();
+        if (infs[k]) return HXyzz::infinity();
         uint32_t raw[12];
         G1Affine a;
         raw_from_be<12>(raw, sums[k]);
         a.x = fe_from_raw<FpParams>(raw);
         raw_from_be<12>(raw, sums[k] + 48);
         a.y = fe_from_raw<FpParams>(raw);
-        return G1Xyzz::from_affine(a.x, a.y);
+        return HXyzz::from_affine(HFp::from_fe(a.x), HFp::from_fe(a.y));
     };
     const auto t3 = now();
-    G1Xyzz proof_lincomb = load(0), proof_z_lincomb = load(1), c_lincomb = load(2);
+    HXyzz proof_lincomb = load(0), proof_z_lincomb = load(1), c_lincomb = load(2);
     HostPoint g;
     if (!setup_generator(g, s)) return C_KZG_ERROR;
     uint32_t ys_raw[8];
     fe_to_raw<FrParams>(ys_raw, ysum);
-    G1Xyzz rhs = xyzz_add(c_lincomb, xyzz_neg(scalar_mul(to_xyzz(g), ys_raw)));
+    HXyzz rhs = xyzz_add(c_lincomb, xyzz_neg(scalar_mul(to_xyzz(g), ys_raw)));
     rhs = xyzz_add(rhs, proof_z_lincomb);
     rc = pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
     if (timing)
