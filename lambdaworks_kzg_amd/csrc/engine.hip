@@ -517,7 +517,8 @@ static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
 // The Fiat-Shamir digests are computed by host threads while the GPU validates and parses (the blobs are host
 // memory here); the GPU hash is the fallback for non-canonical commitment encodings.
 C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
-                              int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb) {
+                              int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb,
+                              const uint8_t *trusted_canon_c) {
     vb.hold = std::unique_lock<std::mutex>(c->verify_mu);  // released when the caller's VerifyBuffers goes away
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
@@ -552,8 +553,15 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, sa));
             LWK_HIP(hipEventRecord(c->ev_join[0], sa));
         }
-        launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
-        LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        if (trusted_canon_c) {
+            // the caller decompressed (and so validated) the commitments itself and hands over their canonical bytes:
+            // no 2 ms validation kernel on the single-blob path
+            memcpy(canon_c + 48 * off, trusted_canon_c + 48 * off, m * 48);
+            hc = trusted_canon_c + 48 * off;
+        } else {
+            launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
+            LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        }
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
         if (proofs48) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         challenge_digests_host(dig.data(), hb, hc, m);

@@ -180,21 +180,25 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     const int mode = g_mode_now();
     if (!blob || !commitment_bytes || !proof_bytes || !s) return bad(mode);
     HostPoint c, pi;
-    if (mode == LWKZG_MODE_REFERENCE) {
-        // lib.rs:473-478: both points are decompressed before the blob is parsed
-        if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return C_KZG_ERROR; }
-        if (!host_g1_decompress(pi, proof_bytes->bytes)) { set_error("invalid proof"); return C_KZG_ERROR; }
+    // lib.rs:473-478: both points are decompressed before the blob is parsed (in c-kzg every failure of this function
+    // is BADARGS, so the order is not observable there). Decompressing here also validates: the per-blob GPU pass
+    // below is told the commitment's canonical bytes instead of re-deriving them with a validation kernel.
+    if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return bad(mode); }
+    if (!host_g1_decompress(pi, proof_bytes->bytes)) { set_error("invalid proof"); return bad(mode); }
+    uint8_t canon_in[48];
+    if (c.inf) {
+        memset(canon_in, 0, 48);
+        canon_in[0] = 0xc0;
+    } else {
+        g1_compress_affine(canon_in, c.a);
     }
     Ctx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
     uint8_t zb[32], yb[32], canon[48];
     VerifyBuffers vb;
-    C_KZG_RET rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb);
+    C_KZG_RET rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb,
+                                       canon_in);
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
-    if (mode == LWKZG_MODE_CKZG) {
-        if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return C_KZG_BADARGS; }
-        if (!host_g1_decompress(pi, proof_bytes->bytes)) { set_error("invalid proof"); return C_KZG_BADARGS; }
-    }
     uint32_t z[8], y[8];
     if (!fr_from_bytes(z, zb, mode) || !fr_from_bytes(y, yb, mode)) return C_KZG_ERROR;
     return verify_core(ok, c, z, y, pi, s);
