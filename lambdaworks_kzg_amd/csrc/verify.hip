@@ -153,6 +153,20 @@ C_KZG_RET bad(int mode) { return mode == LWKZG_MODE_CKZG ? C_KZG_BADARGS : C_KZG
 }  // namespace
 }  // namespace lwk
 
+namespace lwk {
+int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48]) {
+    HostPoint p;
+    memset(canon48, 0, 48);
+    if (!host_g1_decompress(p, in48)) return 2;
+    if (p.inf) {
+        canon48[0] = 0xc0;
+        return 1;
+    }
+    g1_compress_affine(canon48, p.a);
+    return 0;
+}
+}  // namespace lwk
+
 using namespace lwk;
 
 extern "C" {
