@@ -177,6 +177,11 @@ def main():
         ts.enable_direct_table(int(args.direct_bits))
         direct_bits = int(args.direct_bits)
     t_table = time.perf_counter() - t_tab0
+    direct_bits_min = direct_bits
+    if world > 1:   # every rank should have got the same width; report it if one did not
+        tb = torch.tensor([direct_bits], dtype=torch.int32, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.MIN)
+        direct_bits_min = int(tb.item())
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -269,7 +274,7 @@ def main():
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
             "config": {"workload": "BASELINE configs[1]: single-GPU 4096-scalar G1 MSM (blob -> commitment), batch=%d synthetic blobs "
                                    "per GPU per step, device-resident, bit-exact vs CPU" % n,
-                       "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
+                       "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

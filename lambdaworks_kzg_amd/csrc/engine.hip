@@ -153,6 +153,7 @@ C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
 }
 
 static void vs_free(Ctx *c);
+void direct_from_env(const KZGSettings *s);
 
 static void ctx_destroy(Ctx *c) {
     if (!c) return;
@@ -749,6 +750,7 @@ static C_KZG_RET setup_from_bytes(KZGSettings *out, const uint8_t *g1_bytes, con
     out->fs = &c->fs;
     out->g1_values = g1v;
     out->g2_values = g2v;
+    direct_from_env(out);
     return C_KZG_OK;
 }
 
@@ -1221,7 +1223,24 @@ C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev) {
     out->fs = &c->fs;
     out->g1_values = g1v;
     out->g2_values = g2v;
+    direct_from_env(out);
     return C_KZG_OK;
 }
 
 }  // extern "C"
+
+namespace lwk {
+// LWKZG_DIRECT_BITS = 14 | 15 | 16 | auto: a consumer that only knows the reference's nine symbols opts in to the
+// direct table from its environment; every load then tries to enable it (auto: the widest that fits) and quietly
+// stays on the default engine when it does not fit.
+void direct_from_env(const KZGSettings *s) {
+    const char *v = getenv("LWKZG_DIRECT_BITS");
+    if (!v || !*v) return;
+    if (!strcmp(v, "auto")) {
+        for (int bits = 16; bits >= 14; bits--)
+            if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
+        return;
+    }
+    (void)lwkzg_enable_direct_table(s, atoi(v));
+}
+}  // namespace lwk

@@ -646,3 +646,4 @@ def test_direct_tiled_long_msm(K, direct_setup, gpu_setup, oracle):
     for t in range(tiles):
         acc = (acc + sum(s * p for s, p in zip(B.blob_scalars(arr[t].tobytes()), pw))) % R
     assert got == oracle.g1_generator_mul(acc)
+
