@@ -936,10 +936,10 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         LWK_HIP(hipMemcpyAsync(w.comm48, h_comm, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
         // Validate the commitments (lib.rs:372-375): a long serial scalar multiplication per point whose verdict and
-        // canonical bytes are only needed at the very end. A handful of points: on this thread while the GPU works
+        // canonical bytes are only needed at the very end. Up to 64 points: on the host threads while the GPU works
         // (~0.2 ms each on the 64-bit host field, against a 2 ms latency-shaped kernel). A batch: on the GPU, on an
         // auxiliary stream beside everything else.
-        const bool host_validate = m <= 8;
+        const bool host_validate = m <= 64;
         std::vector<int32_t> h_code(m, le ? kStatusBadArgs : kStatusError);
         if (!host_validate) {
             LWK_HIP(hipEventRecord(c->ev_fork, st));
@@ -950,12 +950,13 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         }
         // GPU, main stream: parse the blobs, then the digests as soon as the host threads have them
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
-        if (host_validate) {
-            for (size_t i = 0; i < m; i++)
-                if (host_validate_commitment(h_comm + 48 * i, &h_canon[48 * i]) == 2)
-                    LWK_HIP(hipMemcpyAsync(w.status + i, &h_code[i], 4, hipMemcpyHostToDevice, st));
-        }
         hasher.join();
+        if (host_validate) {  // after the hashing: both want every host thread
+            std::vector<int> vrc(m);
+            host_validate_commitments(h_comm, h_canon.data(), vrc.data(), m);
+            for (size_t i = 0; i < m; i++)
+                if (vrc[i] == 2) LWK_HIP(hipMemcpyAsync(w.status + i, &h_code[i], 4, hipMemcpyHostToDevice, st));
+        }
         LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
         launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);

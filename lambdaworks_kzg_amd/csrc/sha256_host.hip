@@ -124,6 +124,9 @@ void challenge_digest(uint8_t out[32], const uint8_t *blob, const uint8_t *comm4
     }
 }
 
+}  // namespace
+
+// hardware threads this process may really use (shared with the host-side validation of verify.hip)
 unsigned host_threads() {
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
@@ -141,7 +144,6 @@ unsigned host_threads() {
     return n > 32 ? 32 : n;
 }
 
-}  // namespace
 
 // digests[i] = SHA-256(header | blobs[i] | comms[i]) for i < n, spread over the host threads
 void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n) {
