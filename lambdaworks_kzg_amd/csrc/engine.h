@@ -99,8 +99,8 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
 
 // host-side decompress_g1_point + subgroup check + recompression (verify.hip): 0 = affine, 1 = infinity, 2 = invalid
 // (canon48 zeroed); for the few-points paths where a 2 ms validation kernel is the wrong tool
-int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48]);
-void host_validate_commitments(const uint8_t *in48, uint8_t *canon48, int *rc, size_t n);  // on the host threads
+int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48], G1Affine29 *aff = nullptr);
+void host_validate_commitments(const uint8_t *in48, uint8_t *canon48, int *rc, size_t n, G1Affine29 *aff = nullptr);  // on the host threads
 
 // G2 / pairing side (g2_pairing.hip, host only)
 bool g2_fill_values(g2_t *out65, const uint8_t *g2_bytes, size_t n2);

@@ -543,7 +543,10 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemcpyAsync(w.comm48, hc, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
-        if (proofs48) {
+        // up to 64 blobs: both point sets are validated on the host threads (0.2 ms per point per thread against a 2 ms
+        // latency-shaped kernel) and the decompressed points uploaded in the form the kernel would have left
+        const bool host_validate = !trusted_canon_c && n <= 64;
+        if (proofs48 && !host_validate) {
             // the proofs' validation (a 2 ms latency-shaped kernel) runs beside the commitments' on an auxiliary stream;
             // both only ever write the same failure code into status
             hipStream_t sa = c->aux[0];
@@ -554,23 +557,44 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, sa));
             LWK_HIP(hipEventRecord(c->ev_join[0], sa));
         }
+        coefficients_stage(c, w.blobs, m, mode, w.status, st);
         if (trusted_canon_c) {
             // the caller decompressed (and so validated) the commitments itself and hands over their canonical bytes:
             // no 2 ms validation kernel on the single-blob path
             memcpy(canon_c + 48 * off, trusted_canon_c + 48 * off, m * 48);
             hc = trusted_canon_c + 48 * off;
-        } else {
+        } else if (!host_validate) {
             launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
             LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
         }
-        coefficients_stage(c, w.blobs, m, mode, w.status, st);
-        if (proofs48) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        std::vector<int32_t> h_code(m, bad), h_kind;
+        std::vector<G1Affine29> h_aff;
+        if (host_validate) {
+            const size_t np = proofs48 ? 2 * m : m;
+            std::vector<int> vrc(np);
+            h_aff.resize(np);
+            h_kind.resize(np);
+            host_validate_commitments(hc, canon_c + 48 * off, vrc.data(), m, h_aff.data());
+            if (proofs48) host_validate_commitments(proofs48 + 48 * off, canon_p + 48 * off, vrc.data() + m, m, h_aff.data() + m);
+            for (size_t i = 0; i < np; i++) {
+                h_kind[i] = vrc[i];
+                if (vrc[i] == 2) LWK_HIP(hipMemcpyAsync(w.status + (i % m), &h_code[i % m], 4, hipMemcpyHostToDevice, st));
+            }
+            LWK_HIP(hipMemcpyAsync(vb.pts_c + off, h_aff.data(), m * sizeof(G1Affine29), hipMemcpyHostToDevice, st));
+            LWK_HIP(hipMemcpyAsync(vb.kind_c + off, h_kind.data(), m * 4, hipMemcpyHostToDevice, st));
+            if (proofs48) {
+                LWK_HIP(hipMemcpyAsync(vb.pts_p + off, h_aff.data() + m, m * sizeof(G1Affine29), hipMemcpyHostToDevice, st));
+                LWK_HIP(hipMemcpyAsync(vb.kind_p + off, h_kind.data() + m, m * 4, hipMemcpyHostToDevice, st));
+            }
+        }
+        if (proofs48 && !host_validate) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         challenge_digests_host(dig.data(), hb, hc, m);
         LWK_HIP(hipStreamSynchronize(st));
         if (memcmp(canon_c + 48 * off, hc, m * 48) == 0) {
             LWK_HIP(hipMemcpyAsync(w.zbytes, dig.data(), m * 32, hipMemcpyHostToDevice, st));
             launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);
         } else {
+            if (host_validate) LWK_HIP(hipMemcpyAsync(w.canon48, canon_c + 48 * off, m * 48, hipMemcpyHostToDevice, st));
             launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
         }
         launch_eval_quotient(w.scalars, w.z, w.scalars2, w.ybytes, le, m, st);

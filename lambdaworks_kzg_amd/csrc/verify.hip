@@ -157,30 +157,36 @@ C_KZG_RET bad(int mode) { return mode == LWKZG_MODE_CKZG ? C_KZG_BADARGS : C_KZG
 namespace lwk {
 unsigned host_threads();  // sha256_host.hip: hardware threads capped by the cgroup quota
 
-int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48]) {
+int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48], G1Affine29 *aff) {
     HostPoint p;
     memset(canon48, 0, 48);
+    if (aff) {
+        aff->x = F29<2>::zero();
+        aff->y = F29<2>::zero();
+    }
     if (!host_g1_decompress(p, in48)) return 2;
     if (p.inf) {
         canon48[0] = 0xc0;
         return 1;
     }
     g1_compress_affine(canon48, p.a);
+    if (aff) *aff = affine_to_29(p.a);  // what k_validate_commitments leaves on the device for the linear combinations
     return 0;
 }
 
 // the same for n points, spread over the host threads (~0.2 ms per point per thread)
-void host_validate_commitments(const uint8_t *in48, uint8_t *canon48, int *rc, size_t n) {
+void host_validate_commitments(const uint8_t *in48, uint8_t *canon48, int *rc, size_t n, G1Affine29 *aff) {
     unsigned nt = host_threads();
     if (nt > n) nt = (unsigned)n;
+    auto one = [=](size_t i) { rc[i] = host_validate_commitment(in48 + 48 * i, canon48 + 48 * i, aff ? aff + i : nullptr); };
     if (nt <= 1) {
-        for (size_t i = 0; i < n; i++) rc[i] = host_validate_commitment(in48 + 48 * i, canon48 + 48 * i);
+        for (size_t i = 0; i < n; i++) one(i);
         return;
     }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)
         th.emplace_back([=]() {
-            for (size_t i = t; i < n; i += nt) rc[i] = host_validate_commitment(in48 + 48 * i, canon48 + 48 * i);
+            for (size_t i = t; i < n; i += nt) one(i);
         });
     for (auto &x : th) x.join();
 }
