@@ -129,3 +129,17 @@ def test_product_arithmetic_host_crosscheck(tmp_path):
                            os.path.join(ROOT, "tools", "host_check.hip"), "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert out.startswith("ok:"), out
+
+
+def test_direct_table_plan_constants(K):
+    """window plan of the opt-in direct table: pure host arithmetic, callable without a GPU"""
+    from lambdaworks_kzg_amd import capi
+    l = K.lib()
+    assert [l.lwkzg_direct_num_windows(b) for b in (13, 14, 15, 16, 17)] == [0, 19, 17, 16, 0]
+    # 15 signed windows of 2^15 rows + one 15-bit top window of 2^15 rows, per point, 112 bytes per row
+    assert capi.direct_table_bytes(16) == (15 * 4096 * 32768 + 4096 * 32768) * 112 == 240518168576
+    assert capi.direct_table_bytes(15) == (16 * 4096 * 16384 + 4096 * 32768) * 112
+    assert capi.direct_table_bytes(14) == (18 * 4096 * 8192 + 4096 * 8) * 112
+    for bits in (14, 15, 16):   # every scalar bit is covered exactly once: (NW - 1) * bits + top == 255
+        nw = l.lwkzg_direct_num_windows(bits)
+        assert 0 < 255 - bits * (nw - 1) <= bits
