@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BLOBS_PER_GPU, help="blobs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof"])
+    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof", "verify_batch"],
+                    help="commit = the headline (BASELINE configs[1]); blob_proof = configs[2]; verify_batch = configs[3], host-pointer ABI")
     ap.add_argument("--mode", default="reference", choices=["reference", "ckzg"],
                     help="reference = lambdaworks_kzg semantics (default, the headline); ckzg = c-kzg-4844 semantics (adds the inverse NTT)")
     ap.add_argument("--direct-bits", default="auto",
@@ -184,8 +185,12 @@ def main():
         direct_bits_min = int(tb.item())
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    h_blobs = h_comms = h_proofs = None
+
     def step():
-        if args.op == "commit":
+        if args.op == "verify_batch":   # each rank verifies its shard as an independent batch, one all_reduce of the verdict
+            assert D.verify_blob_kzg_proof_batch_sharded(h_blobs, h_comms, h_proofs, n, ts)
+        elif args.op == "commit":
             K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
         else:
             K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, stream,
@@ -195,6 +200,11 @@ def main():
         d_comm = torch.empty(48 * n, dtype=torch.uint8, device=dev)
         K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
         torch.cuda.synchronize(dev)
+
+    if args.op == "verify_batch":      # inputs of the host-pointer ABI: blobs, commitments and proofs in host memory
+        h_blobs = host.tobytes()
+        h_comms = b"".join(K.blob_to_kzg_commitment_batch(h_blobs, ts))
+        h_proofs = b"".join(K.compute_blob_kzg_proof_batch(h_blobs, h_comms, ts))
 
     for _ in range(args.warmup):
         step()
@@ -224,6 +234,8 @@ def main():
         total_blobs = n * world * args.steps
         value = total_blobs / elapsed
         dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
+        if args.op == "verify_batch":   # no MSM here: the longest kernel of the per-blob pass is the one priced
+            dom = max(prof, key=lambda kk: prof[kk]["total_ms"]) if prof else dom
         k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
         avg_ms = k["total_ms"] / max(1, k["launches"])
         # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
@@ -260,7 +272,9 @@ def main():
         except Exception:
             traffic = None
         res = {
-            "metric": "blob_to_kzg_commitment ops/sec (4096-elem blobs)" if args.op == "commit" else "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
+            "metric": {"commit": "blob_to_kzg_commitment ops/sec (4096-elem blobs)",
+                       "blob_proof": "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
+                       "verify_batch": "verify_blob_kzg_proof_batch blobs/sec (4096-elem blobs, host-pointer ABI, PCIe included)"}[args.op],
             "value": value,
             "unit": "ops/s",
             "n_gpus": world,
@@ -272,8 +286,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery, integer)",
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
-            "config": {"workload": "BASELINE configs[1]: single-GPU 4096-scalar G1 MSM (blob -> commitment), batch=%d synthetic blobs "
-                                   "per GPU per step, device-resident, bit-exact vs CPU" % n,
+            "config": {"workload": {"commit": "BASELINE configs[1]: single-GPU 4096-scalar G1 MSM (blob -> commitment), batch=%d synthetic blobs "
+                                             "per GPU per step, device-resident, bit-exact vs CPU",
+                                   "blob_proof": "BASELINE configs[2]: compute_blob_kzg_proof (Fiat-Shamir hash, quotient, MSM), batch=%d synthetic "
+                                                 "blobs per GPU per step, device-resident",
+                                   "verify_batch": "BASELINE configs[3]: verify_blob_kzg_proof_batch, %d synthetic blobs per GPU per step verified as "
+                                                   "one batch per GPU, blobs in host memory (H2D inside the timed region)"}[args.op] % n,
                        "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
