@@ -244,7 +244,7 @@ def main():
         msms_per_launch = n / launches_per_step
         achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
-        # integer picture: a mixed add is 6 Montgomery products (392 v_mad_u64_u32 each on 14x29-bit limbs), 2 squares
+        # integer picture: a mixed add is 6 Montgomery products (392 v_mad_u64_u32 each on 14 limbs of 28 bits), 2 squares
         # (301 each) and one fused product pair a*b - c*d with a single reduction (588); peak = v_mad_u64_u32 issue rate measured by tools/ubench.hip on MI355X
         # (profiles/r01_ubench_instruction_rates.jsonl: 2.93e13 lane-mads/s at 8 waves/SIMD)
         if direct_bits:

@@ -1206,7 +1206,7 @@ C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void 
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     uint8_t *img = (uint8_t *)image_dev;
-    uint64_t hdr[8] = {kCtxMagic, kImgBytes, (uint64_t)kWindowBits, (uint64_t)kNumWindows, 0, 0, 0, 0};
+    uint64_t hdr[8] = {kCtxMagic, kImgBytes, (uint64_t)kWindowBits, (uint64_t)kNumWindows, (uint64_t)P29::W, 0, 0, 0};
     LWK_HIP(hipMemcpyAsync(img, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
     LWK_HIP(hipMemcpyAsync(img + kImgHdr, s->g1_values, kImgG1, hipMemcpyHostToDevice, st));
     LWK_HIP(hipMemsetAsync(img + kImgHdr + kImgG1, 0, kImgG2, st));
@@ -1229,7 +1229,8 @@ C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev) {
     g1_t *g1v = (g1_t *)malloc(kImgG1);
     g2_t *g2v = (g2_t *)malloc((size_t)TRUSTED_SETUP_NUM_G2_POINTS * 288);
     bool ok = g1v && g2v && hipMemcpy(hdr, img, sizeof hdr, hipMemcpyDeviceToHost) == hipSuccess;
-    if (ok && (hdr[0] != kCtxMagic || hdr[1] != kImgBytes || hdr[2] != (uint64_t)kWindowBits || hdr[3] != (uint64_t)kNumWindows)) {
+    if (ok && (hdr[0] != kCtxMagic || hdr[1] != kImgBytes || hdr[2] != (uint64_t)kWindowBits || hdr[3] != (uint64_t)kNumWindows ||
+               hdr[4] != (uint64_t)P29::W)) {  // the table's limb width is part of the format
         set_error("setup image header mismatch (different build or not an image)");
         ok = false;
     }

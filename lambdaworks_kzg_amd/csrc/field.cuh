@@ -277,6 +277,7 @@ LWK_HD Fp sqr(const Fp &a) { return fe_sqr<FpParams>(a); }
 LWK_HD Fr sqr(const Fr &a) { return fe_sqr<FrParams>(a); }
 LWK_HD Fp neg(const Fp &a) { return fe_neg<FpParams>(a); }
 LWK_HD Fp mul_sub(const Fp &a, const Fp &b, const Fp &c, const Fp &d) { return a * b - c * d; }
+LWK_HD Fp normed(const Fp &a) { return a; }  // the lazy field's renormalisation point (field29.cuh); nothing to do here
 LWK_HD Fr neg(const Fr &a) { return fe_neg<FrParams>(a); }
 LWK_HD Fp dbl(const Fp &a) { return fe_dbl<FpParams>(a); }
 // ---- inversion by division steps (Bernstein-Yang "safegcd", 30 steps per batch on 13 signed 30-bit limbs) -------

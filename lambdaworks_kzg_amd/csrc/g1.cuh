@@ -19,7 +19,7 @@
 namespace lwk {
 
 // ---- representation-generic point types -----------------------------------------------------------
-// Two instantiations: saturated Fp (host, setup kernels) and the lazy 29-bit-limb F29<B> of
+// Two instantiations: saturated Fp (host, setup kernels) and the lazy 28-bit-limb F29<B> of
 // field29.cuh (MSM hot loop), whose value bounds (multiples of p) are part of the member types below
 // and are re-derived by the compiler through every formula (`auto` temporaries).
 
@@ -94,7 +94,7 @@ LWK_HD X xyzz_dbl_affine(const QX &qx, const QY &qy) {
     auto xx = sqr(qx);
     auto m = dbl(xx) + xx;
     X r;
-    auto x3 = sqr(m) - dbl(s);
+    auto x3 = normed(sqr(m) - dbl(s));  // a long lazy chain ends here (a no-op with 29-bit limbs)
     r.x = x3;
     r.y = mul_sub(m, s - x3, w, qy);
     r.zz = v;
@@ -113,7 +113,7 @@ LWK_HD X xyzz_dbl(const X &p) {
     auto xx = sqr(p.x);
     auto m = dbl(xx) + xx;
     X r;
-    auto x3 = sqr(m) - dbl(s);
+    auto x3 = normed(sqr(m) - dbl(s));  // a long lazy chain ends here (a no-op with 29-bit limbs)
     r.x = x3;
     r.y = mul_sub(m, s - x3, w, p.y);
     r.zz = v * p.zz;
@@ -137,7 +137,7 @@ LWK_HD X xyzz_madd(const X &acc, const QX &qx, const QY &qy) {
     auto ppp = pp_ * pp;
     auto qq = acc.x * pp;
     X r;
-    auto x3 = sqr(rr) - ppp - dbl(qq);
+    auto x3 = normed(sqr(rr) - ppp - dbl(qq));  // a long lazy chain ends here (a no-op with 29-bit limbs)
     r.x = x3;
     r.y = mul_sub(rr, qq - x3, acc.y, ppp);
     r.zz = acc.zz * pp;
@@ -166,7 +166,7 @@ LWK_HD X xyzz_add(const X &a, const X &b) {
     auto ppp = pp_ * pp;
     auto qq = u1 * pp;
     X r;
-    auto x3 = sqr(rr) - ppp - dbl(qq);
+    auto x3 = normed(sqr(rr) - ppp - dbl(qq));  // a long lazy chain ends here (a no-op with 29-bit limbs)
     r.x = x3;
     r.y = mul_sub(rr, qq - x3, s1, ppp);
     r.zz = a.zz * b.zz * pp;

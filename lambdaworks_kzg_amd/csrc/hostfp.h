@@ -120,6 +120,7 @@ inline HFp operator*(const HFp &a, const HFp &b) {
 inline HFp sqr(const HFp &a) { return a * a; }
 inline HFp dbl(const HFp &a) { return a + a; }
 inline HFp mul_sub(const HFp &a, const HFp &b, const HFp &c, const HFp &d) { return a * b - c * d; }
+inline HFp normed(const HFp &a) { return a; }
 inline bool literal_zero(const HFp &a) { return a.is_zero(); }  // g1.cuh's generic point types: infinity <=> zz == 0
 inline HFp inv(const HFp &a) { return HFp::from_fe(inv(a.to_fe())); }  // division steps (field.cuh)
 

@@ -241,7 +241,7 @@ void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len) {
 
 // decompress_g1_point (incl. the subgroup check) then compress_g1_point again, as compute_blob_kzg_proof +
 // compute_challenge do (/root/reference/src/lib.rs:372-375, src/utils.rs:138). One lane per point, all in the
-// 29-bit-limb field: square root (p = 3 mod 4), root selection by the sign flag, endomorphism subgroup
+// lazy-limb field (field29.cuh): square root (p = 3 mod 4), root selection by the sign flag, endomorphism subgroup
 // test. Re-compressing an affine point needs no inversion: the canonical bytes are x (reduced) + flags.
 // aff_out / kind_out (optional): the validated point in the hot-loop representation and 0 = affine,
 // 1 = infinity, 2 = invalid, for the verify side's linear combinations.

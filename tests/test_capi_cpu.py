@@ -118,7 +118,7 @@ def test_host_fiat_shamir_digests_match_hashlib(K):
 
 def test_product_arithmetic_host_crosscheck(tmp_path):
     """The kernels' own field / group sources (LWK_HD), compiled for the host: division-step inversion vs Fermat,
-    29-bit-limb lazy field vs the 32-bit CIOS field, hot-loop XYZZ scalar multiplication vs the CIOS one
+    28-bit-limb lazy field vs the 32-bit CIOS field, hot-loop XYZZ scalar multiplication vs the CIOS one
     (tools/host_check.hip). No GPU, no oracle: the product checked against itself along independent routes."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -2,7 +2,7 @@
 // and cross-checked against itself along independent routes. Pure host code: runs without a GPU (tests/test_capi_cpu.py
 // builds and runs it under -m "not gpu").
 //   1. division-step inversion (f29_inv, inv(Fp)) == Fermat's a^(p-2), and a * a^-1 == 1
-//   2. hot-loop field (14 x 29-bit limbs, lazy bounds): a*b, a^2, fused a*b - c*d, sums/differences == the 12 x 32-bit
+//   2. hot-loop field (14 x 28-bit limbs, lazy value and limb bounds): a*b, a^2, fused a*b - c*d, sums/differences == the 12 x 32-bit
 //      CIOS field on the same values
 //   3. hot-loop group law: [k]G by double-and-add over F29 (XYZZ, mixed additions) == [k]G over the CIOS field, on
 //      compressed bytes; [r]G = O; [r-1]G = -G; P + P through the addition formula's doubling branch; P + (-P) = O
@@ -70,7 +70,7 @@ int main() {
         bool ok = same(f29_to_fp(a * b), fa * fb) && same(f29_to_fp(sqr(a)), sqr(fa)) &&
                   same(f29_to_fp(mul_sub(a, b, c, d)), fa * fb - fc * fd) && same(f29_to_fp(a + b), fa + fb) &&
                   same(f29_to_fp(a - b), fa - fb) && same(f29_to_fp((a - b) * (c + d + a)), (fa - fb) * (fc + fd + fa)) &&
-                  same(f29_to_fp(sqr(a - b - c)), sqr(fa - fb - fc)) && same(f29_to_fp(neg(a)), neg(fa)) &&
+                  same(f29_to_fp(sqr(normed(a - b - c))), sqr(fa - fb - fc)) && same(f29_to_fp(neg(a)), neg(fa)) &&
                   same(f29_to_fp(cneg(a, true)), neg(fa)) && same(f29_to_fp(cneg(a, false)), fa) &&
                   (a - a).is_zero() && ((a * b) - (b * a)).is_zero() && !(a - b).is_zero() == !same(fa, fb);
         if (!ok && bad++ < 5) printf("field mismatch at case %d\n", k);
