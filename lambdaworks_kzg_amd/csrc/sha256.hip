@@ -7,6 +7,7 @@
 // The reference builds that 131 KB Vec byte by byte on the host for every blob; here the blob is
 // already in HBM, so one lane per blob streams it through the compression function (16 B loads).
 // SHA-256 is sequential per message: the parallelism is across the blobs of the batch.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace lwk {
@@ -179,12 +180,182 @@ __global__ __launch_bounds__(128) void k_challenge(const uint8_t *__restrict__ b
     z_mont[i] = fe_from_raw<FrParams>(s);  // reduced mod r
 }
 
+// ---- lane-pair variant ---------------------------------------------------------------------------------------
+// The consumer's 15-16 instructions per round shrink to 12 (no wait states left over) when a blob's state is split over two neighbouring lanes:
+// the "e half" (e, f, g, h) and the "a half" (a, b, c, d) run the SAME instruction stream on different data --
+//     Sigma(r0) with per-lane rotation amounts (6, 11, 25 | 2, 13, 22),
+//     Ch(e, f, g) = bfi(e, f, g) and Maj(a, b, c) = bfi(a ^ c, b, c) as one bfi(r0 ^ (r2 & a_half), r1, r2),
+//     t = Sigma + select + (W + K | 0), plus h on the e half only (a bank-masked DPP add),
+// and exchange T1 / d through DPP operands: e' = d + T1, a' = T1 + T2. Within a row of 16 lanes, lanes 0-7 are
+// the e halves of eight blobs and lanes 8-15 their a halves (partner = lane ^ 8 = row_ror:8; DPP banks 0-1 | 2-3).
+// Two producer waves (even / odd blocks, half a block per barrier interval each) feed two consumer waves (32 blobs
+// each); the consumers preload the sixteen LDS words of a block before its first round. LWKZG_HASH_PAIRS=0 selects
+// the plain kernel.
+// one round on state registers named R0..R3 (asm operand names), W + K in WK; the new r0 lands in R3's register (the
+// roles rotate through the four registers, back to the start after four rounds). `ta` = r2 & a_half mask is
+// computed one round ahead: the AND fills the wait state the last DPP add needs after t1 is written.
+#define LWK_SHA_PAIR_RND(R0, R1, R2, R3, WK)                                                       \
+    "v_alignbit_b32 %[t1], %[" R0 "], %[" R0 "], %[s1]\n"                                           \
+    "v_alignbit_b32 %[t2], %[" R0 "], %[" R0 "], %[s2]\n"                                           \
+    "v_alignbit_b32 %[t3], %[" R0 "], %[" R0 "], %[s3]\n"                                           \
+    "v_xor_b32 %[t1], %[t1], %[t2]\n"                                                               \
+    "v_xor_b32 %[t1], %[t1], %[t3]\n"                                                               \
+    "v_xor_b32 %[t2], %[ta], %[" R0 "]\n"                                                           \
+    "v_bfi_b32 %[t2], %[t2], %[" R1 "], %[" R2 "]\n"                                                \
+    "v_add3_u32 %[t1], %[t1], %[t2], %[" WK "]\n"                                                   \
+    "v_add_u32_dpp %[t1], %[" R3 "], %[t1] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n"        \
+    "v_add_u32_dpp %[" R3 "], %[" R3 "], %[t1] row_ror:8 row_mask:0xf bank_mask:0x3\n"              \
+    "v_and_b32 %[ta], %[" R1 "], %[bm]\n"                                                           \
+    "v_add_u32_dpp %[" R3 "], %[t1], %[t1] row_ror:8 row_mask:0xf bank_mask:0xc\n"
+
+// four rounds = one 16-byte word of W + K; state in (r0, r1, r2, r3) before and after
+#define LWK_SHA_PAIR_ROUNDS4(V)                                                                              \
+    {                                                                                                        \
+        uint32_t t1, t2, t3;                                                                                 \
+        asm volatile(LWK_SHA_PAIR_RND("a0", "a1", "a2", "a3", "w0") LWK_SHA_PAIR_RND("a3", "a0", "a1", "a2", "w1") \
+                         LWK_SHA_PAIR_RND("a2", "a3", "a0", "a1", "w2") LWK_SHA_PAIR_RND("a1", "a2", "a3", "a0", "w3") \
+                     : [a0] "+v"(r0), [a1] "+v"(r1), [a2] "+v"(r2), [a3] "+v"(r3), [ta] "+v"(ta), [t1] "=&v"(t1),  \
+                       [t2] "=&v"(t2), [t3] "=&v"(t3)                                                         \
+                     : [w0] "v"((V).x), [w1] "v"((V).y), [w2] "v"((V).z), [w3] "v"((V).w), [s1] "v"(s1), [s2] "v"(s2), \
+                       [s3] "v"(s3), [bm] "v"(bm));                                                          \
+    }
+
+__global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
+                                                         Fr *__restrict__ z_mont, int le, size_t n,
+                                                         const uint8_t *__restrict__ only_if_differs_from) {
+    // waves 0, 1: producers (all 64 blobs each; wave 0 expands the even blocks, wave 1 the odd ones, half a block
+    // per barrier interval, so a block has two intervals to get ready); waves 2, 3: consumers (32 blobs each, two
+    // lanes per blob). Block b is written in intervals b and b + 1 and read in interval b + 2: three LDS buffers.
+    __shared__ uint4 wk[3][16][64];
+    __shared__ uint4 zero4;  // what the a halves read in place of W + K
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const bool producer = role < 2;
+    const bool a_half = !producer && ((lane >> 3) & 1);
+    const int blob_in_wg = producer ? lane : (role - 2) * 32 + (lane >> 4) * 8 + (lane & 7);
+    size_t i = (size_t)blockIdx.x * 64 + blob_in_wg;
+    bool active = i < n;
+    if (!active) i = n - 1;  // keeps every address valid; the result is dropped
+    const uint4 *blob = (const uint4 *)(blobs + (size_t)kBlobBytes * i);
+    const uint4 *comm = (const uint4 *)(canon48 + 48 * i);
+    if (only_if_differs_from) {
+        const uint4 *raw = (const uint4 *)(only_if_differs_from + 48 * i);
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint4 a = comm[k], b = raw[k];
+            same = same && a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+        }
+        active = active && !same;
+    }
+    if (threadIdx.x == 0) zero4 = make_uint4(0u, 0u, 0u, 0u);
+    if (!__syncthreads_or(active)) return;
+
+    constexpr int kBlocks = (2 + kBlobBytes / 16 + 3 + 3) / 4;  // 2050
+    // consumer state: (e, f, g, h) on the e half, (a, b, c, d) on the a half; hv = the chaining values of that half
+    uint32_t hv0 = a_half ? 0x6a09e667u : 0x510e527fu, hv1 = a_half ? 0xbb67ae85u : 0x9b05688cu,
+             hv2 = a_half ? 0x3c6ef372u : 0x1f83d9abu, hv3 = a_half ? 0xa54ff53au : 0x5be0cd19u;
+    uint32_t r0 = hv0, r1 = hv1, r2 = hv2, r3 = hv3;
+    const uint32_t s1 = a_half ? 2u : 6u, s2 = a_half ? 13u : 11u, s3 = a_half ? 22u : 25u, bm = a_half ? ~0u : 0u;
+    uint32_t ta = r2 & bm;  // the next round's r2 & a_half mask (see LWK_SHA_PAIR_RND)
+    // producer state: the rolling 16-word window of its current block and the loads of its next one
+    uint32_t w[16];
+    uint4 nxt[4];
+    int pblock = role;  // the block this producer is expanding (role 0: 0, 2, 4, ...; role 1: 1, 3, 5, ...)
+    if (producer) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = challenge_chunk(4 * pblock + q, blob, comm);
+    }
+    for (int it = 0; it < kBlocks + 2; it++) {
+        if (producer) {
+            const int phase = (it - role) & 1;  // 0: first half of the schedule, 1: second half
+            if (it >= role && pblock < kBlocks) {
+                uint4(*dst)[64] = wk[pblock % 3];
+                if (phase == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        w[4 * q] = nxt[q].x; w[4 * q + 1] = nxt[q].y; w[4 * q + 2] = nxt[q].z; w[4 * q + 3] = nxt[q].w;
+                    }
+                    if (pblock + 2 < kBlocks) {  // this producer's next block: its loads have two intervals to land
+#pragma unroll
+                        for (int q = 0; q < 4; q++) nxt[q] = challenge_chunk(4 * (pblock + 2) + q, blob, comm);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 32; t += 4) {
+                        uint32_t o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int r = t + u;
+                            if (r >= 16) {
+                                uint32_t w15 = w[(r - 15) & 15], w2 = w[(r - 2) & 15];
+                                uint32_t g0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                                uint32_t g1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                                w[r & 15] = w[r & 15] + g0 + w[(r - 7) & 15] + g1;
+                            }
+                            o[u] = w[r & 15] + kShaK[r];
+                        }
+                        dst[t >> 2][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 32; t < 64; t += 4) {
+                        uint32_t o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int r = t + u;
+                            uint32_t w15 = w[(r - 15) & 15], w2 = w[(r - 2) & 15];
+                            uint32_t g0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+                            uint32_t g1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+                            w[r & 15] = w[r & 15] + g0 + w[(r - 7) & 15] + g1;
+                            o[u] = w[r & 15] + kShaK[r];
+                        }
+                        dst[t >> 2][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                    pblock += 2;
+                }
+            }
+        } else if (it >= 2) {
+            // e halves walk the 16 x b128 words of their blob, a halves re-read the zero word
+            const char *base = a_half ? (const char *)&zero4 : (const char *)&wk[(it - 2) % 3][0][blob_in_wg];
+            const uint32_t stride = a_half ? 0u : (uint32_t)sizeof(uint4) * 64u;
+            uint4 v[16];  // all sixteen LDS reads in flight before the first round (the asm rounds are scheduling barriers)
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = *(const uint4 *)(base + q * stride);
+#pragma unroll
+            for (int q = 0; q < 16; q++) LWK_SHA_PAIR_ROUNDS4(v[q])
+            hv0 += r0; hv1 += r1; hv2 += r2; hv3 += r3;
+            r0 = hv0; r1 = hv1; r2 = hv2; r3 = hv3;
+            ta = r2 & bm;
+        }
+        __syncthreads();
+    }
+    if (producer) return;
+    // the e half collects the a half's four words and writes z
+    const uint32_t p0 = __shfl_xor(hv0, 8, 64), p1 = __shfl_xor(hv1, 8, 64), p2 = __shfl_xor(hv2, 8, 64),
+                   p3 = __shfl_xor(hv3, 8, 64);
+    if (a_half || !active) return;
+    const uint32_t h[8] = {p0, p1, p2, p3, hv0, hv1, hv2, hv3};
+    uint32_t sdig[8];
+    if (le) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sdig[k] = __builtin_bswap32(h[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sdig[k] = h[7 - k];
+    }
+    z_mont[i] = fe_from_raw<FrParams>(sdig);  // reduced mod r
+}
+
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from) {
     if (n == 0) return;
+    static const bool pairs = !(getenv("LWKZG_HASH_PAIRS") && atoi(getenv("LWKZG_HASH_PAIRS")) == 0);
     ProfScope p(only_if_differs_from ? "k_challenge_fixup" : "k_challenge", st);
-    hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st, blobs, canon48, z_mont, le, n,
-                       only_if_differs_from);
+    if (pairs)
+        hipLaunchKernelGGL(k_challenge_pairs, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, canon48, z_mont, le, n,
+                           only_if_differs_from);
+    else
+        hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st, blobs, canon48, z_mont, le, n,
+                           only_if_differs_from);
 }
 
 // host SHA-256 for the one batch-level hash of verify_blob_kzg_proof_batch (compute_r_powers,
