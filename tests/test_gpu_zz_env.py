@@ -22,3 +22,31 @@ def test_direct_table_opt_in_from_environment(K, gpu_setup):
     env = dict(os.environ, LWKZG_DIRECT_BITS="14")
     out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
     assert out[-2:] == ["14", want]
+
+
+def test_plain_hash_kernel_still_agrees(K, gpu_setup):
+    """LWKZG_HASH_PAIRS=0 keeps the one-consumer-lane-per-blob Fiat-Shamir kernel alive as a cross-check of the
+    lane-pair kernel (fresh process: the choice is read once)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    n = 70                                      # two workgroups, the second one partly empty
+    data = B.synthetic_batch(900, n)
+    d_blobs = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    d_comm = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), n, gpu_setup, None, None)
+    K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, gpu_setup, None, None)
+    torch.cuda.synchronize()
+    want = bytes(d_out.cpu().numpy().tobytes()).hex()
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch, blobs as B; import lambdaworks_kzg_amd as K; "
+            "ts = K.TrustedSetup.from_file(%r); n = %d; d = torch.frombuffer(bytearray(B.synthetic_batch(900, n)), dtype=torch.uint8).cuda(); "
+            "c = torch.empty(48 * n, dtype=torch.uint8, device='cuda'); o = torch.empty(48 * n, dtype=torch.uint8, device='cuda'); "
+            "K.blob_to_kzg_commitment_batch_device(c.data_ptr(), d.data_ptr(), n, ts, None, None); "
+            "K.compute_blob_kzg_proof_batch_device(o.data_ptr(), d.data_ptr(), c.data_ptr(), n, ts, None, None); "
+            "torch.cuda.synchronize(); print(bytes(o.cpu().numpy().tobytes()).hex())"
+            % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH, n))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, LWKZG_HASH_PAIRS="0")).decode().split()
+    assert out[-1] == want
