@@ -248,10 +248,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
         }
     };
 
-    // The mixed addition is split around its last use of the table row: (1) the two products that bring the row to the
-    // accumulator's scale and the degenerate cases (first row, P + P, P - P), (2) everything else. The NEXT row's
-    // gather is issued between the two, into the registers the current row just vacated: no second row buffer, no
-    // copy, and eight products of time for the gather to land.
+    // the next row's gather is issued inside the addition, right after the current row's last use (xyzz_madd_split)
     G1Xyzz29i acc = G1Xyzz29i::infinity();
     bool cv;
     uint32_t cn;
@@ -259,34 +256,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     advance(cv, cn, cr);
     while (cv) {
         const auto qy = cneg(cr.y, cn != 0);
-        bool simple = false;  // the addition was one of the degenerate cases and is already done
-        F29<2, true> u2, s2;
-        if (acc.is_inf()) {
-            acc = G1Xyzz29i::from_affine(cr.x, qy);
-            simple = true;
-        } else {
-            u2 = cr.x * acc.zz;
-            s2 = qy * acc.zzz;
-            if ((u2 - acc.x).is_zero()) {
-                acc = (s2 - acc.y).is_zero() ? xyzz_dbl_affine<G1Xyzz29i>(cr.x, qy) : G1Xyzz29i::infinity();
-                simple = true;
-            }
-        }
-        advance(cv, cn, cr);  // the row is dead from here on: fetch the next one
-        if (!simple) {
-            auto pp_ = u2 - acc.x;
-            auto rr = s2 - acc.y;
-            auto pp = sqr(pp_);
-            auto ppp = pp_ * pp;
-            auto qq = acc.x * pp;
-            auto x3 = normed(sqr(rr) - ppp - dbl(qq));
-            G1Xyzz29i r;
-            r.x = x3;
-            r.y = mul_sub(rr, qq - x3, acc.y, ppp);
-            r.zz = acc.zz * pp;
-            r.zzz = acc.zzz * ppp;
-            acc = r;
-        }
+        xyzz_madd_split(acc, cr.x, qy, [&]() { advance(cv, cn, cr); });
     }
 
     // fold: 64 lanes by shuffles, 4 waves through LDS

@@ -147,6 +147,43 @@ LWK_HD X xyzz_madd(const X &acc, const QX &qx, const QY &qy) {
 
 LWK_HD G1Xyzz xyzz_madd(const G1Xyzz &acc, const G1Affine &q) { return xyzz_madd(acc, q.x, q.y); }
 
+// The same addition, split around its last use of the affine operand: (1) the two products that bring Q to the
+// accumulator's scale plus the degenerate cases (acc = O, P + P, P - P), (2) everything else. `row_is_dead()` runs
+// between the two -- the hot loops issue the gather of their NEXT table row there, into the registers Q just
+// vacated: no second row buffer, no copy, and eight products of time for the gather to land.
+template <class X, class QX, class QY, class F>
+LWK_HD void xyzz_madd_split(X &acc, const QX &qx, const QY &qy, F &&row_is_dead) {
+    bool done = false;
+    decltype(qx * acc.zz) u2;
+    decltype(qy * acc.zzz) s2;
+    if (acc.is_inf()) {
+        acc = X::from_affine(qx, qy);
+        done = true;
+    } else {
+        u2 = qx * acc.zz;
+        s2 = qy * acc.zzz;
+        if ((u2 - acc.x).is_zero()) {
+            if ((s2 - acc.y).is_zero()) acc = xyzz_dbl_affine<X>(qx, qy);
+            else acc = X::infinity();
+            done = true;
+        }
+    }
+    row_is_dead();
+    if (done) return;
+    auto pp_ = u2 - acc.x;
+    auto rr = s2 - acc.y;
+    auto pp = sqr(pp_);
+    auto ppp = pp_ * pp;
+    auto qq = acc.x * pp;
+    auto x3 = normed(sqr(rr) - ppp - dbl(qq));
+    X r;
+    r.x = x3;
+    r.y = mul_sub(rr, qq - x3, acc.y, ppp);
+    r.zz = acc.zz * pp;
+    r.zzz = acc.zzz * ppp;
+    acc = r;
+}
+
 // a + b (add-2008-s), complete
 template <class X>
 LWK_HD X xyzz_add(const X &a, const X &b) {

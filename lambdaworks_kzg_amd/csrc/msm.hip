@@ -291,20 +291,19 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
     const G1Affine29i *tab = (const G1Affine29i *)table;
     G1Xyzz29i acc = G1Xyzz29i::infinity();
     if (begin < end) {
-        // software pipeline: the next entry's index and its table point are in flight while the current
-        // mixed addition (about 4k v_mad_u64_u32) executes; entry -> point is a dependent gather
+        // entry -> point is a dependent gather: the entry index runs two steps ahead, and the next point's gather is
+        // issued inside the addition right after the current point's last use, into the registers it vacated
+        // (xyzz_madd_split), with about 3k v_mad_u64_u32 of time to land
         uint32_t e = ent[begin];
+        uint32_t e1 = begin + 1 < end ? ent[begin + 1] : e;
         G1Affine29i p = tab[e & ~kEntryNegBit];
         for (uint32_t k = begin; k < end; k++) {
-            uint32_t e_next = e;
-            G1Affine29i p_next = p;
-            if (k + 1 < end) {
-                e_next = ent[k + 1];
-                p_next = tab[e_next & ~kEntryNegBit];
-            }
-            acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
-            e = e_next;
-            p = p_next;
+            const auto qy = cneg(p.y, (e & kEntryNegBit) != 0);
+            xyzz_madd_split(acc, p.x, qy, [&]() {
+                e = e1;
+                if (k + 1 < end) p = tab[e & ~kEntryNegBit];
+                if (k + 2 < end) e1 = ent[k + 2];
+            });
         }
     }
     ((G1Xyzz29i *)buckets)[blob * (size_t)kNumBuckets + b] = acc;
