@@ -918,9 +918,33 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
         C_KZG_RET rc = ctx_reserve(c, m);
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;
-        LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
-        rc = commit_batch_device(c, w.out48, w.blobs, m, mode, c->stream, w.status);
-        if (rc != C_KZG_OK) return rc;
+        if (m >= 512) {
+            // large chunks go up in slices of 256 blobs on two alternating streams: the pageable H2D copy of slice
+            // k + 1 (which blocks this thread while it is staged) runs while the GPU works on slice k
+            constexpr size_t kSlice = 256;
+            LWK_HIP(hipEventRecord(c->ev_fork, c->stream));
+            LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+            LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+            int k = 0;
+            for (size_t lo = 0; lo < m; lo += kSlice, k++) {
+                const size_t cnt = m - lo < kSlice ? m - lo : kSlice;
+                hipStream_t sk = c->aux[k & 1];
+                uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
+                LWK_HIP(hipMemcpyAsync(d_blobs, (const uint8_t *)(blobs + off + lo), cnt * (size_t)kBlobBytes,
+                                       hipMemcpyHostToDevice, sk));
+                LWK_HIP(hipMemsetAsync(w.status + lo, 0, cnt * 4, sk));
+                coefficients_stage(c, d_blobs, cnt, mode, w.status + lo, sk, lo);
+                msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, cnt, sk, lo);
+            }
+            for (int j = 0; j < 2; j++) {
+                LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
+                LWK_HIP(hipStreamWaitEvent(c->stream, c->ev_join[j], 0));
+            }
+        } else {
+            LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
+            rc = commit_batch_device(c, w.out48, w.blobs, m, mode, c->stream, w.status);
+            if (rc != C_KZG_OK) return rc;
+        }
         std::vector<uint8_t> h_out(m * 48);
         LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
         rc = collect_status(c, w.status, m, off, first_bad);

@@ -177,6 +177,27 @@ def test_ckzg_batch_reports_first_bad(K, gpu_setup):
     assert rc == K.C_KZG_BADARGS and bad.value == 2
 
 
+def test_large_host_batch_is_sliced_and_reports_first_bad(K, gpu_setup):
+    """host-pointer batches of >= 512 blobs go up in 256-blob slices on two streams: same bytes as the device path,
+    and the first rejected blob is still reported by its index in the whole batch"""
+    import torch
+    K.set_mode(K.MODE_CKZG)
+    n = 600
+    data = bytearray(B.synthetic_batch(3000, n, big_endian=False))
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_in.data_ptr(), n, gpu_setup, None, None)
+    torch.cuda.synchronize()
+    assert b"".join(K.blob_to_kzg_commitment_batch(bytes(data), gpu_setup)) == _host(d_out)
+    bad_blob = B.make_blob("all_ff")                        # every element >= r: not canonical in c-kzg mode
+    data[317 * B.BYTES_PER_BLOB:318 * B.BYTES_PER_BLOB] = bad_blob
+    data[590 * B.BYTES_PER_BLOB:591 * B.BYTES_PER_BLOB] = bad_blob
+    out = C.create_string_buffer(48 * n)
+    bad = C.c_size_t(9999)
+    rc = K.lib().lwkzg_blob_to_kzg_commitment_batch(out, bytes(data), n, gpu_setup.ref(), C.byref(bad))
+    assert rc == K.C_KZG_BADARGS and bad.value == 317
+
+
 # ---- proofs (a8-a11) --------------------------------------------------------------------------------
 
 def test_compute_kzg_proof_ckzg_vectors(K, gpu_setup, vectors):
