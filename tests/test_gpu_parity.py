@@ -90,6 +90,35 @@ def test_ntt_kernel_vs_oracle(K, gpu_setup, oracle):
             assert got[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB] == oracle.fr_ntt4096(v, inverse=inverse)
 
 
+def test_ntt_roundtrip_and_linearity_batch_256(K, gpu_setup):
+    """size-independent properties at batch size: INTT(NTT(x)) == x, NTT(x + y) == NTT(x) + NTT(y) (mod r)"""
+    import numpy as np
+    import torch
+    from lambdaworks_kzg_amd import capi
+    n = 256
+    x = np.frombuffer(B.synthetic_batch(8000, n), dtype=np.uint8)            # canonical (< 2^248) big-endian elements
+    y = np.frombuffer(B.synthetic_batch(9000, n), dtype=np.uint8)
+    d_x, d_y = torch.from_numpy(x.copy()).cuda(), torch.from_numpy(y.copy()).cuda()
+    d_fx, d_fy, d_back = torch.empty_like(d_x), torch.empty_like(d_x), torch.empty_like(d_x)
+    capi.fr_ntt4096_device(d_fx.data_ptr(), d_x.data_ptr(), n, False, gpu_setup)
+    capi.fr_ntt4096_device(d_back.data_ptr(), d_fx.data_ptr(), n, True, gpu_setup)
+    capi.fr_ntt4096_device(d_fy.data_ptr(), d_y.data_ptr(), n, False, gpu_setup)
+    torch.cuda.synchronize()
+    assert torch.equal(d_back, d_x)
+    # linearity on a few vectors, big integers on the host
+    fx, fy = _host(d_fx), _host(d_fy)
+    for v in (0, 100, 255):
+        sx, sy = B.blob_scalars(x[v * B.BYTES_PER_BLOB:(v + 1) * B.BYTES_PER_BLOB].tobytes()), B.blob_scalars(y[v * B.BYTES_PER_BLOB:(v + 1) * B.BYTES_PER_BLOB].tobytes())
+        ssum = b"".join(((a + b) % R).to_bytes(32, "big") for a, b in zip(sx, sy))
+        d_s = _dev(ssum)
+        d_fs = torch.empty_like(d_s)
+        capi.fr_ntt4096_device(d_fs.data_ptr(), d_s.data_ptr(), 1, False, gpu_setup)
+        torch.cuda.synchronize()
+        want = b"".join(((a + b) % R).to_bytes(32, "big") for a, b in
+                        zip(B.blob_scalars(fx[v * B.BYTES_PER_BLOB:(v + 1) * B.BYTES_PER_BLOB]), B.blob_scalars(fy[v * B.BYTES_PER_BLOB:(v + 1) * B.BYTES_PER_BLOB])))
+        assert _host(d_fs) == want
+
+
 def test_msm_kernel_vs_oracle_and_closed_form(K, gpu_setup, oracle, oracle_setup):
     import torch
     from lambdaworks_kzg_amd import capi
