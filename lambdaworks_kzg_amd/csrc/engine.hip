@@ -167,6 +167,7 @@ static void ctx_destroy(Ctx *c) {
     dev_free(c->tw_fwd);
     dev_free(c->tw_inv);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->vstream) hipStreamDestroy(c->vstream);
     for (int k = 0; k < kMaxSplit; k++) {
         if (c->aux[k]) hipStreamDestroy(c->aux[k]);
         if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]);
@@ -200,6 +201,7 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->magic = kCtxMagic;
     c->device = g_default_device;
     c->stream = nullptr;
+    c->vstream = nullptr;
     c->ev_fork = nullptr;
     for (int k = 0; k < kMaxSplit; k++) {
         c->aux[k] = nullptr;
@@ -213,6 +215,17 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->tw_fwd = c->tw_inv = nullptr;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+    if (e == hipSuccess) {
+        // validation kernels (one latency-bound wave per 64 points) run beside the Fiat-Shamir kernel, whose four waves
+        // per workgroup fill a CU's SIMDs; a wave of each on one SIMD halves both. The validation stream is therefore
+        // confined to the upper half of every XCD's CUs, away from where a small grid's workgroups are placed.
+        uint32_t mask[8];
+        for (int k = 0; k < 8; k++) mask[k] = 0xffff0000u;
+        if (hipExtStreamCreateWithCUMask(&c->vstream, 8, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking);
+        }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     for (int k = 0; k < kMaxSplit && e == hipSuccess; k++) {
         e = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);
@@ -426,9 +439,9 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         // hash optimistically from the caller's bytes on `st` while an auxiliary stream validates, then redo only
         // the lanes whose canonical bytes differ.
         LWK_HIP(hipEventRecord(c->ev_fork, st));
-        LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-        launch_validate_commitments(cm, w.canon48, stt, le ? kStatusBadArgs : kStatusError, m, c->aux[0]);
-        LWK_HIP(hipEventRecord(c->ev_join[0], c->aux[0]));
+        LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
+        launch_validate_commitments(cm, w.canon48, stt, le ? kStatusBadArgs : kStatusError, m, c->vstream);
+        LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         coefficients_stage(c, bl, m, mode, stt, st);
         launch_challenge(bl, cm, w.z, le, m, st);
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
@@ -549,7 +562,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         if (proofs48 && !host_validate) {
             // the proofs' validation (a 2 ms latency-shaped kernel) runs beside the commitments' on an auxiliary stream;
             // both only ever write the same failure code into status
-            hipStream_t sa = c->aux[0];
+            hipStream_t sa = c->vstream;
             LWK_HIP(hipEventRecord(c->ev_fork, st));
             LWK_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
             LWK_HIP(hipMemcpyAsync(vb.proof_in + 48 * off, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, sa));
@@ -991,10 +1004,10 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         std::vector<int32_t> h_code(m, le ? kStatusBadArgs : kStatusError);
         if (!host_validate) {
             LWK_HIP(hipEventRecord(c->ev_fork, st));
-            LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-            launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, c->aux[0]);
-            LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, c->aux[0]));
-            LWK_HIP(hipEventRecord(c->ev_join[0], c->aux[0]));
+            LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
+            launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, c->vstream);
+            LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, c->vstream));
+            LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         }
         // GPU, main stream: parse the blobs, then the digests as soon as the host threads have them
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
