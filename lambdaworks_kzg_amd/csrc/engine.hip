@@ -553,6 +553,17 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;
         const uint8_t *hb = blobs + off * (size_t)kBlobBytes, *hc = comm48 + 48 * off;
+        // the Fiat-Shamir digests only need host memory: host threads start on them now, beside the pageable H2D copy
+        // (which blocks this thread for milliseconds) and the GPU's validation / parsing. They assume the caller's
+        // commitment bytes are canonical; the comparison below confirms or refutes that.
+        const uint8_t *hash_comm = trusted_canon_c ? trusted_canon_c + 48 * off : hc;
+        const bool hash_beside = m > 64;  // a few blobs: hashing takes microseconds, a thread and its contention do not pay
+        std::thread hasher;
+        if (hash_beside) hasher = std::thread([&, hash_comm]() { challenge_digests_host(dig.data(), hb, hash_comm, m); });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } joiner{hasher};
         LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemcpyAsync(w.comm48, hc, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
@@ -601,7 +612,8 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             }
         }
         if (proofs48 && !host_validate) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
-        challenge_digests_host(dig.data(), hb, hc, m);
+        if (hash_beside) hasher.join();
+        else challenge_digests_host(dig.data(), hb, hash_comm, m);
         LWK_HIP(hipStreamSynchronize(st));
         if (memcmp(canon_c + 48 * off, hc, m * 48) == 0) {
             LWK_HIP(hipMemcpyAsync(w.zbytes, dig.data(), m * 32, hipMemcpyHostToDevice, st));
