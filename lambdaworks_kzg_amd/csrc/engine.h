@@ -51,6 +51,8 @@ struct VerifyBuffers {
     G1Affine29 *pts_c = nullptr, *pts_p = nullptr;
     int32_t *kind_c = nullptr, *kind_p = nullptr;
     uint8_t *proof_in = nullptr;  // compressed proofs as uploaded (validated on an auxiliary stream)
+    uint8_t *comm_in = nullptr, *canon_dev = nullptr;  // commitments as uploaded; canonical bytes (n commitments, n proofs)
+    int32_t *status_all = nullptr;                      // per-blob verdicts of the up-front validation
     uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
     G1Xyzz29 *d_part = nullptr;
     int32_t *d_inf = nullptr;

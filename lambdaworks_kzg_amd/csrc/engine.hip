@@ -492,6 +492,9 @@ static void vs_free(Ctx *c) {
     dev_free(v.kind_c);
     dev_free(v.kind_p);
     dev_free(v.proof_in);
+    dev_free(v.comm_in);
+    dev_free(v.canon_dev);
+    dev_free(v.status_all);
     dev_free(v.d_r);
     dev_free(v.d_rz);
     dev_free(v.d_aff);
@@ -513,6 +516,8 @@ static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
               hipMalloc((void **)&v.pts_p, cap * sizeof(G1Affine29)) == hipSuccess &&
               hipMalloc((void **)&v.kind_c, cap * 4) == hipSuccess && hipMalloc((void **)&v.kind_p, cap * 4) == hipSuccess &&
               hipMalloc((void **)&v.proof_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.d_r, cap * 32) == hipSuccess &&
+              hipMalloc((void **)&v.comm_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.canon_dev, 2 * cap * 48) == hipSuccess &&
+              hipMalloc((void **)&v.status_all, cap * 4) == hipSuccess &&
               hipMalloc((void **)&v.d_rz, cap * 32) == hipSuccess &&
               hipMalloc((void **)&v.d_part, (3 * nblk + 3) * sizeof(G1Xyzz29)) == hipSuccess &&
               hipMalloc((void **)&v.d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&v.d_inf, 3 * 4) == hipSuccess;
@@ -524,6 +529,113 @@ static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
     }
     c->vs_cap = cap;
     return C_KZG_OK;
+}
+
+// Batches longer than one chunk (1024 blobs). All 2n points are validated ONCE up front (two launches side by side; the kernel is a 2 ms
+// latency chain whatever n is), and the blobs then go through in slices that alternate between the two halves of the
+// workspace and two streams: while the GPU parses / evaluates one slice, this thread is already inside the (blocking,
+// pageable) H2D copy of the next and the host threads hash it. A slot is finished (digests uploaded, y = p(z)
+// evaluated, z and y copied back, statuses checked) right before it is reused, and at the end. Caller holds c->mu.
+static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
+                                     int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p,
+                                     VerifyBuffers &vb) {
+    const int le = mode == LWKZG_MODE_CKZG;
+    const int bad = le ? kStatusBadArgs : kStatusError;
+    hipStream_t st = c->stream, sv = c->vstream;
+    const bool piped = n >= kMaxChunk;
+    const size_t step = piped ? kMaxChunk / 2 : n;
+    C_KZG_RET rcw = ctx_reserve(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rcw != C_KZG_OK) return rcw;
+    Workspace &w = c->ws;
+
+    // up-front validation of every commitment (main stream) and every proof (CU-masked validation stream)
+    LWK_HIP(hipMemcpyAsync(vb.comm_in, comm48, n * 48, hipMemcpyHostToDevice, st));
+    LWK_HIP(hipMemsetAsync(vb.status_all, 0, n * 4, st));
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
+    LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, n * 48, hipMemcpyHostToDevice, sv));
+    launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p);
+    LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, sv));
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
+    launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c);
+    LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));
+    bool validated = false;                                     // host has waited for it once
+
+    struct Slot {
+        bool used = false;
+        size_t off = 0, m = 0, base = 0;
+        hipStream_t sk = nullptr;
+        const uint8_t *hb = nullptr, *hc = nullptr;
+        std::vector<uint8_t> dig;
+        std::thread hasher;
+        ~Slot() { if (hasher.joinable()) hasher.join(); }
+    } slots[2];
+
+    auto begin = [&](Slot &s, size_t off, size_t m, int idx) -> C_KZG_RET {
+        s.used = true;
+        s.off = off;
+        s.m = m;
+        s.base = piped ? (size_t)idx * step : 0;
+        s.sk = c->aux[idx];
+        s.hb = blobs + off * (size_t)kBlobBytes;
+        s.hc = comm48 + 48 * off;
+        s.dig.resize(32 * m);
+        Slot *sp = &s;  // digests assume the caller's commitment bytes are canonical; finish() confirms or refutes that
+        s.hasher = std::thread([sp]() { challenge_digests_host(sp->dig.data(), sp->hb, sp->hc, sp->m); });
+        uint8_t *d_blobs = w.blobs + s.base * (size_t)kBlobBytes;
+        LWK_HIP(hipMemcpyAsync(d_blobs, s.hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, s.sk));
+        LWK_HIP(hipMemsetAsync(w.status + s.base, 0, m * 4, s.sk));
+        coefficients_stage(c, d_blobs, m, mode, w.status + s.base, s.sk, s.base);
+        return C_KZG_OK;
+    };
+
+    auto finish = [&](Slot &s) -> C_KZG_RET {
+        if (!s.used) return C_KZG_OK;
+        s.used = false;
+        const size_t base = s.base, off = s.off, m = s.m;
+        hipStream_t sk = s.sk;
+        s.hasher.join();
+        if (!validated) {  // canonical bytes are on the host from here on
+            LWK_HIP(hipStreamSynchronize(st));
+            validated = true;
+        }
+        Fr *d_z = w.z + base;
+        uint8_t *d_zb = w.zbytes + 32 * base, *d_yb = w.ybytes + 32 * base;
+        if (memcmp(canon_c + 48 * off, s.hc, m * 48) == 0) {
+            LWK_HIP(hipMemcpyAsync(d_zb, s.dig.data(), m * 32, hipMemcpyHostToDevice, sk));
+            launch_z_from_bytes(d_zb, d_z, nullptr, le, m, sk);
+        } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
+            launch_challenge(w.blobs + base * (size_t)kBlobBytes, vb.canon_dev + 48 * off, d_z, le, m, sk);
+        }
+        launch_eval_quotient(w.scalars + base * (size_t)kBlobElems * 8, d_z, w.scalars2 + base * (size_t)kBlobElems * 8, d_yb, le, m,
+                             sk);
+        launch_fr_mont_to_bytes(d_z, d_zb, le, m, sk);
+        LWK_HIP(hipMemcpyAsync(z32 + 32 * off, d_zb, m * 32, hipMemcpyDeviceToHost, sk));
+        LWK_HIP(hipMemcpyAsync(y32 + 32 * off, d_yb, m * 32, hipMemcpyDeviceToHost, sk));
+        return first_status(c, w.status + base, m, sk);
+    };
+
+    // the slice streams start after the caller's earlier work on the main stream
+    LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    int k = 0;
+    C_KZG_RET rc_all = C_KZG_OK;
+    for (size_t off = 0; off < n && rc_all == C_KZG_OK; off += step, k++) {
+        const size_t m = n - off < step ? n - off : step;
+        Slot &s = slots[piped ? (k & 1) : 0];
+        rc_all = finish(s);  // the slot's previous occupant, if any
+        if (rc_all == C_KZG_OK) rc_all = begin(s, off, m, piped ? (k & 1) : 0);
+    }
+    for (int j = 0; j < 2; j++) {  // drain in submission order
+        C_KZG_RET rc = finish(slots[piped ? ((k + j) & 1) : j]);
+        if (rc_all == C_KZG_OK) rc_all = rc;
+    }
+    hipStreamSynchronize(c->aux[0]);
+    hipStreamSynchronize(c->aux[1]);
+    if (!validated) LWK_HIP(hipStreamSynchronize(st));
+    if (rc_all != C_KZG_OK) return rc_all;
+    return first_status(c, vb.status_all, n, st);  // the validation's verdicts
 }
 
 // Everything per blob of a batch verification, in one pass over the blobs: validate C_i and pi_i (keeping the
@@ -545,7 +657,10 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         const VerifyBuffers &v = c->vs;
         vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
         vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
+        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all;
     }
+    if (n > kMaxChunk && proofs48 && !trusted_canon_c)  // up to one chunk the single pass below is ~1 ms shorter
+        return verify_prepare_long(c, blobs, comm48, proofs48, n, mode, z32, y32, canon_c, canon_p, vb);
     std::vector<uint8_t> dig(32 * (n < kMaxChunk ? n : kMaxChunk));
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;

@@ -697,3 +697,21 @@ def test_direct_tiled_long_msm(K, direct_setup, gpu_setup, oracle):
         acc = (acc + sum(s * p for s, p in zip(B.blob_scalars(arr[t].tobytes()), pw))) % R
     assert got == oracle.g1_generator_mul(acc)
 
+
+
+def test_verify_long_batch_pipelined_path(K, gpu_setup):
+    """more than one chunk (1024 blobs): up-front validation of all points + sliced, pipelined per-blob pass. Accepts a
+    valid batch, rejects one with a single wrong proof far into it, errors on an invalid commitment encoding."""
+    n = 1100
+    data = B.synthetic_batch(4000, n)
+    comms = b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup))
+    proofs = b"".join(K.compute_blob_kzg_proof_batch(data, comms, gpu_setup))
+    assert K.verify_blob_kzg_proof_batch(data, comms, proofs, n, gpu_setup) is True
+    wrong = bytearray(proofs)
+    wrong[48 * 1077:48 * 1078] = proofs[48 * 3:48 * 4]          # a valid G1 point, but not this blob's proof
+    assert K.verify_blob_kzg_proof_batch(data, comms, bytes(wrong), n, gpu_setup) is False
+    badc = bytearray(comms)
+    badc[48 * 1050] &= 0x7f                                      # compression flag cleared: not a valid encoding
+    with pytest.raises(K.KzgError) as e:
+        K.verify_blob_kzg_proof_batch(data, bytes(badc), proofs, n, gpu_setup)
+    assert e.value.rc == K.C_KZG_ERROR
