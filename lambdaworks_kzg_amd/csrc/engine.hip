@@ -1053,44 +1053,70 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
-    for (size_t off = 0; off < n; off += kMaxChunk) {
-        size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        C_KZG_RET rc = ctx_reserve(c, m);
+    if (n < 512) {  // one launch set, results and verdicts back in one go
+        C_KZG_RET rc = ctx_reserve(c, n);
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;
-        if (m >= 512) {
-            // large chunks go up in slices of 256 blobs on two alternating streams: the pageable H2D copy of slice
-            // k + 1 (which blocks this thread while it is staged) runs while the GPU works on slice k
-            constexpr size_t kSlice = 256;
-            LWK_HIP(hipEventRecord(c->ev_fork, c->stream));
-            LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-            LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
-            int k = 0;
-            for (size_t lo = 0; lo < m; lo += kSlice, k++) {
-                const size_t cnt = m - lo < kSlice ? m - lo : kSlice;
-                hipStream_t sk = c->aux[k & 1];
-                uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
-                LWK_HIP(hipMemcpyAsync(d_blobs, (const uint8_t *)(blobs + off + lo), cnt * (size_t)kBlobBytes,
-                                       hipMemcpyHostToDevice, sk));
-                LWK_HIP(hipMemsetAsync(w.status + lo, 0, cnt * 4, sk));
-                coefficients_stage(c, d_blobs, cnt, mode, w.status + lo, sk, lo);
-                msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, cnt, sk, lo);
-            }
-            for (int j = 0; j < 2; j++) {
-                LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
-                LWK_HIP(hipStreamWaitEvent(c->stream, c->ev_join[j], 0));
-            }
-        } else {
-            LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
-            rc = commit_batch_device(c, w.out48, w.blobs, m, mode, c->stream, w.status);
-            if (rc != C_KZG_OK) return rc;
-        }
-        std::vector<uint8_t> h_out(m * 48);
-        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
-        rc = collect_status(c, w.status, m, off, first_bad);
+        LWK_HIP(hipMemcpyAsync(w.blobs, blobs, n * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
+        rc = commit_batch_device(c, w.out48, w.blobs, n, mode, c->stream, w.status);
+        if (rc != C_KZG_OK) return rc;
+        std::vector<uint8_t> h_out(n * 48);
+        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, n * 48, hipMemcpyDeviceToHost, c->stream));
+        rc = collect_status(c, w.status, n, 0, first_bad);
         if (rc != C_KZG_OK) return map_rc(rc, mode);
-        memcpy(out + off, h_out.data(), m * 48);
+        memcpy(out, h_out.data(), n * 48);
+        return C_KZG_OK;
     }
+    // Long batches stream through in slices of 512 blobs: slice k uses half k mod 2 of the workspace and stream
+    // k mod 2, so the pageable H2D copy of a slice (which blocks this thread while it is staged) runs beside the GPU's
+    // work on the previous one, a half is only reused by the stream that used it last (stream order is the only
+    // synchronisation needed), and nothing waits for the host until every slice has been submitted.
+    constexpr size_t kSlice = kMaxChunk / 2;
+    C_KZG_RET rc = ctx_reserve(c, kMaxChunk);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    std::vector<int32_t> h_status(n);
+    // results and verdicts of all slices stay on the device until the end: a D2H copy into pageable memory would make
+    // this thread wait for the slice it belongs to
+    uint8_t *d_out_all = nullptr;
+    int32_t *d_status_all = nullptr;
+    if (hipMalloc((void **)&d_out_all, n * 48) != hipSuccess || hipMalloc((void **)&d_status_all, n * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_out_all) hipFree(d_out_all);
+        set_error("lwkzg_blob_to_kzg_commitment_batch: out of device memory for %zu results", n);
+        return C_KZG_MALLOC;
+    }
+    struct Freer {
+        void *a, *b;
+        ~Freer() { hipFree(a); hipFree(b); }
+    } freer{d_out_all, d_status_all};
+    LWK_HIP(hipEventRecord(c->ev_fork, c->stream));
+    LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    size_t k = 0;
+    for (size_t off = 0; off < n; off += kSlice, k++) {
+        const size_t cnt = n - off < kSlice ? n - off : kSlice;
+        const size_t lo = (k % 2) * kSlice;
+        hipStream_t sk = c->aux[k & 1];
+        uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
+        LWK_HIP(hipMemcpyAsync(d_blobs, (const uint8_t *)(blobs + off), cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
+        LWK_HIP(hipMemsetAsync(d_status_all + off, 0, cnt * 4, sk));
+        coefficients_stage(c, d_blobs, cnt, mode, d_status_all + off, sk, lo);
+        msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, d_out_all + 48 * off, cnt, sk, lo);
+    }
+    for (int j = 0; j < 2; j++) {
+        LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
+        LWK_HIP(hipStreamWaitEvent(c->stream, c->ev_join[j], 0));
+    }
+    LWK_HIP(hipMemcpyAsync((uint8_t *)out, d_out_all, n * 48, hipMemcpyDeviceToHost, c->stream));
+    LWK_HIP(hipMemcpyAsync(h_status.data(), d_status_all, n * 4, hipMemcpyDeviceToHost, c->stream));
+    LWK_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++)
+        if (h_status[i] != 0) {
+            if (first_bad) *first_bad = i;
+            set_error("blob %zu rejected (status %d)", i, h_status[i]);
+            return map_rc((C_KZG_RET)h_status[i], mode);
+        }
     return C_KZG_OK;
 }
 
