@@ -126,6 +126,33 @@ void challenge_digest(uint8_t out[32], const uint8_t *blob, const uint8_t *comm4
 
 }  // namespace
 
+// SHA-256 of an arbitrary message with the SHA extensions when the CPU has them (the batch-level Fiat-Shamir hash of
+// verify_blob_kzg_proof_batch: 160 bytes per blob), the portable routine otherwise
+void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len) {
+    if (!have_shani()) {
+        sha256_host(out, msg, len);
+        return;
+    }
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    const size_t whole = len / 64;
+    compress_shani(h, msg, whole);
+    uint8_t tail[128];
+    memset(tail, 0, sizeof tail);
+    const size_t rem = len - 64 * whole;
+    memcpy(tail, msg + 64 * whole, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem + 9 <= 64 ? 64 : 128;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    compress_shani(h, tail, tl / 64);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(h[k] >> 24);
+        out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(h[k] >> 8);
+        out[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
 // hardware threads this process may really use (shared with the host-side validation of verify.hip)
 unsigned host_threads() {
     unsigned n = std::thread::hardware_concurrency();

@@ -24,6 +24,7 @@ namespace lwk {
 bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, int n);
 bool pairing_check_compressed(const uint8_t *g1s, const uint8_t *g2s, int n, bool *ok);
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
+void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len);  // sha256_host.hip: SHA extensions when present
 
 namespace {
 
@@ -289,7 +290,7 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         memcpy(m + 112, &canon_p[48 * i], 48);
     }
     uint8_t dg[32];
-    sha256_host(dg, msg.data(), msg.size());
+    sha256_fast(dg, msg.data(), msg.size());
     uint32_t rraw[8];
     {
         uint32_t t[8];
@@ -297,19 +298,40 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         Fr f = fe_from_raw<FrParams>(t);  // hash_field_unsafe: reduced mod r
         fe_to_raw<FrParams>(rraw, f);
     }
-    // scalars r^i, r^i z_i (for the GPU) and sum r^i y_i (one host scalar)
-    Fr rf = fe_from_raw<FrParams>(rraw), rp = Fr::one(), ysum = Fr::zero();
+    // scalars r^i, r^i z_i (for the GPU) and sum r^i y_i (one host scalar), on the 64-bit host field. The running power
+    // stays in Montgomery form; a Montgomery product with a RAW factor (z_i, y_i, 1) yields the raw product directly.
+    auto hfr_raw = [](const uint32_t t[8]) {
+        HFr x;
+        for (int k = 0; k < 4; k++) x.l[k] = (uint64_t)t[2 * k] | ((uint64_t)t[2 * k + 1] << 32);
+        return x;
+    };
+    auto hfr_to_be = [](uint8_t *out, const HFr &x) {
+        uint32_t t[8];
+        for (int k = 0; k < 4; k++) {
+            t[2 * k] = (uint32_t)x.l[k];
+            t[2 * k + 1] = (uint32_t)(x.l[k] >> 32);
+        }
+        raw_to_be<8>(out, t);
+    };
+    const uint32_t one_limbs[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    const HFr one_raw = hfr_raw(one_limbs);
+    const HFr r_mont = hfr_raw(rraw) * hfr_raw(FrParams::R2);
+    HFr rp = HFr::one(), ysum = HFr::zero();  // rp: r^i in Montgomery form; ysum: raw
     std::vector<uint8_t> sc_r(32 * n), sc_rz(32 * n);
     for (size_t i = 0; i < n; i++) {
-        uint32_t zr[8], yr[8], t[8];
-        if (!fr_from_bytes(zr, &zs[32 * i], mode) || !fr_from_bytes(yr, &ys[32 * i], mode)) return C_KZG_ERROR;
-        Fr zf = fe_from_raw<FrParams>(zr), yf = fe_from_raw<FrParams>(yr);
-        fe_to_raw<FrParams>(t, rp);
-        raw_to_be<8>(&sc_r[32 * i], t);
-        fe_to_raw<FrParams>(t, rp * zf);
-        raw_to_be<8>(&sc_rz[32 * i], t);
-        ysum = ysum + rp * yf;
-        rp = rp * rf;
+        uint32_t zr[8], yr[8];
+        if (le) {
+            raw_from_le<8>(zr, &zs[32 * i]);
+            raw_from_le<8>(yr, &ys[32 * i]);
+        } else {
+            raw_from_be<8>(zr, &zs[32 * i]);
+            raw_from_be<8>(yr, &ys[32 * i]);
+        }
+        if (raw_geq<8>(zr, FrParams::MOD) || raw_geq<8>(yr, FrParams::MOD)) return C_KZG_ERROR;  // the GPU wrote canonical values
+        hfr_to_be(&sc_r[32 * i], rp * one_raw);
+        hfr_to_be(&sc_rz[32 * i], rp * hfr_raw(zr));
+        ysum = ysum + rp * hfr_raw(yr);
+        rp = rp * r_mont;
     }
     const auto t2 = now();
     // three variable-base linear combinations on the GPU (g1_lincomb, lib.rs:679-685)
@@ -332,7 +354,10 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     HostPoint g;
     if (!setup_generator(g, s)) return C_KZG_ERROR;
     uint32_t ys_raw[8];
-    fe_to_raw<FrParams>(ys_raw, ysum);
+    for (int k = 0; k < 4; k++) {
+        ys_raw[2 * k] = (uint32_t)ysum.l[k];
+        ys_raw[2 * k + 1] = (uint32_t)(ysum.l[k] >> 32);
+    }
     HXyzz rhs = xyzz_add(c_lincomb, xyzz_neg(scalar_mul(to_xyzz(g), ys_raw)));
     rhs = xyzz_add(rhs, proof_z_lincomb);
     rc = pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
