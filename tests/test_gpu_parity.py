@@ -572,6 +572,24 @@ def test_c_consumer_links_and_matches_oracle(K, oracle, oracle_setup, tmp_path):
     assert kv["g1_0_x_limb0"] == "17f1d3a73197d794"
 
 
+def test_reference_lib_test_rs_mirror_in_c(K, tmp_path):
+    """tests/lib_test_mirror.c: the reference's own integration tests (tests/lib_test.rs) as a C program against the
+    drop-in library -- all nine symbols, incl. load_trusted_setup from bytes and verify_blob_kzg_proof_batch"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "lib")
+    exe = str(tmp_path / "lib_test_mirror")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "lib_test_mirror.c"), "-o", exe, "-L", lib_dir, "-llambdaworks_kzg",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ)
+    env.pop("LWKZG_MODE", None)
+    out = subprocess.run([exe, SETUP_PATH], env=env, timeout=300, capture_output=True)
+    assert out.returncode == 0, out.stderr.decode()
+    assert b"all assertions held" in out.stdout
+
+
 def test_noncanonical_infinity_commitment_takes_gpu_hash_fallback(K, gpu_setup, oracle, oracle_setup):
     """decompress_g1_point does not inspect the remaining bits of an infinity encoding (compression.rs:73-75) and
     compute_challenge hashes the RE-compressed point (utils.rs:138): a commitment 0xc0 | junk must hash as c0 00..00.
