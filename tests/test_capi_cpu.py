@@ -143,3 +143,15 @@ def test_direct_table_plan_constants(K):
     for bits in (14, 15, 16):   # every scalar bit is covered exactly once: (NW - 1) * bits + top == 255
         nw = l.lwkzg_direct_num_windows(bits)
         assert 0 < 255 - bits * (nw - 1) <= bits
+
+
+def test_c_consumers_compile_and_link_against_the_header_and_library(tmp_path):
+    """the two C programs of tests/ (the fuzz-harness-style consumer and the lib_test.rs mirror) build against
+    include/lambdaworks_kzg_amd.h and link against the shared library with a plain C compiler; running them needs a GPU"""
+    lib_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "lib")
+    for src in ("c_abi_harness.c", "lib_test_mirror.c"):
+        exe = str(tmp_path / src.replace(".c", ""))
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", src), "-o", exe, "-L", lib_dir, "-llambdaworks_kzg",
+                               "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+        assert os.path.exists(exe)
