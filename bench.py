@@ -110,8 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BLOBS_PER_GPU, help="blobs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof", "verify_batch"],
-                    help="commit = the headline (BASELINE configs[1]); blob_proof = configs[2]; verify_batch = configs[3], host-pointer ABI")
+    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof", "verify_batch", "tiled_msm"],
+                    help="commit = the headline (BASELINE configs[1]); blob_proof = configs[2]; verify_batch = configs[3], host-pointer ABI; tiled_msm = configs[4], one 2^20-term MSM split over the GPUs (strong scaling)")
     ap.add_argument("--mode", default="reference", choices=["reference", "ckzg"],
                     help="reference = lambdaworks_kzg semantics (default, the headline); ckzg = c-kzg-4844 semantics (adds the inverse NTT)")
     ap.add_argument("--direct-bits", default="auto",
@@ -186,9 +186,13 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     h_blobs = h_comms = h_proofs = None
+    d_tiles = None
+    tiles_total = 256                      # 2^20 terms over the setup tiled 256 times
 
     def step():
-        if args.op == "verify_batch":   # each rank verifies its shard as an independent batch, one all_reduce of the verdict
+        if args.op == "tiled_msm":      # each rank sums its share of the tiles, one all_gather of 48-byte partial sums
+            D.msm_tiled_sharded(d_tiles, int(d_tiles.numel()) // 32, ts, dev)
+        elif args.op == "verify_batch":   # each rank verifies its shard as an independent batch, one all_reduce of the verdict
             assert D.verify_blob_kzg_proof_batch_sharded(h_blobs, h_comms, h_proofs, n, ts)
         elif args.op == "commit":
             K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
@@ -201,6 +205,10 @@ def main():
         K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
         torch.cuda.synchronize(dev)
 
+    if args.op == "tiled_msm":
+        t_first, t_cnt = D.shard_range(tiles_total, world, rank)
+        tiles = np.frombuffer(B.synthetic_batch(5000 + t_first, t_cnt), dtype=np.uint8)   # canonical 248-bit scalars, big-endian
+        d_tiles = torch.from_numpy(tiles.copy()).to(dev)
     if args.op == "verify_batch":      # inputs of the host-pointer ABI: blobs, commitments and proofs in host memory
         h_blobs = host.tobytes()
         h_comms = b"".join(K.blob_to_kzg_commitment_batch(h_blobs, ts))
@@ -233,6 +241,8 @@ def main():
     if rank == 0:
         total_blobs = n * world * args.steps
         value = total_blobs / elapsed
+        if args.op == "tiled_msm":
+            value = tiles_total * 4096 * args.steps / elapsed      # terms per second, whole job
         dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
         if args.op == "verify_batch":   # no MSM here: the longest kernel of the per-blob pass is the one priced
             dom = max(prof, key=lambda kk: prof[kk]["total_ms"]) if prof else dom
@@ -242,6 +252,8 @@ def main():
         # the units one launch processes = blobs per step / launches per step
         launches_per_step = max(1, round(k["launches"] / max(1, args.steps)))
         msms_per_launch = n / launches_per_step
+        if args.op == "tiled_msm":    # a tile is one 4096-term MSM; rank 0's share of the tiles per launch
+            msms_per_launch = D.shard_range(tiles_total, world, 0)[1] / launches_per_step
         achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
         # integer picture: a mixed add is 6 Montgomery products (392 v_mad_u64_u32 each on 14 limbs of 28 bits), 2 squares
@@ -274,15 +286,16 @@ def main():
         res = {
             "metric": {"commit": "blob_to_kzg_commitment ops/sec (4096-elem blobs)",
                        "blob_proof": "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
-                       "verify_batch": "verify_blob_kzg_proof_batch blobs/sec (4096-elem blobs, host-pointer ABI, PCIe included)"}[args.op],
+                       "verify_batch": "verify_blob_kzg_proof_batch blobs/sec (4096-elem blobs, host-pointer ABI, PCIe included)",
+                       "tiled_msm": "G1 MSM terms/sec (one 2^20-term MSM over the tiled setup)"}[args.op],
             "value": value,
-            "unit": "ops/s",
+            "unit": "terms/s" if args.op == "tiled_msm" else "ops/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.op == "tiled_msm" else "weak",
             "vs_baseline": None,
             "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery, integer)",
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
@@ -291,7 +304,9 @@ def main():
                                    "blob_proof": "BASELINE configs[2]: compute_blob_kzg_proof (Fiat-Shamir hash, quotient, MSM), batch=%d synthetic "
                                                  "blobs per GPU per step, device-resident",
                                    "verify_batch": "BASELINE configs[3]: verify_blob_kzg_proof_batch, %d synthetic blobs per GPU per step verified as "
-                                                   "one batch per GPU, blobs in host memory (H2D inside the timed region)"}[args.op] % n,
+                                                   "one batch per GPU, blobs in host memory (H2D inside the timed region)",
+                                   "tiled_msm": "BASELINE configs[4]: one 2^20-term G1 MSM over the setup tiled 256 times, tiles split over "
+                                                "the GPUs, partial sums gathered and added on the host (%d is unused here)"}[args.op] % n,
                        "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
