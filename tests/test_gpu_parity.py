@@ -733,3 +733,19 @@ def test_verify_long_batch_pipelined_path(K, gpu_setup):
     with pytest.raises(K.KzgError) as e:
         K.verify_blob_kzg_proof_batch(data, bytes(badc), proofs, n, gpu_setup)
     assert e.value.rc == K.C_KZG_ERROR
+
+
+def test_direct_table_that_does_not_fit_leaves_the_default_engine(K, direct_setup, gpu_setup):
+    """a second settings object asking for a table the device can no longer hold gets C_KZG_MALLOC and keeps working on
+    the bucket path (only meaningful while the 240 GB table of the fixture is resident)"""
+    ts, bits = direct_setup
+    if bits != 16:
+        pytest.skip("needs the 240 GB table resident")
+    other = K.TrustedSetup.from_file(SETUP_PATH)
+    with pytest.raises(K.KzgError) as e:
+        other.enable_direct_table(16)
+    assert e.value.rc == K.C_KZG_MALLOC
+    assert other.direct_table_bits() == 0
+    blob = B.synthetic_blob(31337)
+    assert K.blob_to_kzg_commitment(blob, other) == K.blob_to_kzg_commitment(blob, ts) == K.blob_to_kzg_commitment(blob, gpu_setup)
+    other.free()
