@@ -167,7 +167,9 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
  * bit-identical to the default path. window_bits = 0 frees the table and returns to the default path.
  * Returns C_KZG_MALLOC (engine unchanged, default path still usable) when the table does not fit, C_KZG_BADARGS for
  * other widths. Replaces nothing in the reference: lambdaworks' pippenger::msm (call sites src/lib.rs:242,270,329,394)
- * has no precomputation at all. */
+ * has no precomputation at all. The environment variable LWKZG_DIRECT_BITS=14|15|16|auto makes every
+ * load_trusted_setup* call do this itself (a table that does not fit is skipped silently), for consumers that only
+ * know the nine reference symbols. */
 C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits);
 int lwkzg_direct_table_bits(const KZGSettings *s);   /* 0 = default path, 14/15/16 = direct table live, -1 = bad settings */
 int lwkzg_direct_num_windows(int window_bits);       /* additions per scalar on the direct path (0 for other widths) */
