@@ -560,7 +560,7 @@ def test_c_consumer_links_and_matches_oracle(K, oracle, oracle_setup, tmp_path):
     bpath.write_bytes(blob)
     env = dict(os.environ)
     env.pop("LWKZG_MODE", None)
-    out = subprocess.check_output([exe, SETUP_PATH, str(bpath)], env=env, timeout=300).decode().split("\n")
+    out = subprocess.check_output([exe, SETUP_PATH, str(bpath)], env=env, timeout=1200).decode().split("\n")
     kv = dict(l.split(" ", 1) for l in out if " " in l)
     rc, cm = oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_R)
     assert kv["commitment"] == cm.hex()
@@ -585,7 +585,7 @@ def test_reference_lib_test_rs_mirror_in_c(K, tmp_path):
                            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     env = dict(os.environ)
     env.pop("LWKZG_MODE", None)
-    out = subprocess.run([exe, SETUP_PATH], env=env, timeout=300, capture_output=True)
+    out = subprocess.run([exe, SETUP_PATH], env=env, timeout=1200, capture_output=True)
     assert out.returncode == 0, out.stderr.decode()
     assert b"all assertions held" in out.stdout
 
