@@ -215,17 +215,11 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->tw_fwd = c->tw_inv = nullptr;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
-    if (e == hipSuccess) {
-        // validation kernels (one latency-bound wave per 64 points) run beside the Fiat-Shamir kernel, whose four waves
-        // per workgroup fill a CU's SIMDs; a wave of each on one SIMD halves both. The validation stream is therefore
-        // confined to the upper half of every XCD's CUs, away from where a small grid's workgroups are placed.
-        uint32_t mask[8];
-        for (int k = 0; k < 8; k++) mask[k] = 0xffff0000u;
-        if (hipExtStreamCreateWithCUMask(&c->vstream, 8, mask) != hipSuccess) {
-            (void)hipGetLastError();
-            e = hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking);
-        }
-    }
+    // validation kernels get a stream of their own. (A CU-masked stream -- hipExtStreamCreateWithCUMask, upper half of
+    // every XCD, which keeps these one-wave-per-SIMD kernels off the SIMDs of the Fiat-Shamir kernel and was worth 4 % on
+    // 1024-proof batches -- made free_trusted_setup hang in about half the runs whenever a second process was using
+    // the GPU, and was removed.)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     for (int k = 0; k < kMaxSplit && e == hipSuccess; k++) {
         e = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);

@@ -13,6 +13,7 @@
 
 #define CHECK(cond)                                                        \
     do {                                                                   \
+        if (getenv("MIRROR_TRACE")) fprintf(stderr, "line %d\n", __LINE__);   \
         if (!(cond)) {                                                     \
             fprintf(stderr, "line %d: %s failed (%s)\n", __LINE__, #cond, lwkzg_last_error()); \
             return 1;                                                      \
