@@ -491,13 +491,17 @@ def test_load_free_cycles_and_two_settings(K, oracle, oracle_setup):
     """load/free repeatedly (no leaked device state), and two live settings objects used alternately"""
     import torch
     from conftest import SETUP_PATH
-    free0 = torch.cuda.mem_get_info()[0]
-    for _ in range(3):
+    def cycle():
         ts = K.TrustedSetup.from_file(SETUP_PATH)
         assert K.blob_to_kzg_commitment(B.synthetic_blob(1), ts) == tau_closed_form(oracle, B.blob_scalars(B.synthetic_blob(1)))
         ts.free()
-    torch.cuda.synchronize()
-    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)      # nothing substantial left behind
+        torch.cuda.synchronize()
+    for _ in range(2):       # the runtime's own stream / signal pools fill during the first two cycles and stay (tools/leak_check.py)
+        cycle()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(4):
+        cycle()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (32 << 20)      # nothing left behind per cycle
     a, b = K.TrustedSetup.from_file(SETUP_PATH), K.TrustedSetup.from_bytes(oracle_setup.g1_compressed(), oracle_setup.g2_compressed())
     blob = B.synthetic_blob(2)
     assert K.blob_to_kzg_commitment(blob, a) == K.blob_to_kzg_commitment(blob, b)
