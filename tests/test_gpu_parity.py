@@ -753,3 +753,36 @@ def test_direct_table_that_does_not_fit_leaves_the_default_engine(K, direct_setu
     blob = B.synthetic_blob(31337)
     assert K.blob_to_kzg_commitment(blob, other) == K.blob_to_kzg_commitment(blob, ts) == K.blob_to_kzg_commitment(blob, gpu_setup)
     other.free()
+
+
+def test_concurrent_callers_on_one_settings_object(K, gpu_setup):
+    """the reference's KZGSettings is read-only after load, so callers may share it across threads (SURVEY 8b);
+    here calls serialise on the context's mutexes: four threads mixing commitments, proofs and verifications must get
+    exactly the single-threaded answers, with no deadlock between the verify-side and the engine locks"""
+    import threading
+    blobs = [B.synthetic_blob(600 + i) for i in range(6)]
+    comms = [K.blob_to_kzg_commitment(b, gpu_setup) for b in blobs]
+    proofs = [K.compute_blob_kzg_proof(b, c, gpu_setup) for b, c in zip(blobs, comms)]
+    joined = (b"".join(blobs), b"".join(comms), b"".join(proofs))
+    errors = []
+
+    def worker(seed):
+        try:
+            for it in range(6):
+                i = (seed + it) % 6
+                assert K.blob_to_kzg_commitment(blobs[i], gpu_setup) == comms[i]
+                assert K.compute_blob_kzg_proof(blobs[i], comms[i], gpu_setup) == proofs[i]
+                assert K.verify_blob_kzg_proof(blobs[i], comms[i], proofs[i], gpu_setup) is True
+                assert K.verify_blob_kzg_proof(blobs[i], comms[i], proofs[(i + 1) % 6], gpu_setup) is False
+                assert K.verify_blob_kzg_proof_batch(joined[0], joined[1], joined[2], 6, gpu_setup) is True
+                assert K.blob_to_kzg_commitment_batch(joined[0], gpu_setup) == comms
+        except Exception as e:      # pragma: no cover - reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert errors == []
