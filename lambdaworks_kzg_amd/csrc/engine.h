@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "../../include/lambdaworks_kzg_amd.h"
 #include "kernels.h"
 
@@ -56,8 +57,16 @@ struct VerifyBuffers {
     uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
     G1Xyzz29 *d_part = nullptr;
     int32_t *d_inf = nullptr;
+    // small batches validated on the host threads keep their points here instead (n commitments, then n proofs; kind 0 =
+    // affine point, 1 = infinity) and the linear combinations run on the host threads too (verify.hip)
+    std::vector<G1Affine29> h_aff;
+    std::vector<int32_t> h_kind;
     std::unique_lock<std::mutex> hold;
 };
+
+// Up to this many blobs a verification / proof call validates its points on the host threads: ~0.2 ms per point per
+// thread against a 2 ms latency-shaped kernel. 4 per usable hardware thread, at most 64.
+size_t host_small_batch_limit();
 
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {

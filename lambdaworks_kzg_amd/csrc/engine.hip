@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <map>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -549,12 +550,20 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
     LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
     LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, n * 48, hipMemcpyHostToDevice, sv));
     launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p);
-    LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, sv));
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c);
-    LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));
-    bool validated = false;                                     // host has waited for it once
+    // the canonical bytes come back the first time the host needs them: a device-to-host copy into pageable memory
+    // blocks this thread until the stream has reached it, and the first slices should be on their way by then
+    bool validated = false;
+    auto fetch_canon = [&]() -> C_KZG_RET {
+        if (validated) return C_KZG_OK;
+        LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipStreamSynchronize(st));
+        validated = true;
+        return C_KZG_OK;
+    };
 
     struct Slot {
         bool used = false;
@@ -590,9 +599,9 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         const size_t base = s.base, off = s.off, m = s.m;
         hipStream_t sk = s.sk;
         s.hasher.join();
-        if (!validated) {  // canonical bytes are on the host from here on
-            LWK_HIP(hipStreamSynchronize(st));
-            validated = true;
+        {
+            C_KZG_RET rcf = fetch_canon();
+            if (rcf != C_KZG_OK) return rcf;
         }
         Fr *d_z = w.z + base;
         uint8_t *d_zb = w.zbytes + 32 * base, *d_yb = w.ybytes + 32 * base;
@@ -627,7 +636,10 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
     }
     hipStreamSynchronize(c->aux[0]);
     hipStreamSynchronize(c->aux[1]);
-    if (!validated) LWK_HIP(hipStreamSynchronize(st));
+    {
+        C_KZG_RET rcf = fetch_canon();
+        if (rcf != C_KZG_OK) return rcf;
+    }
     if (rc_all != C_KZG_OK) return rc_all;
     return first_status(c, vb.status_all, n, st);  // the validation's verdicts
 }
@@ -678,7 +690,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
         // up to 64 blobs: both point sets are validated on the host threads (0.2 ms per point per thread against a 2 ms
         // latency-shaped kernel) and the decompressed points uploaded in the form the kernel would have left
-        const bool host_validate = !trusted_canon_c && n <= 64;
+        const bool host_validate = !trusted_canon_c && n <= host_small_batch_limit();
         if (proofs48 && !host_validate) {
             // the proofs' validation (a 2 ms latency-shaped kernel) runs beside the commitments' on an auxiliary stream;
             // both only ever write the same failure code into status
@@ -687,7 +699,6 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             LWK_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
             LWK_HIP(hipMemcpyAsync(vb.proof_in + 48 * off, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, sa));
             launch_validate_commitments(vb.proof_in + 48 * off, w.out48, w.status, bad, m, sa, vb.pts_p + off, vb.kind_p + off);
-            LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, sa));
             LWK_HIP(hipEventRecord(c->ev_join[0], sa));
         }
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
@@ -698,7 +709,6 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             hc = trusted_canon_c + 48 * off;
         } else if (!host_validate) {
             launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
-            LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
         }
         std::vector<int32_t> h_code(m, bad), h_kind;
         std::vector<G1Affine29> h_aff;
@@ -713,16 +723,19 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
                 h_kind[i] = vrc[i];
                 if (vrc[i] == 2) LWK_HIP(hipMemcpyAsync(w.status + (i % m), &h_code[i % m], 4, hipMemcpyHostToDevice, st));
             }
-            LWK_HIP(hipMemcpyAsync(vb.pts_c + off, h_aff.data(), m * sizeof(G1Affine29), hipMemcpyHostToDevice, st));
-            LWK_HIP(hipMemcpyAsync(vb.kind_c + off, h_kind.data(), m * 4, hipMemcpyHostToDevice, st));
-            if (proofs48) {
-                LWK_HIP(hipMemcpyAsync(vb.pts_p + off, h_aff.data() + m, m * sizeof(G1Affine29), hipMemcpyHostToDevice, st));
-                LWK_HIP(hipMemcpyAsync(vb.kind_p + off, h_kind.data() + m, m * 4, hipMemcpyHostToDevice, st));
+            if (proofs48) {  // the linear combinations of so few points run on the host threads as well
+                vb.h_aff = std::move(h_aff);
+                vb.h_kind = std::move(h_kind);
             }
         }
         if (proofs48 && !host_validate) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         if (hash_beside) hasher.join();
         else challenge_digests_host(dig.data(), hb, hash_comm, m);
+        // device-to-host copies into pageable memory block this thread until the stream has reached them, so the
+        // canonical bytes are fetched only after every launch above has been submitted
+        if (!trusted_canon_c && !host_validate)
+            LWK_HIP(hipMemcpyAsync(canon_c + 48 * off, w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        if (proofs48 && !host_validate) LWK_HIP(hipMemcpyAsync(canon_p + 48 * off, w.out48, m * 48, hipMemcpyDeviceToHost, st));
         LWK_HIP(hipStreamSynchronize(st));
         if (memcmp(canon_c + 48 * off, hc, m * 48) == 0) {
             LWK_HIP(hipMemcpyAsync(w.zbytes, dig.data(), m * 32, hipMemcpyHostToDevice, st));
@@ -1114,6 +1127,187 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
     return C_KZG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long host batches of proofs (512 blobs and up) stream through in slices of 512 blobs, like the commitments above:
+// slice k uses half k mod 2 of the workspace on stream k mod 2, so the pageable H2D copy of slice k + 1 (which blocks
+// this thread while it is staged) runs beside the GPU's work on slice k. Results and verdicts of all slices stay on
+// the device until the end. The caller holds c->mu.
+
+namespace {
+
+struct DevBlock {  // one device allocation carved into 256-byte aligned pieces
+    uint8_t *base = nullptr;
+    size_t used = 0, cap = 0;
+    ~DevBlock() { if (base) hipFree(base); }
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+    bool alloc(size_t bytes) {
+        cap = bytes;
+        if (hipMalloc((void **)&base, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            base = nullptr;
+            return false;
+        }
+        return true;
+    }
+    uint8_t *take(size_t bytes) {
+        uint8_t *p = base + used;
+        used += pad(bytes);
+        return p;
+    }
+};
+
+C_KZG_RET scan_status(const std::vector<int32_t> &h_status, size_t *first_bad, int mode) {
+    for (size_t i = 0; i < h_status.size(); i++)
+        if (h_status[i] != 0) {
+            if (first_bad) *first_bad = i;
+            set_error("blob %zu rejected (status %d)", i, h_status[i]);
+            return map_rc((C_KZG_RET)h_status[i], mode);
+        }
+    return C_KZG_OK;
+}
+
+C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, const uint8_t *blobs, const uint8_t *zs, size_t n,
+                              int mode, size_t *first_bad) {
+    constexpr size_t kSlice = kMaxChunk / 2;
+    const int le = mode == LWKZG_MODE_CKZG;
+    C_KZG_RET rc = ctx_reserve(c, kMaxChunk);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    DevBlock blk;
+    if (!blk.alloc(DevBlock::pad(n * 48) + 2 * DevBlock::pad(n * 32) + DevBlock::pad(n * 4))) {
+        set_error("lwkzg_compute_kzg_proof_batch: out of device memory for %zu results", n);
+        return C_KZG_MALLOC;
+    }
+    uint8_t *d_out = blk.take(n * 48), *d_y = blk.take(n * 32), *d_z = blk.take(n * 32);
+    int32_t *d_status = (int32_t *)blk.take(n * 4);
+    std::vector<int32_t> h_status(n);
+    hipStream_t st = c->stream;
+    LWK_HIP(hipMemcpyAsync(d_z, zs, n * 32, hipMemcpyHostToDevice, st));
+    LWK_HIP(hipMemsetAsync(d_status, 0, n * 4, st));
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    size_t k = 0;
+    for (size_t off = 0; off < n; off += kSlice, k++) {
+        const size_t cnt = n - off < kSlice ? n - off : kSlice;
+        const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
+        hipStream_t sk = c->aux[k & 1];
+        uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
+        LWK_HIP(hipMemcpyAsync(d_blobs, blobs + off * (size_t)kBlobBytes, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
+        coefficients_stage(c, d_blobs, cnt, mode, d_status + off, sk, lo);
+        launch_z_from_bytes(d_z + 32 * off, w.z + lo, d_status + off, le, cnt, sk);
+        launch_eval_quotient(w.scalars + so, w.z + lo, w.scalars2 + so, d_y + 32 * off, le, cnt, sk);
+        msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo);
+    }
+    for (int j = 0; j < 2; j++) {
+        LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[j], 0));
+    }
+    std::vector<uint8_t> h_out(n * 48), h_y(n * 32);  // the caller's buffers are only written on success
+    LWK_HIP(hipMemcpyAsync(h_out.data(), d_out, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(h_y.data(), d_y, n * 32, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(h_status.data(), d_status, n * 4, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipStreamSynchronize(st));
+    rc = scan_status(h_status, first_bad, mode);
+    if (rc != C_KZG_OK) return rc;
+    memcpy(proofs_out, h_out.data(), n * 48);
+    memcpy(ys_out, h_y.data(), n * 32);
+    return C_KZG_OK;
+}
+
+// compute_blob_kzg_proof for a long batch: every commitment is validated once up front on the validation stream (the
+// kernel is a ~2 ms latency chain whatever n is); the host threads hash slice k (the digests assume the caller's
+// commitment bytes are canonical) while it is copied; the canonical bytes decide per slice between those digests and
+// the GPU hash over the canonical encoding.
+C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode,
+                             size_t *first_bad) {
+    constexpr size_t kSlice = kMaxChunk / 2;
+    const int le = mode == LWKZG_MODE_CKZG;
+    C_KZG_RET rc = ctx_reserve(c, kMaxChunk);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    DevBlock blk;
+    if (!blk.alloc(3 * DevBlock::pad(n * 48) + DevBlock::pad(n * 32) + DevBlock::pad(n * 4))) {
+        set_error("lwkzg_compute_blob_kzg_proof_batch: out of device memory for %zu results", n);
+        return C_KZG_MALLOC;
+    }
+    static const bool timing = getenv("LWKZG_TIMING") != nullptr;  // phase wall-clock to stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    uint8_t *d_out = blk.take(n * 48), *d_comm = blk.take(n * 48), *d_canon = blk.take(n * 48);
+    uint8_t *d_dig = blk.take(n * 32);
+    int32_t *d_status = (int32_t *)blk.take(n * 4);
+    std::vector<int32_t> h_status(n);
+    std::vector<uint8_t> h_canon(n * 48), h_dig(n * 32);
+    hipStream_t st = c->stream, sv = c->vstream;
+    LWK_HIP(hipMemsetAsync(d_status, 0, n * 4, st));
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    LWK_HIP(hipMemcpyAsync(d_comm, comm48, n * 48, hipMemcpyHostToDevice, sv));
+    launch_validate_commitments(d_comm, d_canon, d_status, le ? kStatusBadArgs : kStatusError, n, sv);  // lib.rs:372-375
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
+    bool validated = false;
+    size_t k = 0;
+    for (size_t off = 0; off < n; off += kSlice, k++) {
+        const size_t cnt = n - off < kSlice ? n - off : kSlice;
+        const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
+        hipStream_t sk = c->aux[k & 1];
+        uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
+        const uint8_t *hb = blobs + off * (size_t)kBlobBytes, *hc = comm48 + 48 * off;
+        uint8_t *dig = h_dig.data() + 32 * off;
+        std::thread hasher([=]() { challenge_digests_host(dig, hb, hc, cnt); });
+        struct Joiner {
+            std::thread &t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } joiner{hasher};
+        const auto ta = now();
+        LWK_HIP(hipMemcpyAsync(d_blobs, hb, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
+        const auto tb = now();
+        coefficients_stage(c, d_blobs, cnt, mode, d_status + off, sk, lo);
+        hasher.join();
+        const auto tc = now();
+        if (timing) fprintf(stderr, "[blob_proofs_sliced] slice %zu at %.2f ms: h2d %.2f ms, hash wait %.2f ms\n", k, ms(t0, ta), ms(ta, tb), ms(tb, tc));
+        if (!validated) {
+            // A device-to-host copy into pageable memory blocks this thread until the stream has reached it, so the
+            // canonical bytes are only fetched here, after the first slice has been submitted. From here on they are
+            // on the host, and the slice streams may read d_canon.
+            LWK_HIP(hipMemcpyAsync(h_canon.data(), d_canon, n * 48, hipMemcpyDeviceToHost, sv));
+            LWK_HIP(hipStreamSynchronize(sv));
+            validated = true;
+        }
+        if (memcmp(h_canon.data() + 48 * off, hc, cnt * 48) == 0) {
+            LWK_HIP(hipMemcpyAsync(d_dig + 32 * off, dig, cnt * 32, hipMemcpyHostToDevice, sk));
+            launch_z_from_bytes(d_dig + 32 * off, w.z + lo, nullptr, le, cnt, sk);  // digest -> Fr, reduced (utils.rs:148-154)
+        } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
+            launch_challenge(d_blobs, d_canon + 48 * off, w.z + lo, le, cnt, sk);
+        }
+        launch_eval_quotient(w.scalars + so, w.z + lo, w.scalars2 + so, nullptr, le, cnt, sk);
+        msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo);
+    }
+    for (int j = 0; j < 2; j++) {
+        LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[j], 0));
+    }
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));
+    std::vector<uint8_t> h_out(n * 48);
+    LWK_HIP(hipMemcpyAsync(h_out.data(), d_out, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(h_status.data(), d_status, n * 4, hipMemcpyDeviceToHost, st));
+    const auto td = now();
+    LWK_HIP(hipStreamSynchronize(st));
+    if (timing) fprintf(stderr, "[blob_proofs_sliced] n=%zu: submitted at %.2f ms, drained at %.2f ms\n", n, ms(t0, td), ms(t0, now()));
+    rc = scan_status(h_status, first_bad, mode);
+    if (rc != C_KZG_OK) return rc;
+    memcpy(out, h_out.data(), n * 48);
+    return C_KZG_OK;
+}
+
+}  // namespace
+
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
                                              const KZGSettings *s, size_t *first_bad) {
     const int mode = mode_now();
@@ -1122,6 +1316,8 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
+    if (n >= kMaxChunk / 2)
+        return blob_proofs_sliced(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, n, mode, first_bad);
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         C_KZG_RET rc = ctx_reserve(c, m);
@@ -1147,13 +1343,12 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         // canonical bytes are only needed at the very end. Up to 64 points: on the host threads while the GPU works
         // (~0.2 ms each on the 64-bit host field, against a 2 ms latency-shaped kernel). A batch: on the GPU, on an
         // auxiliary stream beside everything else.
-        const bool host_validate = m <= 64;
+        const bool host_validate = m <= host_small_batch_limit();
         std::vector<int32_t> h_code(m, le ? kStatusBadArgs : kStatusError);
         if (!host_validate) {
             LWK_HIP(hipEventRecord(c->ev_fork, st));
             LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
             launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, c->vstream);
-            LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, c->vstream));
             LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         }
         // GPU, main stream: parse the blobs, then the digests as soon as the host threads have them
@@ -1169,7 +1364,12 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
         msm_stages(c, w.scalars2, w.out48, m, st);
-        if (!host_validate) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        if (!host_validate) {
+            // (a device-to-host copy into pageable memory blocks this thread until the stream has reached it: the
+            // canonical bytes are fetched only now that everything else has been submitted)
+            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+            LWK_HIP(hipMemcpyAsync(h_canon.data(), w.canon48, m * 48, hipMemcpyDeviceToHost, st));
+        }
         LWK_HIP(hipStreamSynchronize(st));
         if (memcmp(h_canon.data(), h_comm, m * 48) != 0) {
             // a non-canonical but valid encoding somewhere in the chunk (or an invalid point, reported through
@@ -1196,6 +1396,9 @@ C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, c
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
+    if (n >= kMaxChunk / 2)
+        return point_proofs_sliced(c, (uint8_t *)proofs_out, (uint8_t *)ys_out, (const uint8_t *)blobs, (const uint8_t *)zs, n, mode,
+                                   first_bad);
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         C_KZG_RET rc = ctx_reserve(c, m);

@@ -154,7 +154,7 @@ void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len) {
 }
 
 // hardware threads this process may really use (shared with the host-side validation of verify.hip)
-unsigned host_threads() {
+static unsigned probe_host_threads() {
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
     // respect a cgroup CPU quota (containers expose every hardware thread but allow far fewer)
@@ -169,6 +169,16 @@ unsigned host_threads() {
         fclose(f);
     }
     return n > 32 ? 32 : n;
+}
+
+unsigned host_threads() {
+    static const unsigned n = probe_host_threads();
+    return n;
+}
+
+size_t host_small_batch_limit() {
+    const size_t lim = 4 * (size_t)host_threads();
+    return lim > 64 ? 64 : lim;
 }
 
 

@@ -25,6 +25,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
 bool pairing_check_compressed(const uint8_t *g1s, const uint8_t *g2s, int n, bool *ok);
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len);  // sha256_host.hip: SHA extensions when present
+unsigned host_threads();  // sha256_host.hip: hardware threads capped by the cgroup quota
 
 namespace {
 
@@ -143,10 +144,63 @@ C_KZG_RET verify_core(bool *ok, const HostPoint &c, const uint32_t z[8], const u
         set_error("g1_values[0] is not a curve point");
         return C_KZG_ERROR;
     }
-    HXyzz lhs = to_xyzz(c);
-    lhs = xyzz_add(lhs, xyzz_neg(scalar_mul(to_xyzz(g), y)));  // C - [y]G
-    lhs = xyzz_add(lhs, scalar_mul(to_xyzz(pi), z));            //   + [z]pi
+    HXyzz zpi;
+    std::thread side([&]() { zpi = scalar_mul(to_xyzz(pi), z); });  // the two scalar multiplications side by side
+    HXyzz lhs = xyzz_add(to_xyzz(c), xyzz_neg(scalar_mul(to_xyzz(g), y)));  // C - [y]G
+    side.join();
+    lhs = xyzz_add(lhs, zpi);                                               //   + [z]pi
     return pairing_verdict(ok, lhs, to_xyzz(pi), s);
+}
+
+// The three linear combinations of a small batch on the host threads (g1_lincomb, lib.rs:679-685):
+//   out[0] = sum r_i pi_i,  out[1] = sum (r_i z_i) pi_i,  out[2] = sum r_i C_i
+// over the points the host validation kept (aff/kind: n commitments, then n proofs). The 3n terms are dealt out in
+// contiguous runs, so a thread mostly works on one sum; within a run the terms share their doublings (Straus).
+void host_lincomb3(HXyzz out[3], const G1Affine29 *aff, const int32_t *kind, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n) {
+    struct Term {
+        HFp x, y;
+        uint32_t k[8];
+        int sum;
+    };
+    std::vector<Term> terms;
+    terms.reserve(3 * n);
+    for (int s = 0; s < 3; s++)
+        for (size_t i = 0; i < n; i++) {
+            const size_t p = s == 2 ? i : n + i;  // commitments first, then proofs
+            if (kind[p] != 0) continue;           // the point at infinity adds nothing
+            Term t;
+            t.x = HFp::from_fe(f29_to_fp(aff[p].x));
+            t.y = HFp::from_fe(f29_to_fp(aff[p].y));
+            raw_from_be<8>(t.k, (s == 1 ? sc_rz : sc_r) + 32 * i);
+            t.sum = s;
+            terms.push_back(t);
+        }
+    for (int s = 0; s < 3; s++) out[s] = HXyzz::infinity();
+    const size_t nterms = terms.size();
+    if (nterms == 0) return;
+    unsigned nt = host_threads();
+    if (nt > nterms) nt = (unsigned)nterms;
+    std::vector<HXyzz> part(3 * (size_t)nt, HXyzz::infinity());
+    auto run = [&](unsigned t) {
+        const size_t lo = nterms * t / nt, hi = nterms * (t + 1) / nt;
+        HXyzz acc[3] = {HXyzz::infinity(), HXyzz::infinity(), HXyzz::infinity()};
+        for (int bit = 255; bit >= 0; bit--) {
+            for (int s = 0; s < 3; s++) acc[s] = xyzz_dbl(acc[s]);  // returns at once while a sum is still empty
+            for (size_t j = lo; j < hi; j++)
+                if ((terms[j].k[bit >> 5] >> (bit & 31)) & 1) acc[terms[j].sum] = xyzz_madd(acc[terms[j].sum], terms[j].x, terms[j].y);
+        }
+        for (int s = 0; s < 3; s++) part[3 * t + s] = acc[s];
+    };
+    if (nt <= 1) {
+        run(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(run, t);
+        run(0);
+        for (auto &x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; t++)
+        for (int s = 0; s < 3; s++) out[s] = xyzz_add(out[s], part[3 * t + s]);
 }
 
 int g_mode_now() { return lwkzg_get_mode(); }
@@ -156,8 +210,6 @@ C_KZG_RET bad(int mode) { return mode == LWKZG_MODE_CKZG ? C_KZG_BADARGS : C_KZG
 }  // namespace lwk
 
 namespace lwk {
-unsigned host_threads();  // sha256_host.hip: hardware threads capped by the cgroup quota
-
 int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48], G1Affine29 *aff) {
     HostPoint p;
     memset(canon48, 0, 48);
@@ -206,10 +258,15 @@ C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Byte
     HostPoint c, pi;
     uint32_t z[8], y[8];
     // order of the reference: commitment, z, y, proof (lib.rs:424-440)
-    if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return bad(mode); }
+    // (every failure here is the same return code, so the two decompressions may run side by side)
+    bool pi_ok = false;
+    std::thread side([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
+    const bool c_ok = host_g1_decompress(c, commitment_bytes->bytes);
+    side.join();
+    if (!c_ok) { set_error("invalid commitment"); return bad(mode); }
     if (!fr_from_bytes(z, z_bytes->bytes, mode)) { set_error("z is not canonical"); return bad(mode); }
     if (!fr_from_bytes(y, y_bytes->bytes, mode)) { set_error("y is not canonical"); return bad(mode); }
-    if (!host_g1_decompress(pi, proof_bytes->bytes)) { set_error("invalid proof"); return bad(mode); }
+    if (!pi_ok) { set_error("invalid proof"); return bad(mode); }
     return verify_core(ok, c, z, y, pi, s);
 }
 
@@ -223,8 +280,14 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     // lib.rs:473-478: both points are decompressed before the blob is parsed (in c-kzg every failure of this function
     // is BADARGS, so the order is not observable there). Decompressing here also validates: the per-blob GPU pass
     // below is told the commitment's canonical bytes instead of re-deriving them with a validation kernel.
+    // (the proof is decompressed by a second thread meanwhile, and through the GPU pass, which does not need it)
+    bool pi_ok = false;
+    std::thread side([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{side};
     if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return bad(mode); }
-    if (!host_g1_decompress(pi, proof_bytes->bytes)) { set_error("invalid proof"); return bad(mode); }
     uint8_t canon_in[48];
     if (c.inf) {
         memset(canon_in, 0, 48);
@@ -238,6 +301,8 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     VerifyBuffers vb;
     C_KZG_RET rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb,
                                        canon_in);
+    side.join();
+    if (!pi_ok) { set_error("invalid proof"); return bad(mode); }
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
     uint32_t z[8], y[8];
     if (!fr_from_bytes(z, zb, mode) || !fr_from_bytes(y, yb, mode)) return C_KZG_ERROR;
@@ -334,12 +399,20 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         rp = rp * r_mont;
     }
     const auto t2 = now();
-    // three variable-base linear combinations on the GPU (g1_lincomb, lib.rs:679-685)
+    // three variable-base linear combinations (g1_lincomb, lib.rs:679-685): on the GPU over the points the validation
+    // kernels left there, or on the host threads when the batch was small enough to be validated there
     uint8_t sums[3][96];
     int infs[3];
-    rc = lincomb3_device_host(ctx, vb, sc_r.data(), sc_rz.data(), n, sums, infs);
-    if (rc != C_KZG_OK) return C_KZG_ERROR;
+    HXyzz hsum[3];
+    const bool on_host = vb.h_aff.size() == 2 * n && vb.h_kind.size() == 2 * n;
+    if (on_host) {
+        host_lincomb3(hsum, vb.h_aff.data(), vb.h_kind.data(), sc_r.data(), sc_rz.data(), n);
+    } else {
+        rc = lincomb3_device_host(ctx, vb, sc_r.data(), sc_rz.data(), n, sums, infs);
+        if (rc != C_KZG_OK) return C_KZG_ERROR;
+    }
     auto load = [&](int k) {
+        if (on_host) return hsum[k];
         if (infs[k]) return HXyzz::infinity();
         uint32_t raw[12];
         G1Affine a;

@@ -786,3 +786,66 @@ def test_concurrent_callers_on_one_settings_object(K, gpu_setup):
         t.join(timeout=300)
     assert not any(t.is_alive() for t in threads), "deadlock"
     assert errors == []
+
+
+def test_long_host_proof_batches_are_sliced(K, gpu_setup):
+    """host-pointer proof batches of >= 512 blobs stream through in 512-blob slices on two streams with the commitments
+    validated once up front: same bytes as short calls over the same inputs; a non-canonical infinity encoding deep in
+    the batch still takes the hash over the canonical bytes; the first rejected input is reported by its index in the
+    whole batch"""
+    n, piece = 1100, 275
+    K.set_mode(K.MODE_REFERENCE)
+    data = B.synthetic_batch(5000, n)
+    comms = bytearray(b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup)))
+    junk = bytes([0xc0]) + bytes(range(1, 48))
+    comms[48 * 700:48 * 701] = junk                      # valid (infinity), not canonical, second slice
+    comms = bytes(comms)
+    blob = lambda i: data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
+    want = []
+    for lo in range(0, n, piece):                        # short calls: the single-pass path
+        want += K.compute_blob_kzg_proof_batch(data[lo * B.BYTES_PER_BLOB:(lo + piece) * B.BYTES_PER_BLOB],
+                                               comms[48 * lo:48 * (lo + piece)], gpu_setup)
+    got = K.compute_blob_kzg_proof_batch(data, comms, gpu_setup)
+    assert got == want
+    assert got[700] == K.compute_blob_kzg_proof(blob(700), bytes([0xc0]) + bytes(47), gpu_setup)
+    for i in (0, 511, 512, 1099):
+        assert K.verify_blob_kzg_proof(blob(i), comms[48 * i:48 * i + 48], got[i], gpu_setup) is True
+    # invalid commitment far into the batch, in front of another one
+    badc = bytearray(comms)
+    badc[48 * 900] &= 0x7f
+    badc[48 * 1000] &= 0x7f
+    out, bad = C.create_string_buffer(48 * n), C.c_size_t(9999)
+    rc = K.lib().lwkzg_compute_blob_kzg_proof_batch(out, data, bytes(badc), n, gpu_setup.ref(), C.byref(bad))
+    assert rc == K.C_KZG_ERROR and bad.value == 900
+    assert out.raw == bytes(48 * n)                      # nothing written on failure
+
+    # evaluation proofs at caller-chosen points
+    zs = b"".join(B.synthetic_blob(7000 + i)[:32] for i in range(n))
+    wantp = []
+    for lo in range(0, n, piece):
+        wantp += K.compute_kzg_proof_batch(data[lo * B.BYTES_PER_BLOB:(lo + piece) * B.BYTES_PER_BLOB],
+                                           zs[32 * lo:32 * (lo + piece)], gpu_setup)
+    gotp = K.compute_kzg_proof_batch(data, zs, gpu_setup)
+    assert gotp == wantp
+    for i in (3, 600, 1099):
+        assert K.verify_kzg_proof(comms[48 * i:48 * i + 48], zs[32 * i:32 * i + 32], gotp[i][1], gotp[i][0], gpu_setup) is True
+
+    # c-kzg mode: non-canonical blob element / evaluation point -> BADARGS with the first index
+    K.set_mode(K.MODE_CKZG)
+    try:
+        data_le = bytearray(B.synthetic_batch(5100, n, big_endian=False))
+        zs_le = bytearray(b"".join(B.synthetic_blob(7100 + i, big_endian=False)[:32] for i in range(n)))
+        good = K.compute_kzg_proof_batch(bytes(data_le), bytes(zs_le), gpu_setup)
+        short = K.compute_kzg_proof_batch(bytes(data_le[:300 * B.BYTES_PER_BLOB]), bytes(zs_le[:32 * 300]), gpu_setup)
+        assert good[:300] == short
+        zs_bad = bytearray(zs_le)
+        zs_bad[32 * 800:32 * 801] = b"\xff" * 32
+        data_bad = bytearray(data_le)
+        data_bad[1050 * B.BYTES_PER_BLOB:1051 * B.BYTES_PER_BLOB] = B.make_blob("all_ff")
+        outp, outy = C.create_string_buffer(48 * n), C.create_string_buffer(32 * n)
+        rc = K.lib().lwkzg_compute_kzg_proof_batch(outp, outy, bytes(data_bad), bytes(zs_bad), n, gpu_setup.ref(), C.byref(bad))
+        assert rc == K.C_KZG_BADARGS and bad.value == 800
+        rc = K.lib().lwkzg_compute_kzg_proof_batch(outp, outy, bytes(data_bad), bytes(zs_le), n, gpu_setup.ref(), C.byref(bad))
+        assert rc == K.C_KZG_BADARGS and bad.value == 1050
+    finally:
+        K.set_mode(K.MODE_REFERENCE)

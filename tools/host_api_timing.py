@@ -15,7 +15,7 @@ def best(fn, reps=3):
     return out, min(ts_)
 
 
-for n in (1, 16, 256, 1024):
+for n in (1, 16, 256, 512, 1024, 4096):
     data = B.synthetic_batch(0, n)
     K.blob_to_kzg_commitment_batch(data, ts)
     comms, tc = best(lambda: K.blob_to_kzg_commitment_batch(data, ts))
@@ -24,4 +24,7 @@ for n in (1, 16, 256, 1024):
     pr, tp = best(lambda: K.compute_blob_kzg_proof_batch(data, cm, ts))
     prj = b"".join(pr)
     ok, tv = best(lambda: K.verify_blob_kzg_proof_batch(data, cm, prj, n, ts))
-    print("host API n=%d (best of 3): commit %.2f ms (%.0f/s)  blob_proof %.2f ms (%.0f/s)  verify_batch %.2f ms ok=%s" % (n, tc*1e3, n/tc, tp*1e3, n/tp, tv*1e3, ok))
+    zs = data[:32 * n]
+    K.compute_kzg_proof_batch(data, zs, ts)
+    _, tz = best(lambda: K.compute_kzg_proof_batch(data, zs, ts))
+    print("host API n=%d (best of 3): commit %.2f ms (%.0f/s)  blob_proof %.2f ms (%.0f/s)  point_proof %.2f ms (%.0f/s)  verify_batch %.2f ms ok=%s" % (n, tc*1e3, n/tc, tp*1e3, n/tp, tz*1e3, n/tz, tv*1e3, ok))
