@@ -9,6 +9,12 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -182,23 +188,96 @@ size_t host_small_batch_limit() {
 }
 
 
-// digests[i] = SHA-256(header | blobs[i] | comms[i]) for i < n, spread over the host threads
-void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n) {
-    unsigned nt = host_threads();
-    if (nt > n) nt = (unsigned)n;
-    if (nt <= 1) {
-        for (size_t i = 0; i < n; i++) challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i);
+// ---- the host threads ----------------------------------------------------------------------------
+// Hashing, point validation and the small linear combinations are spread over host_threads() - 1 persistent workers
+// plus the calling thread: starting sixteen std::threads costs ~0.4 ms, several times the work of a small batch.
+// The workers sleep on a condition variable between calls and are never joined (the pool lives as long as the
+// process; a forked child gets a fresh one, since threads do not survive fork).
+namespace {
+
+class HostPool {
+  public:
+    explicit HostPool(unsigned workers) : pid_(getpid()) {
+        for (unsigned k = 0; k < workers; k++) std::thread([this]() { worker(); }).detach();
+    }
+    pid_t pid() const { return pid_; }
+
+    void run(size_t n, const std::function<void(size_t)> &fn) {
+        std::lock_guard<std::mutex> one_at_a_time(run_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            gen_++;
+        }
+        cv_work_.notify_all();
+        claim_loop(fn, n);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_gen_ = gen_;  // workers that wake up from here on skip this round
+        cv_done_.wait(lk, [this]() { return active_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void claim_loop(const std::function<void(size_t)> &fn, size_t n) {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) break;
+            fn(i);
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&]() { return gen_ != seen; });
+            seen = gen_;
+            if (done_gen_ == gen_) continue;
+            const std::function<void(size_t)> *fn = fn_;
+            const size_t n = n_;
+            active_++;
+            lk.unlock();
+            claim_loop(*fn, n);
+            lk.lock();
+            if (--active_ == 0) cv_done_.notify_all();
+        }
+    }
+
+    const pid_t pid_;
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0, done_gen_ = 0;
+    unsigned active_ = 0;
+};
+
+}  // namespace
+
+// fn(0) .. fn(n - 1), each exactly once, on the host threads (the caller works too); returns when all are done.
+// Calls from different threads take turns. fn must not call host_parallel_for itself.
+void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+    const unsigned nt = host_threads();
+    if (n <= 1 || nt <= 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
         return;
     }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) {
-        size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-        th.emplace_back([=]() {
-            for (size_t i = lo; i < hi; i++)
-                challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i);
-        });
+    static std::mutex pool_mu;
+    static HostPool *pool = nullptr;  // deliberately leaked: its workers are detached
+    HostPool *p;
+    {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if (!pool || pool->pid() != getpid()) pool = new HostPool(nt - 1);
+        p = pool;
     }
-    for (auto &t : th) t.join();
+    p->run(n, fn);
+}
+
+// digests[i] = SHA-256(header | blobs[i] | comms[i]) for i < n, spread over the host threads
+void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n) {
+    host_parallel_for(n, [=](size_t i) { challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i); });
 }
 
 }  // namespace lwk

@@ -16,6 +16,7 @@
 
 #include <string.h>
 
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -26,6 +27,7 @@ bool pairing_check_compressed(const uint8_t *g1s, const uint8_t *g2s, int n, boo
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len);  // sha256_host.hip: SHA extensions when present
 unsigned host_threads();  // sha256_host.hip: hardware threads capped by the cgroup quota
+void host_parallel_for(size_t n, const std::function<void(size_t)> &fn);  // sha256_host.hip: persistent workers
 
 namespace {
 
@@ -181,7 +183,7 @@ void host_lincomb3(HXyzz out[3], const G1Affine29 *aff, const int32_t *kind, con
     unsigned nt = host_threads();
     if (nt > nterms) nt = (unsigned)nterms;
     std::vector<HXyzz> part(3 * (size_t)nt, HXyzz::infinity());
-    auto run = [&](unsigned t) {
+    auto run = [&](size_t t) {
         const size_t lo = nterms * t / nt, hi = nterms * (t + 1) / nt;
         HXyzz acc[3] = {HXyzz::infinity(), HXyzz::infinity(), HXyzz::infinity()};
         for (int bit = 255; bit >= 0; bit--) {
@@ -191,14 +193,7 @@ void host_lincomb3(HXyzz out[3], const G1Affine29 *aff, const int32_t *kind, con
         }
         for (int s = 0; s < 3; s++) part[3 * t + s] = acc[s];
     };
-    if (nt <= 1) {
-        run(0);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(run, t);
-        run(0);
-        for (auto &x : th) x.join();
-    }
+    host_parallel_for(nt, run);
     for (unsigned t = 0; t < nt; t++)
         for (int s = 0; s < 3; s++) out[s] = xyzz_add(out[s], part[3 * t + s]);
 }
@@ -229,19 +224,7 @@ int host_validate_commitment(const uint8_t in48[48], uint8_t canon48[48], G1Affi
 
 // the same for n points, spread over the host threads (~0.2 ms per point per thread)
 void host_validate_commitments(const uint8_t *in48, uint8_t *canon48, int *rc, size_t n, G1Affine29 *aff) {
-    unsigned nt = host_threads();
-    if (nt > n) nt = (unsigned)n;
-    auto one = [=](size_t i) { rc[i] = host_validate_commitment(in48 + 48 * i, canon48 + 48 * i, aff ? aff + i : nullptr); };
-    if (nt <= 1) {
-        for (size_t i = 0; i < n; i++) one(i);
-        return;
-    }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([=]() {
-            for (size_t i = t; i < n; i += nt) one(i);
-        });
-    for (auto &x : th) x.join();
+    host_parallel_for(n, [=](size_t i) { rc[i] = host_validate_commitment(in48 + 48 * i, canon48 + 48 * i, aff ? aff + i : nullptr); });
 }
 }  // namespace lwk
 
