@@ -18,6 +18,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdio.h>
+
+#include <chrono>
+#include <memory>
+#include <mutex>
+#include <vector>
+
 namespace lwk {
 
 namespace {
@@ -76,6 +83,29 @@ struct H12 {
 inline H12 operator*(const H12 &a, const H12 &b) {
     H6 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
     return {t0 + mul_v(t1), (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1};
+}
+// a^2 by the complex method over Fp6[w]/(w^2 - v): two Fp6 products instead of three
+inline H12 f12sqr(const H12 &a) {
+    H6 ab = a.c0 * a.c1;
+    H6 t = (a.c0 + a.c1) * (a.c0 + mul_v(a.c1)) - ab - mul_v(ab);
+    return {t, ab + ab};
+}
+// f * (a + b v) in Fp6: five Fp2 products
+inline H6 f6mul_by_01(const H6 &f, const H2 &a, const H2 &b) {
+    H2 t0 = f.c0 * a, t1 = f.c1 * b;
+    H6 r;
+    r.c0 = t0 + mul_xi((f.c1 + f.c2) * b - t1);
+    r.c1 = (f.c0 + f.c1) * (a + b) - t0 - t1;
+    r.c2 = t1 + f.c2 * a;
+    return r;
+}
+// f * l for a line value l = (a + b v) + (c v) w with c in Fp (the shape `line` below produces): 36 Fp products, not 54
+inline H12 f12mul_by_line(const H12 &f, const H2 &a, const H2 &b, const HFp &c) {
+    H6 t0 = f6mul_by_01(f.c0, a, b);
+    H6 t1 = {mul_xi(mul_fp(f.c1.c2, c)), mul_fp(f.c1.c0, c), mul_fp(f.c1.c1, c)};  // f.c1 * (c v)
+    H2 bc = {b.c0 + c, b.c1};
+    H6 cross = f6mul_by_01(f.c0 + f.c1, a, bc) - t0 - t1;
+    return {t0 + mul_v(t1), cross};
 }
 inline H12 f12one() { return {f6one(), f6zero()}; }
 inline H12 f12conj(const H12 &a) { return {a.c0, f6neg(a.c1)}; }
@@ -313,13 +343,56 @@ H12 line(const H2 &lambda, const G2A &t, const HFp &xp, const HFp &yp) {
     return l;
 }
 
+const u64 kAbsZ = 0xd201000000010000ull;  // |z|, z < 0
+
+// The G2 arguments of the verifications are the two setup points, the same on every call: the slope and the constant
+// term of every line of their Miller loops (63 tangents + 5 chords) depend on Q alone and are computed once per
+// distinct Q -- with them a step needs no G2 arithmetic and no inversion, only the evaluation at P.
+struct LineCoeff {
+    H2 lambda, c0;  // l(P) = c0 + (-lambda x_P) v + (y_P) v w,  c0 = lambda x_T - y_T
+};
+struct FixedQ {
+    H2 x, y;
+    std::vector<LineCoeff> lines;  // in the order the loop consumes them
+};
+
+std::shared_ptr<const FixedQ> fixed_q_lines(const G2A &q) {
+    static std::mutex mu;
+    static std::vector<std::shared_ptr<const FixedQ>> cache;  // a handful of entries: linear search
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : cache)
+            if (f2eq(e->x, q.x) && f2eq(e->y, q.y)) return e;
+    }
+    auto fq = std::make_shared<FixedQ>();
+    fq->x = q.x;
+    fq->y = q.y;
+    G2A t = q;
+    for (int bit = 62; bit >= 0; bit--) {
+        H2 xx = t.x * t.x;
+        H2 lambda = (xx + xx + xx) * f2inv(t.y + t.y);  // tangent: 3 x^2 / (2 y)
+        fq->lines.push_back({lambda, lambda * t.x - t.y});
+        H2 x3 = lambda * lambda - t.x - t.x;
+        t = {x3, lambda * (t.x - x3) - t.y};
+        if ((kAbsZ >> bit) & 1) {
+            lambda = (t.y - q.y) * f2inv(t.x - q.x);  // chord through T and Q (T != +-Q for points of order r inside the loop)
+            fq->lines.push_back({lambda, lambda * t.x - t.y});
+            x3 = lambda * lambda - t.x - q.x;
+            t = {x3, lambda * (t.x - x3) - t.y};
+        }
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() < 8) cache.push_back(fq);  // beyond that (the test hook with arbitrary points) nothing is kept
+    return fq;
+}
+
 }  // namespace
 
 // prod_i e(P_i, Q_i) == 1 for affine, non-infinity inputs (callers drop pairs with an infinity: e = 1)
 bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, int n) {
     init_consts();
     if (n == 0) return true;
-    const u64 z = 0xd201000000010000ull;  // |z|, z < 0
+    const u64 z = kAbsZ;
     G2A t[4], q[4];
     HFp px[4], py[4];
     if (n > 4) return false;
@@ -330,6 +403,34 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
         py[i] = HFp::from_fe(ps[i].y);
     }
     H12 f = f12one();
+    static int on_the_fly = -1;  // LWKZG_PAIRING_NO_PRECOMP=1: the loop below that walks T itself (cross-check)
+    if (on_the_fly < 0) on_the_fly = getenv("LWKZG_PAIRING_NO_PRECOMP") ? 1 : 0;
+    if (!on_the_fly) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::shared_ptr<const FixedQ> fq[4];
+        for (int i = 0; i < n; i++) fq[i] = fixed_q_lines(q[i]);
+        size_t k = 0;
+        auto step = [&]() {
+            for (int i = 0; i < n; i++) {
+                const LineCoeff &lc = fq[i]->lines[k];
+                f = f12mul_by_line(f, lc.c0, f2neg(mul_fp(lc.lambda, px[i])), py[i]);
+            }
+            k++;
+        };
+        for (int bit = 62; bit >= 0; bit--) {
+            f = f12sqr(f);
+            step();
+            if ((z >> bit) & 1) step();
+        }
+        static const bool timing = getenv("LWKZG_TIMING") != nullptr;
+        if (!timing) return final_exponentiation_is_one(f12conj(f));  // z < 0
+        const auto t1 = std::chrono::steady_clock::now();
+        const bool verdict = final_exponentiation_is_one(f12conj(f));
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lambdaworks_kzg_amd] pairing product of %d: Miller loop %.3f ms, final exponentiation %.3f ms\n", n,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+        return verdict;
+    }
     // all denominators of a step are inverted together (Montgomery's trick): one Fp inversion per step, not one per pairing
     auto batch_inv = [&](H2 *d) {
         H2 pre[4];

@@ -382,6 +382,20 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         rp = rp * r_mont;
     }
     const auto t2 = now();
+    // [sum r^i y_i]G on a thread of its own, beside the linear combinations
+    HostPoint g;
+    if (!setup_generator(g, s)) return C_KZG_ERROR;
+    uint32_t ys_raw[8];
+    for (int k = 0; k < 4; k++) {
+        ys_raw[2 * k] = (uint32_t)ysum.l[k];
+        ys_raw[2 * k + 1] = (uint32_t)(ysum.l[k] >> 32);
+    }
+    HXyzz ysum_g;
+    std::thread side([&]() { ysum_g = scalar_mul(to_xyzz(g), ys_raw); });
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{side};
     // three variable-base linear combinations (g1_lincomb, lib.rs:679-685): on the GPU over the points the validation
     // kernels left there, or on the host threads when the batch was small enough to be validated there
     uint8_t sums[3][96];
@@ -407,14 +421,8 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     };
     const auto t3 = now();
     HXyzz proof_lincomb = load(0), proof_z_lincomb = load(1), c_lincomb = load(2);
-    HostPoint g;
-    if (!setup_generator(g, s)) return C_KZG_ERROR;
-    uint32_t ys_raw[8];
-    for (int k = 0; k < 4; k++) {
-        ys_raw[2 * k] = (uint32_t)ysum.l[k];
-        ys_raw[2 * k + 1] = (uint32_t)(ysum.l[k] >> 32);
-    }
-    HXyzz rhs = xyzz_add(c_lincomb, xyzz_neg(scalar_mul(to_xyzz(g), ys_raw)));
+    side.join();
+    HXyzz rhs = xyzz_add(c_lincomb, xyzz_neg(ysum_g));
     rhs = xyzz_add(rhs, proof_z_lincomb);
     rc = pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
     if (timing)

@@ -103,6 +103,41 @@ def test_host_pairing_product(K, oracle, oracle_setup):
     assert capi.pairing_product_is_one(bytes([0xc0]) + bytes(47), H) is True      # e(O, Q) = 1
 
 
+_PAIRING_CASES = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from lambdaworks_kzg_amd import capi
+lines = open(%r).read().split()
+g1 = [bytes.fromhex(x) for x in lines[2:2 + 4096]]
+g2 = [bytes.fromhex(x) for x in lines[2 + 4096:2 + 4096 + 65]]
+def negc(c):
+    b = bytearray(c); b[0] ^= 0x20; return bytes(b)
+out = []
+for j, k in [(0, 1), (3, 2), (5, 7), (1, 11), (9, 13), (2, 17), (4, 19), (6, 23), (8, 29), (10, 31), (12, 37), (0, 64)]:
+    # e([tau^j]G, [tau^k]H) * e(-[tau^(j+k)]G, H) == 1; twelve distinct first G2 points (more than the line cache keeps)
+    out.append(capi.pairing_product_is_one(g1[j] + negc(g1[j + k]), g2[k] + g2[0]))
+    out.append(capi.pairing_product_is_one(g1[j] + negc(g1[j + k + 1]), g2[k] + g2[0]))
+    out.append(capi.pairing_product_is_one(g1[j + 1] + negc(g1[j + k]), g2[k] + g2[0]))
+out.append(capi.pairing_product_is_one(g1[2] + negc(g1[3]) + g1[7] + negc(g1[9]), g2[1] + g2[0] + g2[2] + g2[0]))   # four pairs
+out.append(capi.pairing_product_is_one(g1[2] + negc(g1[3]) + g1[7] + negc(g1[8]), g2[1] + g2[0] + g2[2] + g2[0]))
+print("".join("1" if v else "0" for v in out))
+"""
+
+
+def test_host_pairing_variants_agree():
+    """the fixed-Q line precomputation + sparse line products (default), the loop that walks T itself, the generic Fp12
+    squaring and the plain 1268-bit final exponentiation all give the expected verdicts on bilinearity cases over
+    thirteen distinct G2 points of the tau = 1337 setup"""
+    import sys
+    code = _PAIRING_CASES % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH)
+    want = "100" * 12 + "10"
+    for var in ({}, {"LWKZG_PAIRING_NO_PRECOMP": "1"}, {"LWKZG_PAIRING_GENERIC_SQR": "1"},
+                {"LWKZG_PAIRING_NAIVE": "1", "LWKZG_PAIRING_NO_PRECOMP": "1"}):
+        env = dict(os.environ, **var)
+        got = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1]
+        assert got == want, (var, got)
+
+
 def test_host_fiat_shamir_digests_match_hashlib(K):
     """the host-pointer proof entry points hash on the host (SHA extensions when present): same bytes as hashlib"""
     import hashlib
