@@ -47,16 +47,6 @@ int direct_num_windows(int bits) {
 // ------------------------------------------------------------------------------------------------
 // table build, step 1: Q[j][i] = 2^(C j) P_i in affine hot-loop form (one lane per point)
 
-LWK_HD G1Affine29 xyzz29_to_affine29(const G1Xyzz29 &p) {
-    auto i = f29_inv(p.zz * p.zzz);
-    auto izz = i * p.zzz;
-    auto izzz = i * p.zz;
-    G1Affine29 r;
-    r.x = p.x * izz;
-    r.y = p.y * izzz;
-    return r;
-}
-
 template <int C>
 __global__ __launch_bounds__(64) void k_direct_qbase(const G1Affine *__restrict__ points, G1Affine29 *__restrict__ qbase) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

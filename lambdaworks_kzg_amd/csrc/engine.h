@@ -50,6 +50,7 @@ struct Workspace {
 // of the same settings object out until this one is done with it.
 struct VerifyBuffers {
     G1Affine29 *pts_c = nullptr, *pts_p = nullptr;
+    G1Affine29 *mult_c = nullptr, *mult_p = nullptr;  // [2^32]P, [2^64]P, [2^96]P of every point (3 n entries each)
     int32_t *kind_c = nullptr, *kind_p = nullptr;
     uint8_t *proof_in = nullptr;  // compressed proofs as uploaded (validated on an auxiliary stream)
     uint8_t *comm_in = nullptr, *canon_dev = nullptr;  // commitments as uploaded; canonical bytes (n commitments, n proofs)

@@ -484,6 +484,8 @@ static void vs_free(Ctx *c) {
     VerifyBuffers &v = c->vs;
     dev_free(v.pts_c);
     dev_free(v.pts_p);
+    dev_free(v.mult_c);
+    dev_free(v.mult_p);
     dev_free(v.kind_c);
     dev_free(v.kind_p);
     dev_free(v.proof_in);
@@ -509,6 +511,8 @@ static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
     const size_t nblk = lincomb3_blocks(cap);
     bool ok = hipMalloc((void **)&v.pts_c, cap * sizeof(G1Affine29)) == hipSuccess &&
               hipMalloc((void **)&v.pts_p, cap * sizeof(G1Affine29)) == hipSuccess &&
+              hipMalloc((void **)&v.mult_c, 3 * cap * sizeof(G1Affine29)) == hipSuccess &&
+              hipMalloc((void **)&v.mult_p, 3 * cap * sizeof(G1Affine29)) == hipSuccess &&
               hipMalloc((void **)&v.kind_c, cap * 4) == hipSuccess && hipMalloc((void **)&v.kind_p, cap * 4) == hipSuccess &&
               hipMalloc((void **)&v.proof_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.d_r, cap * 32) == hipSuccess &&
               hipMalloc((void **)&v.comm_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.canon_dev, 2 * cap * 48) == hipSuccess &&
@@ -550,8 +554,10 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
     LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
     LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, n * 48, hipMemcpyHostToDevice, sv));
     launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p);
+    launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);  // for the linear combinations; needs no scalar
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c);
+    launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));
     // the canonical bytes come back the first time the host needs them: a device-to-host copy into pageable memory
     // blocks this thread until the stream has reached it, and the first slices should be on their way by then
@@ -661,6 +667,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         C_KZG_RET rcv = vs_reserve(c, n);
         if (rcv != C_KZG_OK) return rcv;
         const VerifyBuffers &v = c->vs;
+        vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
         vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
         vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
         vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all;
@@ -685,29 +692,38 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             std::thread &t;
             ~Joiner() { if (t.joinable()) t.join(); }
         } joiner{hasher};
-        LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemcpyAsync(w.comm48, hc, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
         // up to 64 blobs: both point sets are validated on the host threads (0.2 ms per point per thread against a 2 ms
         // latency-shaped kernel) and the decompressed points uploaded in the form the kernel would have left
         const bool host_validate = !trusted_canon_c && n <= host_small_batch_limit();
         if (proofs48 && !host_validate) {
-            // the proofs' validation (a 2 ms latency-shaped kernel) runs beside the commitments' on an auxiliary stream;
-            // both only ever write the same failure code into status
-            hipStream_t sa = c->vstream;
+            // Both point sets are validated on streams of their own, started before the blobs go up (the copy blocks
+            // this thread for milliseconds): decompression + subgroup test, then the multiples the linear combinations
+            // will want, are a ~3 ms latency chain per set that nothing on the main stream should queue behind. Both
+            // validations only ever write the same failure code into status.
+            hipStream_t sa = c->vstream, sc = c->aux[0];
             LWK_HIP(hipEventRecord(c->ev_fork, st));
             LWK_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
             LWK_HIP(hipMemcpyAsync(vb.proof_in + 48 * off, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, sa));
             launch_validate_commitments(vb.proof_in + 48 * off, w.out48, w.status, bad, m, sa, vb.pts_p + off, vb.kind_p + off);
             LWK_HIP(hipEventRecord(c->ev_join[0], sa));
+            launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, m, sa);  // (off == 0 here: longer batches take the path above)
+            LWK_HIP(hipEventRecord(c->ev_join[2], sa));
+            LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
+            launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, sc, vb.pts_c + off, vb.kind_c + off);
+            LWK_HIP(hipEventRecord(c->ev_join[1], sc));
+            launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, m, sc);
+            LWK_HIP(hipEventRecord(c->ev_join[3], sc));
         }
+        LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
         if (trusted_canon_c) {
             // the caller decompressed (and so validated) the commitments itself and hands over their canonical bytes:
             // no 2 ms validation kernel on the single-blob path
             memcpy(canon_c + 48 * off, trusted_canon_c + 48 * off, m * 48);
             hc = trusted_canon_c + 48 * off;
-        } else if (!host_validate) {
+        } else if (!host_validate && !proofs48) {
             launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
         }
         std::vector<int32_t> h_code(m, bad), h_kind;
@@ -728,7 +744,10 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
                 vb.h_kind = std::move(h_kind);
             }
         }
-        if (proofs48 && !host_validate) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        if (proofs48 && !host_validate) {
+            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
+        }
         if (hash_beside) hasher.join();
         else challenge_digests_host(dig.data(), hb, hash_comm, m);
         // device-to-host copies into pageable memory block this thread until the stream has reached them, so the
@@ -750,6 +769,10 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
         rc = first_status(c, w.status, m, st);
         if (rc != C_KZG_OK) return rc;
+        if (proofs48 && !host_validate) {  // the linear combinations (main stream, later) read the multiples
+            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[2], 0));
+            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[3], 0));
+        }
     }
     return C_KZG_OK;
 }
@@ -774,7 +797,7 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
     if (ok) ok = hipMemcpyAsync(d_r, sc_r, 32 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
                  hipMemcpyAsync(d_rz, sc_rz, 32 * n, hipMemcpyHostToDevice, st) == hipSuccess;
     if (ok) {
-        launch_lincomb3(vb.pts_p, vb.kind_p, vb.pts_c, vb.kind_c, d_r, d_rz, d_part, n, st);
+        launch_lincomb3(vb.pts_p, vb.kind_p, vb.mult_p, vb.pts_c, vb.kind_c, vb.mult_c, d_r, d_rz, d_part, n, st);
         G1Xyzz29 *totals = d_part + 3 * nblk;
         for (int k = 0; k < 3; k++) launch_sum_points(d_part + k * nblk, nblk, totals + k, 0, st);
         launch_xyzz29_to_affine_be(totals, d_aff, d_inf, 3, st);

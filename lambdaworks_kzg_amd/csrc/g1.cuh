@@ -240,6 +240,17 @@ LWK_HD G1Affine xyzz_to_affine(const G1Xyzz29 &p) {
     return r;
 }
 
+// same, staying in the hot-loop representation
+LWK_HD G1Affine29 xyzz29_to_affine29(const G1Xyzz29 &p) {
+    auto i = f29_inv(p.zz * p.zzz);
+    auto izz = i * p.zzz;
+    auto izzz = i * p.zz;
+    G1Affine29 r;
+    r.x = p.x * izz;
+    r.y = p.y * izzz;
+    return r;
+}
+
 LWK_HD G1Affine29 affine_to_29(const G1Affine &p) {
     G1Affine29 r;
     r.x = f29_from_fp(p.x);

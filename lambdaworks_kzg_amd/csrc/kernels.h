@@ -87,8 +87,12 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
 //   set 0 = sum r_i P_i, set 1 = sum rz_i P_i (P = proofs), set 2 = sum r_i C_i (C = commitments);
 // per-block partial sums to partial[set * nblk + block]
 size_t lincomb3_blocks(size_t n);  // workgroups (= partial sums) per set
-void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *comms, const int32_t *comm_kind,
-                     const uint8_t *sc_r_be, const uint8_t *sc_rz_be, G1Xyzz29 *partial, size_t n, hipStream_t st);
+// *_mult: [2^32]P, [2^64]P, [2^96]P of every point (3 n entries, launch_point_multiples), so that each scalar is cut
+// into 32-bit pieces on lanes of their own
+void launch_point_multiples(const G1Affine29 *pts, const int32_t *kind, G1Affine29 *mult, size_t n, hipStream_t st);
+void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *proof_mult, const G1Affine29 *comms,
+                     const int32_t *comm_kind, const G1Affine29 *comm_mult, const uint8_t *sc_r_be, const uint8_t *sc_rz_be,
+                     G1Xyzz29 *partial, size_t n, hipStream_t st);
 void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from = nullptr);

@@ -115,7 +115,10 @@ __global__ __launch_bounds__(64) void k_build_table(const G1Affine *__restrict__
 }
 
 constexpr int kLincombThreads = 256;
-constexpr int kLincombTerms = kLincombThreads / 2;  // two lanes per term (endomorphism split)
+constexpr int kLincombPieces = 4;                               // 32-bit pieces of each 128-bit half scalar
+constexpr int kLincombLanes = 2 * kLincombPieces;               // lanes per term: endomorphism split x pieces
+constexpr int kLincombTerms = kLincombThreads / kLincombLanes;  // 32 terms per workgroup
+constexpr int kPieceBits = 128 / kLincombPieces;
 
 // k = lo + hi * z^2 with z^2 = 0xac45a4010001a4020000000100000000 (the curve parameter squared, 128 bits);
 // k < r = z^4 - z^2 + 1, so both halves fit 128 bits. Bitwise restoring division, once per lane.
@@ -148,27 +151,57 @@ __device__ __forceinline__ void split_by_z2(uint32_t lo[4], uint32_t hi[4], cons
     for (int i = 0; i < 4; i++) lo[i] = rem[i];
 }
 
+// mult[(j - 1) n + i] = [2^(32 j)] pts[i], j = 1 .. 3, affine, for the points the validation kernel accepted. Needs the
+// points only, not the scalars: it runs right behind the validation, beside the per-blob pass, and lets k_lincomb3 cut
+// every scalar into 32-bit pieces on lanes of their own (a lone wave needs ~8-10 us per group operation however idle
+// the chip is, so the length of the serial chain is all that matters there).
+__global__ __launch_bounds__(64) void k_point_multiples(const G1Affine29 *__restrict__ pts, const int32_t *__restrict__ kind,
+                                                        G1Affine29 *__restrict__ mult, size_t n) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (kLincombPieces - 1) * n) return;
+    const size_t i = gid % n;
+    const int j = (int)(gid / n) + 1;
+    if (kind[i] != 0) {
+        mult[gid].x = F29<2>::zero();
+        mult[gid].y = F29<2>::zero();
+        return;
+    }
+    G1Affine29i p = ((const G1Affine29i *)pts)[i];
+    G1Xyzz29i acc = G1Xyzz29i::from_affine(p.x, p.y);
+    for (int k = 0; k < kPieceBits * j; k++) acc = xyzz_dbl(acc);
+    mult[gid] = xyzz29_to_affine29(*(G1Xyzz29 *)&acc);  // a point of prime order r: no multiple of it is the point at infinity
+}
+
+void launch_point_multiples(const G1Affine29 *pts, const int32_t *kind, G1Affine29 *mult, size_t n, hipStream_t st) {
+    ProfScope p("k_point_multiples", st);
+    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64)), dim3(64), 0, st, pts, kind, mult, n);
+}
+
 // The three linear combinations of verify_kzg_proof_batch (/root/reference/src/lib.rs:679-685) in ONE launch, on points
 // the validation kernel already decompressed into the hot-loop representation. A 255-bit double-and-add is a serial
-// chain of ~383 group operations on one lane, so the chain is halved with the curve endomorphism phi(x, y) = (beta x, y),
-// which acts on G1 as multiplication by -z^2:  [k]P = [lo]P + [hi](-phi(P)),  k = lo + hi z^2.  Two lanes per term, a
-// 128-bit double-and-add each (field products inlined: no call boundaries on the chain), then the workgroup sums
-// its 256 results in LDS.
+// chain of ~383 group operations on one lane, so the chain is cut twice. The curve endomorphism phi(x, y) = (beta x, y)
+// acts on G1 as multiplication by -z^2:  [k]P = [lo]P + [hi](-phi(P)),  k = lo + hi z^2, two 128-bit halves. Each half
+// is cut into four 32-bit pieces that multiply [2^(32 j)]P (k_point_multiples; phi commutes with the multiples). Eight
+// lanes per term, a 32-bit double-and-add each (field products inlined: no call boundaries on the chain), then the
+// workgroup sums its 256 results in LDS.
 __global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *__restrict__ proofs,
                                                               const int32_t *__restrict__ proof_kind,
+                                                              const G1Affine29 *__restrict__ proof_mult,
                                                               const G1Affine29 *__restrict__ comms,
                                                               const int32_t *__restrict__ comm_kind,
+                                                              const G1Affine29 *__restrict__ comm_mult,
                                                               const uint8_t *__restrict__ sc_r, const uint8_t *__restrict__ sc_rz,
                                                               G1Xyzz29 *__restrict__ partial, size_t n) {
     __shared__ G1Xyzz29 sh[kLincombThreads];
-    const int tid = threadIdx.x, set = blockIdx.y, half = tid & 1;
-    const size_t i = (size_t)blockIdx.x * kLincombTerms + (tid >> 1);
+    const int tid = threadIdx.x, set = blockIdx.y, half = tid & 1, piece = (tid >> 1) % kLincombPieces;
+    const size_t i = (size_t)blockIdx.x * kLincombTerms + tid / kLincombLanes;
     const G1Affine29 *pts = set == 2 ? comms : proofs;
+    const G1Affine29 *mult = set == 2 ? comm_mult : proof_mult;
     const int32_t *kind = set == 2 ? comm_kind : proof_kind;
     const uint8_t *sc = set == 1 ? sc_rz : sc_r;
     G1Xyzz29i acc = G1Xyzz29i::infinity();
     if (i < n && kind[i] == 0) {
-        G1Affine29i p = ((const G1Affine29i *)pts)[i];
+        G1Affine29i p = piece == 0 ? ((const G1Affine29i *)pts)[i] : ((const G1Affine29i *)mult)[(size_t)(piece - 1) * n + i];
         uint32_t k[8], lo[4], hi[4];
         raw_from_be<8>(k, sc + 32 * i);
         split_by_z2(lo, hi, k);
@@ -184,11 +217,13 @@ __global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *
 #pragma unroll
             for (int q = 0; q < 4; q++) lo[q] = hi[q];
         }
-        int bit = 127;
-        while (bit >= 0 && !((lo[bit >> 5] >> (bit & 31)) & 1)) bit--;  // leading zeros: nothing to double yet
+        static_assert(kPieceBits == 32, "one 32-bit word per lane");
+        const uint32_t w = lo[piece];
+        int bit = 31;
+        while (bit >= 0 && !((w >> bit) & 1)) bit--;  // leading zeros: nothing to double yet
         for (; bit >= 0; bit--) {
             acc = xyzz_dbl(acc);
-            if ((lo[bit >> 5] >> (bit & 31)) & 1) acc = xyzz_madd(acc, p.x, p.y);
+            if ((w >> bit) & 1) acc = xyzz_madd(acc, p.x, p.y);
         }
     }
     sh[tid] = *(G1Xyzz29 *)&acc;
@@ -202,12 +237,13 @@ __global__ __launch_bounds__(kLincombThreads) void k_lincomb3(const G1Affine29 *
 
 size_t lincomb3_blocks(size_t n) { return (n + kLincombTerms - 1) / kLincombTerms; }
 
-void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *comms, const int32_t *comm_kind,
-                     const uint8_t *sc_r_be, const uint8_t *sc_rz_be, G1Xyzz29 *partial, size_t n, hipStream_t st) {
+void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *proof_mult, const G1Affine29 *comms,
+                     const int32_t *comm_kind, const G1Affine29 *comm_mult, const uint8_t *sc_r_be, const uint8_t *sc_rz_be,
+                     G1Xyzz29 *partial, size_t n, hipStream_t st) {
     ProfScope p("k_lincomb3", st);
     unsigned grid = (unsigned)lincomb3_blocks(n);
-    hipLaunchKernelGGL(k_lincomb3, dim3(grid, 3), dim3(kLincombThreads), 0, st, proofs, proof_kind, comms, comm_kind,
-                       sc_r_be, sc_rz_be, partial, n);
+    hipLaunchKernelGGL(k_lincomb3, dim3(grid, 3), dim3(kLincombThreads), 0, st, proofs, proof_kind, proof_mult, comms, comm_kind,
+                       comm_mult, sc_r_be, sc_rz_be, partial, n);
 }
 
 __global__ __launch_bounds__(64) void k_xyzz29_to_affine_be(const G1Xyzz29 *__restrict__ in, uint8_t *__restrict__ out96,
