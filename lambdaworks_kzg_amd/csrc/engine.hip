@@ -1083,7 +1083,9 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
-    if (n < 512) {  // one launch set, results and verdicts back in one go
+    // (the bucket engine overlaps the tails of its own sub-batches inside commit_batch_device, which a lone 512-blob slice
+    // would forgo: it takes the single pass up to a whole chunk)
+    if (n < 512 || (!c->direct_table && n <= kMaxChunk)) {  // one launch set, results and verdicts back in one go
         C_KZG_RET rc = ctx_reserve(c, n);
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;

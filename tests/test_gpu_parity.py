@@ -207,11 +207,12 @@ def test_ckzg_batch_reports_first_bad(K, gpu_setup):
 
 
 def test_large_host_batch_is_sliced_and_reports_first_bad(K, gpu_setup):
-    """host-pointer batches of >= 512 blobs go up in 256-blob slices on two streams: same bytes as the device path,
-    and the first rejected blob is still reported by its index in the whole batch"""
+    """long host-pointer batches (>= 512 blobs with the direct table, more than one 1024-blob chunk on the default engine)
+    go up in 512-blob slices on two streams: same bytes as the device path, and the first rejected blob is still
+    reported by its index in the whole batch"""
     import torch
     K.set_mode(K.MODE_CKZG)
-    n = 600
+    n = 1100
     data = bytearray(B.synthetic_batch(3000, n, big_endian=False))
     d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
@@ -220,7 +221,7 @@ def test_large_host_batch_is_sliced_and_reports_first_bad(K, gpu_setup):
     assert b"".join(K.blob_to_kzg_commitment_batch(bytes(data), gpu_setup)) == _host(d_out)
     bad_blob = B.make_blob("all_ff")                        # every element >= r: not canonical in c-kzg mode
     data[317 * B.BYTES_PER_BLOB:318 * B.BYTES_PER_BLOB] = bad_blob
-    data[590 * B.BYTES_PER_BLOB:591 * B.BYTES_PER_BLOB] = bad_blob
+    data[1090 * B.BYTES_PER_BLOB:1091 * B.BYTES_PER_BLOB] = bad_blob
     out = C.create_string_buffer(48 * n)
     bad = C.c_size_t(9999)
     rc = K.lib().lwkzg_blob_to_kzg_commitment_batch(out, bytes(data), n, gpu_setup.ref(), C.byref(bad))
@@ -676,6 +677,11 @@ def test_direct_commitments_match_default_path(K, direct_setup, gpu_setup, oracl
     assert got == want
     blob0 = data[:B.BYTES_PER_BLOB]
     assert got[0] == tau_closed_form(oracle, B.blob_scalars(blob0))
+    if n == 1024:   # the sliced proof paths on the direct engine
+        cm = b"".join(got)
+        assert K.compute_blob_kzg_proof_batch(data, cm, ts) == K.compute_blob_kzg_proof_batch(data, cm, gpu_setup)
+        zs = data[:32 * n]
+        assert K.compute_kzg_proof_batch(data, zs, ts) == K.compute_kzg_proof_batch(data, zs, gpu_setup)
 
 
 def test_direct_proofs_both_modes_match_default_path(K, direct_setup, gpu_setup, oracle, oracle_setup):
