@@ -1075,6 +1075,15 @@ static C_KZG_RET map_rc(C_KZG_RET rc, int mode) {
     return rc;
 }
 
+// Slice schedule of the long host batches: 512 blobs at a time (one half of the workspace). A batch shorter than a chunk
+// starts with 128 + 384 instead, so that the GPU is at work after a quarter of the first upload (6.4 instead of 7.1 ms
+// for 512 commitments); from a whole chunk on, the smaller launches cost what the earlier start gains.
+static size_t slice_len(size_t k, size_t remaining, size_t n) {
+    size_t want = kMaxChunk / 2;
+    if (n < kMaxChunk && k < 2) want = k == 0 ? kMaxChunk / 8 : kMaxChunk / 2 - kMaxChunk / 8;
+    return remaining < want ? remaining : want;
+}
+
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s,
                                              size_t *first_bad) {
     const int mode = mode_now();
@@ -1126,8 +1135,8 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
     LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
     LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
     size_t k = 0;
-    for (size_t off = 0; off < n; off += kSlice, k++) {
-        const size_t cnt = n - off < kSlice ? n - off : kSlice;
+    for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
+        cnt = slice_len(k, n - off, n);
         const size_t lo = (k % 2) * kSlice;
         hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
@@ -1213,8 +1222,8 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
     LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
     LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
     size_t k = 0;
-    for (size_t off = 0; off < n; off += kSlice, k++) {
-        const size_t cnt = n - off < kSlice ? n - off : kSlice;
+    for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
+        cnt = slice_len(k, n - off, n);
         const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
         hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
@@ -1278,8 +1287,8 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     bool validated = false;
     size_t k = 0;
-    for (size_t off = 0; off < n; off += kSlice, k++) {
-        const size_t cnt = n - off < kSlice ? n - off : kSlice;
+    for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
+        cnt = slice_len(k, n - off, n);
         const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
         hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;

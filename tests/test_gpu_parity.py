@@ -667,7 +667,7 @@ def test_direct_adversarial_digits_closed_form(K, direct_setup, oracle):
         assert g == tau_closed_form(oracle, ss)
 
 
-@pytest.mark.parametrize("n", [1, 3, 64, 200, 1024])
+@pytest.mark.parametrize("n", [1, 3, 64, 200, 700, 1024])
 def test_direct_commitments_match_default_path(K, direct_setup, gpu_setup, oracle, n):
     """every launch geometry of the direct kernel (16 .. 1 workgroups per blob) against the bucket path"""
     ts, _ = direct_setup
@@ -677,7 +677,7 @@ def test_direct_commitments_match_default_path(K, direct_setup, gpu_setup, oracl
     assert got == want
     blob0 = data[:B.BYTES_PER_BLOB]
     assert got[0] == tau_closed_form(oracle, B.blob_scalars(blob0))
-    if n == 1024:   # the sliced proof paths on the direct engine
+    if n >= 700:    # the sliced proof paths on the direct engine (700: the 128 + 384 + rest schedule)
         cm = b"".join(got)
         assert K.compute_blob_kzg_proof_batch(data, cm, ts) == K.compute_blob_kzg_proof_batch(data, cm, gpu_setup)
         zs = data[:32 * n]
@@ -855,3 +855,18 @@ def test_long_host_proof_batches_are_sliced(K, gpu_setup):
         assert rc == K.C_KZG_BADARGS and bad.value == 1050
     finally:
         K.set_mode(K.MODE_REFERENCE)
+
+
+def test_host_proof_batch_below_one_chunk_short_first_slices(K, gpu_setup):
+    """512 .. 1023 blobs: slices of 128, 384 and the rest; same bytes as short single-pass calls"""
+    n, piece = 700, 350
+    data = B.synthetic_batch(8000, n)
+    comms = b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup))
+    zs = b"".join(B.synthetic_blob(8800 + i)[:32] for i in range(n))
+    want_b, want_p = [], []
+    for lo in range(0, n, piece):
+        sl = data[lo * B.BYTES_PER_BLOB:(lo + piece) * B.BYTES_PER_BLOB]
+        want_b += K.compute_blob_kzg_proof_batch(sl, comms[48 * lo:48 * (lo + piece)], gpu_setup)
+        want_p += K.compute_kzg_proof_batch(sl, zs[32 * lo:32 * (lo + piece)], gpu_setup)
+    assert K.compute_blob_kzg_proof_batch(data, comms, gpu_setup) == want_b
+    assert K.compute_kzg_proof_batch(data, zs, gpu_setup) == want_p
