@@ -75,7 +75,7 @@ struct Ctx {
     uint64_t magic;
     int device;
     hipStream_t stream;
-    hipStream_t vstream;            // point-validation kernels, CU-masked away from the main stream's small grids
+    hipStream_t vstream;            // point-validation kernels (a plain stream of their own; see ctx_new on CU masks)
     hipStream_t aux[kMaxSplit];     // sub-batch streams of commit_batch_device
     hipEvent_t ev_fork, ev_join[kMaxSplit];
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)

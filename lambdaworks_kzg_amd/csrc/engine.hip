@@ -547,7 +547,7 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
     if (rcw != C_KZG_OK) return rcw;
     Workspace &w = c->ws;
 
-    // up-front validation of every commitment (main stream) and every proof (CU-masked validation stream)
+    // up-front validation of every commitment (main stream) and every proof (validation stream)
     LWK_HIP(hipMemcpyAsync(vb.comm_in, comm48, n * 48, hipMemcpyHostToDevice, st));
     LWK_HIP(hipMemsetAsync(vb.status_all, 0, n * 4, st));
     LWK_HIP(hipEventRecord(c->ev_fork, st));

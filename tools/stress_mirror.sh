@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-if [ -n "$NOMASK" ]; then export LWKZG_NO_CUMASK=1; fi
 L=$PWD/lambdaworks_kzg_amd/lib
 gcc -std=c11 -O1 -I include tests/lib_test_mirror.c -o /tmp/mirror -L $L -llambdaworks_kzg -Wl,-rpath,$L -Wl,-rpath,/opt/rocm/lib || exit 1
 # a second process holding a context with a workspace, like the pytest parent
