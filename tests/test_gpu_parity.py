@@ -870,3 +870,37 @@ def test_host_proof_batch_below_one_chunk_short_first_slices(K, gpu_setup):
         want_p += K.compute_kzg_proof_batch(sl, zs[32 * lo:32 * (lo + piece)], gpu_setup)
     assert K.compute_blob_kzg_proof_batch(data, comms, gpu_setup) == want_b
     assert K.compute_kzg_proof_batch(data, zs, gpu_setup) == want_p
+
+
+@pytest.mark.parametrize("n", [2, 7, 64, 65, 200, 700])
+def test_verify_batch_every_path_random_tamper(K, gpu_setup, oracle, n):
+    """batch verification through each of its internal routes (host-thread validation + linear combinations up to 64
+    blobs, validation kernels + piece-split GPU linear combinations above): accepts the honest batch; rejects it with
+    one proof, one commitment or one blob swapped for another valid one at a random place; points at infinity
+    (zero blob, zero quotient) take part"""
+    rnd = random.Random(1000 + n)
+    blobs = [B.synthetic_blob(12000 + 31 * n + i) for i in range(n)]
+    blobs[rnd.randrange(n)] = bytes(B.BYTES_PER_BLOB)                     # commitment and proof at infinity
+    const = bytearray(B.BYTES_PER_BLOB)
+    const[31] = 5
+    blobs[rnd.randrange(1, n) if blobs[0] == bytes(B.BYTES_PER_BLOB) else 0] = bytes(const)   # constant polynomial: proof at infinity
+    data = b"".join(blobs)
+    comms = K.blob_to_kzg_commitment_batch(data, gpu_setup)
+    proofs = K.compute_blob_kzg_proof_batch(data, b"".join(comms), gpu_setup)
+    assert bytes([0xc0]) + bytes(47) in proofs
+    cj, pj = b"".join(comms), b"".join(proofs)
+    assert K.verify_blob_kzg_proof_batch(data, cj, pj, n, gpu_setup) is True
+    other = oracle.g1_generator_mul(rnd.randrange(2, R))                  # a valid G1 point that proves nothing here
+    i = rnd.randrange(n)
+    bad_p = pj[:48 * i] + other + pj[48 * i + 48:]
+    assert K.verify_blob_kzg_proof_batch(data, cj, bad_p, n, gpu_setup) is False
+    j = rnd.randrange(n)
+    bad_c = cj[:48 * j] + other + cj[48 * j + 48:]
+    assert K.verify_blob_kzg_proof_batch(data, bad_c, pj, n, gpu_setup) is False
+    k = rnd.randrange(n)
+    bad_b = data[:k * B.BYTES_PER_BLOB] + B.synthetic_blob(99000 + n) + data[(k + 1) * B.BYTES_PER_BLOB:]
+    assert K.verify_blob_kzg_proof_batch(bad_b, cj, pj, n, gpu_setup) is False
+    # single-blob entry point agrees on a sample
+    for t in rnd.sample(range(n), min(n, 3)):
+        assert K.verify_blob_kzg_proof(blobs[t], comms[t], proofs[t], gpu_setup) is True
+        assert K.verify_blob_kzg_proof(blobs[t], comms[t], other, gpu_setup) is False
