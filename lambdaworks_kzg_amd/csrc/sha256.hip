@@ -485,7 +485,14 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
                                  hipStream_t st, G1Affine29 *aff_out, int32_t *kind_out) {
     ProfScope p("k_validate_commitments", st);
-    hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, comm48, canon48, status,
+    // The kernel is a one-wave-per-workgroup latency chain that runs beside other latency chains (the Fiat-Shamir hash of
+    // the device-resident proofs, the other point set's validation). Where a wave of each shares a SIMD, both run at
+    // about half speed, and the dispatcher likes to start every kernel's workgroups on the same compute units. An LDS
+    // footprint the kernel never touches keeps them apart: 112 KB here + the hash kernel's 48 KB (or a second
+    // validation workgroup) exceed the 160 KB of a compute unit, so the dispatcher has to pick another one. The hash
+    // of 1024 blobs takes 3.2 ms instead of 4.3 ms beside it (LWKZG_VALIDATE_LDS_PAD=0 switches the padding off).
+    static const unsigned lds_pad = getenv("LWKZG_VALIDATE_LDS_PAD") ? (unsigned)atoi(getenv("LWKZG_VALIDATE_LDS_PAD")) : 112u * 1024u;
+    hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), lds_pad, st, comm48, canon48, status,
                        bad_code, n, aff_out, kind_out);
 }
 
