@@ -14,7 +14,12 @@
 
 #include <string.h>
 
+#include <functional>
+#include <vector>
+
 namespace lwk {
+void host_parallel_for(size_t n, const std::function<void(size_t)> &fn);  // sha256_host.hip
+
 
 static inline Fp2 fp2_add(const Fp2 &a, const Fp2 &b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
 static inline Fp2 fp2_sub(const Fp2 &a, const Fp2 &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
@@ -115,24 +120,28 @@ bool g2_decompress(Fp2 &x, Fp2 &y, bool &inf, const uint8_t in[96]) {
 }
 
 bool g2_fill_values(g2_t *out, const uint8_t *g2_bytes, size_t n2) {
-    for (size_t i = 0; i < n2; i++) {
+    // one Fp2 square root per point on the 32-bit host field (~1.5 ms): spread over the host threads
+    std::vector<int> bad(n2, 0);
+    host_parallel_for(n2, [&](size_t i) {
         Fp2 x, y;
         bool inf = false;
         if (!g2_decompress(x, y, inf, g2_bytes + 96 * i)) {
-            set_error("g2 point %zu: invalid compressed point", i);
-            return false;
+            bad[i] = 1;
+            return;
         }
         memset(&out[i], 0, sizeof(g2_t));
-        if (inf) {
-            // g2_point_to_blst_p2 of the neutral element goes through to_affine upstream; keep (0, 0, z = 0)
-            continue;
-        }
+        if (inf) return;  // g2_point_to_blst_p2 of the neutral element goes through to_affine upstream; keep (0, 0, z = 0)
         fp_to_blst(&out[i].x.fp[0], x.c0);
         fp_to_blst(&out[i].x.fp[1], x.c1);
         fp_to_blst(&out[i].y.fp[0], y.c0);
         fp_to_blst(&out[i].y.fp[1], y.c1);
         out[i].z.fp[0].l[5] = 1;  // z = 1 + 0 i, canonical, most-significant limb first
-    }
+    });
+    for (size_t i = 0; i < n2; i++)
+        if (bad[i]) {
+            set_error("g2 point %zu: invalid compressed point", i);
+            return false;
+        }
     return true;
 }
 
