@@ -165,6 +165,12 @@ void launch_raw_to_be(const uint32_t *raw, uint8_t *out_be, size_t n_elems, hipS
 // The recurrence is a composition of affine maps x -> c + m x, so it parallelises as a suffix scan:
 // lane t owns coefficients [16t, 16t+16); L_t = sum_k c_{16t+k} z^k; H_t = L_t + z^16 H_{t+1}
 // (Hillis-Steele over (multiplier, value) pairs in LDS); acc at the chunk's upper edge is H_{t+1}.
+//
+// Representation: only z and its powers (the multipliers) are in Montgomery form. The coefficients, every accumulator
+// and the quotient stay RAW canonical integers: a Montgomery product of a Montgomery multiplier (z R) with a raw value
+// x is (z R) x / R = z x, raw again -- so the 4096 conversions in and the 4096 conversions out (a product each) that a
+// uniform Montgomery pipeline would need never happen. The coefficients arrive reduced (k_parse_be_reduce, the
+// inverse transform's exit), which is what the product's "first operand < r" requirement and the additions need.
 
 constexpr int kEvalThreads = 256;
 constexpr int kEvalChunk = kBlobElems / kEvalThreads;  // 16
@@ -184,12 +190,13 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__r
 #pragma unroll
     for (int k = 0; k < kEvalChunk; k++) {
         uint4 lo = cin[2 * k], hi = cin[2 * k + 1];
-        uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        c[k] = fe_from_raw<FrParams>(s);
+        const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) c[k].l[q] = s[q];  // raw
     }
     Fr L = c[kEvalChunk - 1];
 #pragma unroll
-    for (int k = kEvalChunk - 2; k >= 0; k--) L = L * z + c[k];
+    for (int k = kEvalChunk - 2; k >= 0; k--) L = z * L + c[k];  // (Montgomery multiplier first: it is the operand < r)
     Fr m = z;
 #pragma unroll
     for (int k = 1; k < kEvalChunk; k <<= 1) m = sqr(m);  // z^16
@@ -220,10 +227,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__r
         acc = c[k] + z * acc;
         int i = i0 + k;
         if (i >= 1) {
-            uint32_t s[8];
-            fe_to_raw<FrParams>(s, acc);
-            qout[2 * (i - 1)] = make_uint4(s[0], s[1], s[2], s[3]);
-            qout[2 * (i - 1) + 1] = make_uint4(s[4], s[5], s[6], s[7]);
+            qout[2 * (i - 1)] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
+            qout[2 * (i - 1) + 1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
         }
     }
     if (t == kEvalThreads - 1) {
@@ -232,7 +237,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__r
     }
     if (t == 0 && y_out) {
         uint32_t s[8];
-        fe_to_raw<FrParams>(s, acc);  // acc_0 = y
+#pragma unroll
+        for (int q = 0; q < 8; q++) s[q] = acc.l[q];  // acc_0 = y, raw already
         uint8_t *yo = y_out + 32 * blob;
         if (le) raw_to_le<8>(yo, s); else raw_to_be<8>(yo, s);
     }
