@@ -702,19 +702,25 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             // this thread for milliseconds): decompression + subgroup test, then the multiples the linear combinations
             // will want, are a ~3 ms latency chain per set that nothing on the main stream should queue behind. Both
             // validations only ever write the same failure code into status.
-            hipStream_t sa = c->vstream, sc = c->aux[0];
+            // The validation is split in two launches here (square root; subgroup test + canonical bytes), and the
+            // multiples run on a fourth stream beside the second one. (off == 0: longer batches take the path above.)
+            hipStream_t sa = c->vstream, sc = c->aux[0], sm = c->aux[1];
             LWK_HIP(hipEventRecord(c->ev_fork, st));
             LWK_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
-            LWK_HIP(hipMemcpyAsync(vb.proof_in + 48 * off, proofs48 + 48 * off, m * 48, hipMemcpyHostToDevice, sa));
-            launch_validate_commitments(vb.proof_in + 48 * off, w.out48, w.status, bad, m, sa, vb.pts_p + off, vb.kind_p + off);
+            LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, m * 48, hipMemcpyHostToDevice, sa));
+            launch_decompress_points(vb.proof_in, vb.pts_p, vb.kind_p, m, sa);
+            LWK_HIP(hipEventRecord(c->ev_join[4], sa));
+            launch_subgroup_canon(vb.pts_p, vb.kind_p, w.out48, w.status, bad, m, sa);
             LWK_HIP(hipEventRecord(c->ev_join[0], sa));
-            launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, m, sa);  // (off == 0 here: longer batches take the path above)
-            LWK_HIP(hipEventRecord(c->ev_join[2], sa));
             LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
-            launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, sc, vb.pts_c + off, vb.kind_c + off);
+            launch_decompress_points(w.comm48, vb.pts_c, vb.kind_c, m, sc);
+            LWK_HIP(hipEventRecord(c->ev_join[5], sc));
+            launch_subgroup_canon(vb.pts_c, vb.kind_c, w.canon48, w.status, bad, m, sc);
             LWK_HIP(hipEventRecord(c->ev_join[1], sc));
-            launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, m, sc);
-            LWK_HIP(hipEventRecord(c->ev_join[3], sc));
+            LWK_HIP(hipStreamWaitEvent(sm, c->ev_join[4], 0));
+            LWK_HIP(hipStreamWaitEvent(sm, c->ev_join[5], 0));
+            launch_point_multiples2(vb.pts_p, vb.kind_p, vb.mult_p, vb.pts_c, vb.kind_c, vb.mult_c, m, sm);
+            LWK_HIP(hipEventRecord(c->ev_join[2], sm));
         }
         LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
@@ -769,10 +775,8 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
         rc = first_status(c, w.status, m, st);
         if (rc != C_KZG_OK) return rc;
-        if (proofs48 && !host_validate) {  // the linear combinations (main stream, later) read the multiples
+        if (proofs48 && !host_validate)  // the linear combinations (main stream, later) read the multiples
             LWK_HIP(hipStreamWaitEvent(st, c->ev_join[2], 0));
-            LWK_HIP(hipStreamWaitEvent(st, c->ev_join[3], 0));
-        }
     }
     return C_KZG_OK;
 }

@@ -258,6 +258,38 @@ LWK_HD G1Affine29 affine_to_29(const G1Affine &p) {
     return r;
 }
 
+// decompress_g1_point (/root/reference/src/compression.rs:62-103) WITHOUT the subgroup check, in the hot-loop
+// representation: 0 = (x, y) is the point, 1 = point at infinity, 2 = invalid (not flagged compressed, or x^3 + 4 is
+// not a square). want_greater = the ZCash sign bit (select_sqrt_value_from_third_bit).
+LWK_HD int g1_decompress29_nocheck(const uint8_t *in48, F29<2> &x, F29<2> &y, bool &want_greater) {
+    uint8_t b[48];
+    for (int k = 0; k < 48; k++) b[k] = in48[k];
+    const uint8_t prefix = b[0] >> 5;
+    want_greater = (prefix & 1) != 0;
+    if (!(prefix & 4)) return 2;  // not flagged compressed
+    if (prefix & 2) return 1;     // infinity; remaining input bits are not inspected (compression.rs:73-75)
+    b[0] &= 0x1f;
+    uint32_t raw[12];
+    raw_from_be<12>(raw, b);
+    x = f29_from_raw32(raw);  // x >= p is reduced, as upstream from_bytes_be is believed to
+    uint32_t four[12] = {4};
+    F29<2> y2 = (sqr(x) * x + f29_from_raw32(four)) * F29<1>::one();  // the product by R mod p reduces < 4p back to < 2p
+    const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                            0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+    F29<2> r = f29_pow<12>(y2, e);  // y2^((p+1)/4)
+    if (!(sqr(r) - y2).is_zero()) return 2;  // x^3 + 4 is not a square: not on the curve
+    uint32_t ry[12], half[12], one[12] = {1};
+    f29_to_raw32(ry, r);
+    // r is the greater root  <=>  r > (p - 1) / 2
+    raw_sub<12>(half, FpParams::MOD, one);
+#pragma unroll
+    for (int k = 0; k < 11; k++) half[k] = (half[k] >> 1) | (half[k + 1] << 31);
+    half[11] >>= 1;
+    const bool r_greater = !raw_geq<12>(half, ry);
+    y = cneg(r, want_greater != r_greater) * F29<1>::one();  // back to < 2p
+    return 0;
+}
+
 // [k]P, k = NK little-endian 32-bit limbs (plain integer, not reduced); left-to-right double-and-add
 template <int NK>
 LWK_HD G1Xyzz xyzz_mul_affine(const G1Affine &p, const uint32_t *k) {

@@ -90,6 +90,12 @@ size_t lincomb3_blocks(size_t n);  // workgroups (= partial sums) per set
 // *_mult: [2^32]P, [2^64]P, [2^96]P of every point (3 n entries, launch_point_multiples), so that each scalar is cut
 // into 32-bit pieces on lanes of their own
 void launch_point_multiples(const G1Affine29 *pts, const int32_t *kind, G1Affine29 *mult, size_t n, hipStream_t st);
+void launch_point_multiples2(const G1Affine29 *pts_a, const int32_t *kind_a, G1Affine29 *mult_a, const G1Affine29 *pts_b,
+                             const int32_t *kind_b, G1Affine29 *mult_b, size_t n, hipStream_t st);  // two sets, one launch
+// launch_validate_commitments in two launches (sha256.hip): the multiples above can start after the first
+void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st);
+void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
+                           hipStream_t st);
 void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *proof_mult, const G1Affine29 *comms,
                      const int32_t *comm_kind, const G1Affine29 *comm_mult, const uint8_t *sc_r_be, const uint8_t *sc_rz_be,
                      G1Xyzz29 *partial, size_t n, hipStream_t st);

@@ -155,13 +155,19 @@ __device__ __forceinline__ void split_by_z2(uint32_t lo[4], uint32_t hi[4], cons
 // points only, not the scalars: it runs right behind the validation, beside the per-blob pass, and lets k_lincomb3 cut
 // every scalar into 32-bit pieces on lanes of their own (a lone wave needs ~8-10 us per group operation however idle
 // the chip is, so the length of the serial chain is all that matters there).
-__global__ __launch_bounds__(64) void k_point_multiples(const G1Affine29 *__restrict__ pts, const int32_t *__restrict__ kind,
-                                                        G1Affine29 *__restrict__ mult, size_t n) {
+// blockIdx.y selects one of two point sets (proofs / commitments in one launch).
+__global__ __launch_bounds__(64) void k_point_multiples(const G1Affine29 *__restrict__ pts_a, const int32_t *__restrict__ kind_a,
+                                                        G1Affine29 *__restrict__ mult_a, const G1Affine29 *__restrict__ pts_b,
+                                                        const int32_t *__restrict__ kind_b, G1Affine29 *__restrict__ mult_b,
+                                                        size_t n) {
+    const G1Affine29 *pts = blockIdx.y ? pts_b : pts_a;
+    const int32_t *kind = blockIdx.y ? kind_b : kind_a;
+    G1Affine29 *mult = blockIdx.y ? mult_b : mult_a;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (kLincombPieces - 1) * n) return;
     const size_t i = gid % n;
     const int j = (int)(gid / n) + 1;
-    if (kind[i] != 0) {
+    if ((kind[i] & 0xff) != 0) {  // (bit 8 may carry a sign bit while the split validation is under way)
         mult[gid].x = F29<2>::zero();
         mult[gid].y = F29<2>::zero();
         return;
@@ -169,12 +175,25 @@ __global__ __launch_bounds__(64) void k_point_multiples(const G1Affine29 *__rest
     G1Affine29i p = ((const G1Affine29i *)pts)[i];
     G1Xyzz29i acc = G1Xyzz29i::from_affine(p.x, p.y);
     for (int k = 0; k < kPieceBits * j; k++) acc = xyzz_dbl(acc);
-    mult[gid] = xyzz29_to_affine29(*(G1Xyzz29 *)&acc);  // a point of prime order r: no multiple of it is the point at infinity
+    if (acc.is_inf()) {  // only a point off the subgroup can double away; its batch is rejected by the validation
+        mult[gid].x = F29<2>::zero();
+        mult[gid].y = F29<2>::zero();
+        return;
+    }
+    mult[gid] = xyzz29_to_affine29(*(G1Xyzz29 *)&acc);
 }
 
 void launch_point_multiples(const G1Affine29 *pts, const int32_t *kind, G1Affine29 *mult, size_t n, hipStream_t st) {
     ProfScope p("k_point_multiples", st);
-    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64)), dim3(64), 0, st, pts, kind, mult, n);
+    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64)), dim3(64), 0, st, pts, kind, mult,
+                       pts, kind, mult, n);
+}
+
+void launch_point_multiples2(const G1Affine29 *pts_a, const int32_t *kind_a, G1Affine29 *mult_a, const G1Affine29 *pts_b,
+                             const int32_t *kind_b, G1Affine29 *mult_b, size_t n, hipStream_t st) {
+    ProfScope p("k_point_multiples", st);
+    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64), 2), dim3(64), 0, st, pts_a, kind_a,
+                       mult_a, pts_b, kind_b, mult_b, n);
 }
 
 // The three linear combinations of verify_kzg_proof_batch (/root/reference/src/lib.rs:679-685) in ONE launch, on points

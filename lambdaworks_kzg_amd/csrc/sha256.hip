@@ -425,52 +425,26 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
     G1Affine29 aff;
     aff.x = F29<2>::zero();
     aff.y = F29<2>::zero();
-    uint8_t b[48], o[48];
-    for (int k = 0; k < 48; k++) b[k] = comm48[48 * i + k];
+    uint8_t o[48];
     for (int k = 0; k < 48; k++) o[k] = 0;
-    const uint8_t prefix = b[0] >> 5;
-    int rc = 0;
-    if (!(prefix & 4)) {
-        rc = 2;  // not flagged compressed
-    } else if (prefix & 2) {
-        o[0] = 0xc0;  // infinity; remaining input bits are not inspected (compression.rs:73-75)
-        rc = 1;
-    } else {
-        b[0] &= 0x1f;
-        uint32_t raw[12];
-        raw_from_be<12>(raw, b);
-        F29<2> x = f29_from_raw32(raw);  // x >= p is reduced, as upstream from_bytes_be is believed to
-        uint32_t four[12] = {4};
-        F29<2> y2 = (sqr(x) * x + f29_from_raw32(four)) * F29<1>::one();  // the product by R mod p reduces < 4p back to < 2p
-        const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
-                                0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
-        F29<2> y = f29_pow<12>(y2, e);  // y2^((p+1)/4)
-        if (!(sqr(y) - y2).is_zero()) {
-            rc = 2;  // x^3 + 4 is not a square: not on the curve
+    F29<2> x = F29<2>::zero(), y = F29<2>::zero();
+    bool want_greater = false;
+    int rc = g1_decompress29_nocheck(comm48 + 48 * i, x, y, want_greater);
+    if (rc == 1) {
+        o[0] = 0xc0;
+    } else if (rc == 0) {
+        uint32_t braw[12];
+        g1_beta_raw(braw);
+        if (!g1_in_subgroup_endo<G1Xyzz29>(x, y, f29_from_raw32(braw))) {
+            rc = 2;
         } else {
-            uint32_t ry[12], half[12], one[12] = {1};
-            f29_to_raw32(ry, y);
-            // y is the greater root  <=>  y > (p - 1) / 2
-            raw_sub<12>(half, FpParams::MOD, one);
-#pragma unroll
-            for (int k = 0; k < 11; k++) half[k] = (half[k] >> 1) | (half[k + 1] << 31);
-            half[11] >>= 1;
-            bool y_greater = !raw_geq<12>(half, ry);
-            bool want_greater = (prefix & 1) != 0;  // select_sqrt_value_from_third_bit
-            auto ysel = cneg(y, want_greater != y_greater);
-            uint32_t braw[12];
-            g1_beta_raw(braw);
-            if (!g1_in_subgroup_endo<G1Xyzz29>(x, ysel, f29_from_raw32(braw))) {
-                rc = 2;
-            } else {
-                uint32_t rx[12];
-                f29_to_raw32(rx, x);
-                raw_to_be<12>(o, rx);
-                o[0] |= 0x80;
-                if (want_greater) o[0] |= 0x20;
-                aff.x = x;
-                aff.y = ysel * F29<1>::one();  // back to < 2p
-            }
+            uint32_t rx[12];
+            f29_to_raw32(rx, x);
+            raw_to_be<12>(o, rx);
+            o[0] |= 0x80;
+            if (want_greater) o[0] |= 0x20;
+            aff.x = x;
+            aff.y = y;
         }
     }
     if (rc == 2) {
@@ -502,6 +476,72 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
     }
     hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, comm48, canon48, status,
                        bad_code, n, aff_out, kind_out);
+}
+
+// ---- the same validation in two launches, for the batch verification ------------------------------------------------
+// k_decompress_points: square root only. k_subgroup_canon: subgroup test + canonical bytes + verdicts. What lies
+// between them is the point of the split: the multiples the linear combinations want (setup.hip: k_point_multiples) need
+// the decompressed point but not the subgroup verdict, so they run BESIDE the second kernel instead of behind it.
+// kind carries the sign bit in bit 8 between the two kernels (rc | want_greater << 8) and is final (0 / 1 / 2) after
+// the second; readers in between mask with 0xff.
+
+__global__ __launch_bounds__(64) void k_decompress_points(const uint8_t *__restrict__ in48, G1Affine29 *__restrict__ pts,
+                                                          int32_t *__restrict__ kind, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F29<2> x = F29<2>::zero(), y = F29<2>::zero();
+    bool want_greater = false;
+    const int rc = g1_decompress29_nocheck(in48 + 48 * i, x, y, want_greater);
+    G1Affine29 aff;
+    aff.x = rc == 0 ? x : F29<2>::zero();
+    aff.y = rc == 0 ? y : F29<2>::zero();
+    pts[i] = aff;
+    kind[i] = rc | (want_greater ? 0x100 : 0);
+}
+
+__global__ __launch_bounds__(64) void k_subgroup_canon(G1Affine29 *__restrict__ pts, int32_t *__restrict__ kind,
+                                                       uint8_t *__restrict__ canon48, int32_t *__restrict__ status, int bad_code,
+                                                       size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k0 = kind[i];
+    int rc = k0 & 0xff;
+    uint8_t o[48];
+    for (int k = 0; k < 48; k++) o[k] = 0;
+    if (rc == 1) {
+        o[0] = 0xc0;
+    } else if (rc == 0) {
+        const G1Affine29 aff = pts[i];
+        uint32_t braw[12];
+        g1_beta_raw(braw);
+        if (!g1_in_subgroup_endo<G1Xyzz29>(aff.x, aff.y, f29_from_raw32(braw))) {
+            rc = 2;
+            G1Affine29 z;
+            z.x = F29<2>::zero();
+            z.y = F29<2>::zero();
+            pts[i] = z;
+        } else {
+            uint32_t rx[12];
+            f29_to_raw32(rx, aff.x);
+            raw_to_be<12>(o, rx);
+            o[0] |= 0x80;
+            if (k0 & 0x100) o[0] |= 0x20;
+        }
+    }
+    if (rc == 2) status[i] = bad_code;
+    for (int k = 0; k < 48; k++) canon48[48 * i + k] = o[k];
+    kind[i] = rc;
+}
+
+void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st) {
+    ProfScope p("k_decompress_points", st);
+    hipLaunchKernelGGL(k_decompress_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in48, pts, kind, n);
+}
+
+void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
+                           hipStream_t st) {
+    ProfScope p("k_subgroup_canon", st);
+    hipLaunchKernelGGL(k_subgroup_canon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pts, kind, canon48, status, bad_code, n);
 }
 
 }  // namespace lwk
