@@ -260,31 +260,44 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     const int mode = g_mode_now();
     if (!blob || !commitment_bytes || !proof_bytes || !s) return bad(mode);
     HostPoint c, pi;
-    // lib.rs:473-478: both points are decompressed before the blob is parsed (in c-kzg every failure of this function
-    // is BADARGS, so the order is not observable there). Decompressing here also validates: the per-blob GPU pass
-    // below is told the commitment's canonical bytes instead of re-deriving them with a validation kernel.
-    // (the proof is decompressed by a second thread meanwhile, and through the GPU pass, which does not need it)
-    bool pi_ok = false;
-    std::thread side([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
+    // lib.rs:473-478: both points are decompressed before the blob is parsed (every failure of this function has the
+    // same return code in either mode, so the order is not observable). Here both decompressions (0.2 ms each: square
+    // root + subgroup test) run on threads of their own BESIDE the per-blob GPU pass, which is started on the
+    // assumption that the caller's commitment bytes are the canonical encoding -- what the challenge hashes
+    // (utils.rs:138) -- and is repeated with the canonical bytes in the rare case that they are not (an infinity
+    // encoding with stray bits). Decompressing here also validates: the GPU pass needs no validation kernel.
+    bool pi_ok = false, c_ok = false;
+    std::thread side_pi([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
+    std::thread side_c([&]() { c_ok = host_g1_decompress(c, commitment_bytes->bytes); });
     struct Joiner {
-        std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } joiner{side};
-    if (!host_g1_decompress(c, commitment_bytes->bytes)) { set_error("invalid commitment"); return bad(mode); }
-    uint8_t canon_in[48];
+        std::thread &a, &b;
+        ~Joiner() {
+            if (a.joinable()) a.join();
+            if (b.joinable()) b.join();
+        }
+    } joiner{side_pi, side_c};
+    Ctx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    uint8_t zb[32], yb[32], canon[48], canon_in[48];
+    C_KZG_RET rc;
+    {
+        VerifyBuffers vb;
+        rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb,
+                                 commitment_bytes->bytes);
+    }
+    side_c.join();
+    if (!c_ok) { set_error("invalid commitment"); return bad(mode); }
     if (c.inf) {
         memset(canon_in, 0, 48);
         canon_in[0] = 0xc0;
     } else {
         g1_compress_affine(canon_in, c.a);
     }
-    Ctx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    uint8_t zb[32], yb[32], canon[48];
-    VerifyBuffers vb;
-    C_KZG_RET rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb,
-                                       canon_in);
-    side.join();
+    if (memcmp(canon_in, commitment_bytes->bytes, 48) != 0) {  // valid, but not the canonical bytes: hash those instead
+        VerifyBuffers vb;
+        rc = verify_prepare_host(ctx, blob->bytes, commitment_bytes->bytes, nullptr, 1, mode, zb, yb, canon, nullptr, vb, canon_in);
+    }
+    side_pi.join();
     if (!pi_ok) { set_error("invalid proof"); return bad(mode); }
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
     uint32_t z[8], y[8];

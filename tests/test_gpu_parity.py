@@ -904,3 +904,27 @@ def test_verify_batch_every_path_random_tamper(K, gpu_setup, oracle, n):
     for t in rnd.sample(range(n), min(n, 3)):
         assert K.verify_blob_kzg_proof(blobs[t], comms[t], proofs[t], gpu_setup) is True
         assert K.verify_blob_kzg_proof(blobs[t], comms[t], other, gpu_setup) is False
+
+
+def test_verify_single_blob_noncanonical_infinity_commitment(K, gpu_setup):
+    """verify_blob_kzg_proof starts its GPU pass on the caller's commitment bytes and repeats it when the decompression
+    (on a thread beside it) finds that they were not the canonical encoding: an infinity encoding with stray bits, for
+    the zero blob, must verify exactly like c0 00..00; an invalid commitment or proof is still an error"""
+    zero = bytes(B.BYTES_PER_BLOB)
+    inf = bytes([0xc0]) + bytes(47)
+    junk = bytes([0xc0]) + bytes(range(1, 48))
+    assert K.blob_to_kzg_commitment(zero, gpu_setup) == inf
+    assert K.compute_blob_kzg_proof(zero, inf, gpu_setup) == inf
+    for _ in range(3):
+        assert K.verify_blob_kzg_proof(zero, inf, inf, gpu_setup) is True
+        assert K.verify_blob_kzg_proof(zero, junk, inf, gpu_setup) is True
+        assert K.verify_blob_kzg_proof(zero, junk, junk, gpu_setup) is True
+    blob = B.synthetic_blob(4242)
+    c = K.blob_to_kzg_commitment(blob, gpu_setup)
+    p = K.compute_blob_kzg_proof(blob, c, gpu_setup)
+    assert K.verify_blob_kzg_proof(blob, c, p, gpu_setup) is True
+    assert K.verify_blob_kzg_proof(blob, junk, p, gpu_setup) is False
+    for badc, badp in ((bytes(48), p), (c, bytes(48)), (bytes([c[0] & 0x7f]) + c[1:], p)):
+        with pytest.raises(K.KzgError) as e:
+            K.verify_blob_kzg_proof(blob, badc, badp, gpu_setup)
+        assert e.value.rc == K.C_KZG_ERROR
