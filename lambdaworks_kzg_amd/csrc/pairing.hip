@@ -23,9 +23,12 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace lwk {
+
+unsigned host_threads();  // sha256_host.hip
 
 namespace {
 
@@ -409,18 +412,35 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
         const auto t0 = std::chrono::steady_clock::now();
         std::shared_ptr<const FixedQ> fq[4];
         for (int i = 0; i < n; i++) fq[i] = fixed_q_lines(q[i]);
-        size_t k = 0;
-        auto step = [&]() {
-            for (int i = 0; i < n; i++) {
-                const LineCoeff &lc = fq[i]->lines[k];
-                f = f12mul_by_line(f, lc.c0, f2neg(mul_fp(lc.lambda, px[i])), py[i]);
+        // Miller loop over the pairs [lo, hi): one squaring per bit shared by them
+        auto miller = [&](int lo, int hi) {
+            H12 g = f12one();
+            size_t k = 0;
+            auto step = [&]() {
+                for (int i = lo; i < hi; i++) {
+                    const LineCoeff &lc = fq[i]->lines[k];
+                    g = f12mul_by_line(g, lc.c0, f2neg(mul_fp(lc.lambda, px[i])), py[i]);
+                }
+                k++;
+            };
+            for (int bit = 62; bit >= 0; bit--) {
+                g = f12sqr(g);
+                step();
+                if ((z >> bit) & 1) step();
             }
-            k++;
+            return g;
         };
-        for (int bit = 62; bit >= 0; bit--) {
-            f = f12sqr(f);
-            step();
-            if ((z >> bit) & 1) step();
+        static const bool two_threads = host_threads() >= 2 && !getenv("LWKZG_PAIRING_ONE_THREAD");
+        if (n == 2 && two_threads) {
+            // the two pairings of a verification on two threads: each pays its own squarings (36 of the 74 field products
+            // of a step), but the loop takes 0.26 ms instead of 0.40 ms
+            H12 g1;
+            std::thread side([&]() { g1 = miller(1, 2); });
+            H12 g0 = miller(0, 1);
+            side.join();
+            f = g0 * g1;
+        } else {
+            f = miller(0, n);
         }
         static const bool timing = getenv("LWKZG_TIMING") != nullptr;
         if (!timing) return final_exponentiation_is_one(f12conj(f));  // z < 0
