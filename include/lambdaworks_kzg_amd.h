@@ -134,7 +134,9 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
  *   LWKZG_MODE_CKZG: what the c-kzg-4844 vectors under the reference's tests/ encode -- canonical
  *       little-endian scalars are evaluations on the bit-reversed 4096th roots of unity (inverse NTT
  *       in front of the same MSM), little-endian z/y/digest, invalid input is C_KZG_BADARGS.
- * Process-wide; initial value from the environment variable LWKZG_MODE ("reference"|"ckzg"). */
+ * Process-wide; initial value from the environment variable LWKZG_MODE ("reference"|"ckzg"). Every entry point
+ * reads the mode once, when it is entered: do not call lwkzg_set_mode while calls whose results should be in a
+ * particular mode are in flight on other threads. */
 #define LWKZG_MODE_REFERENCE 0
 #define LWKZG_MODE_CKZG 1
 int lwkzg_set_mode(int mode); /* returns the previous mode, or -1 if `mode` is invalid */
@@ -153,26 +155,41 @@ C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, c
 /* Device-resident forms: every pointer is a DEVICE pointer on the settings' GPU; `stream` is a
  * hipStream_t (NULL = the engine's own stream). Asynchronous: kernels are enqueued and the call
  * returns; per-blob status words (0 = ok, C_KZG_RET otherwise) are written to status_dev (n x int32,
- * may be NULL). No allocation happens here once lwkzg_reserve() has been called for >= n. */
+ * may be NULL). No allocation happens here once lwkzg_reserve() has been called for >= n (proof calls of more than
+ * 1024 blobs allocate n x 84 bytes once). Calls on one settings object share its workspace: whatever `stream` each is
+ * given, the library orders their GPU work one after the other (event dependencies, no host blocking), so two calls
+ * in flight on two streams are safe and serial. A proof call hashes and validates ALL its blobs up front (two latency
+ * chains of ~3 ms whose duration does not depend on n), then runs the MSMs chunk by chunk: one call of 4096 blobs
+ * pays them once, four calls of 1024 four times. */
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void *blobs_dev, size_t n,
                                                     const KZGSettings *s, void *stream, int32_t *status_dev);
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void *blobs_dev, const void *commitments48_dev,
                                                     size_t n, const KZGSettings *s, void *stream, int32_t *status_dev);
 C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
 
-/* Opt-in "direct" fixed-base MSM for this settings object: trade HBM capacity for arithmetic. With every
- * multiple d * 2^(window_bits * j) * P_i of every setup point resident (68 GB for window_bits = 14, 135 GB
- * for 15, 240 GB for 16), the 4096-term MSM behind every entry point above becomes 4096 * ceil(255 /
- * window_bits) gathered mixed additions: no digit sort, no buckets, no bucket reduction. Results are
- * bit-identical to the default path. window_bits = 0 frees the table and returns to the default path.
- * Returns C_KZG_MALLOC (engine unchanged, default path still usable) when the table does not fit, C_KZG_BADARGS for
+/* "Direct" fixed-base MSM for this settings object: trade HBM capacity for arithmetic. With every
+ * multiple d * 2^(window_bits * j) * P_i of every setup point resident (window_bits 10 .. 16: 6, 11, 21, 36, 68,
+ * 135, 240 GB), the 4096-term MSM behind every entry point above becomes 4096 * ceil(255 / window_bits) gathered
+ * mixed additions (26, 24, 22, 20, 19, 17, 16 per scalar): no digit sort, no buckets, no bucket reduction. Results
+ * are bit-identical between all widths and the bucket engine. window_bits = 0 frees the table and selects the bucket
+ * engine (9 MB table, 20 additions per scalar plus sort and reduction).
+ * Returns C_KZG_MALLOC (engine unchanged and still usable) when the table does not fit, C_KZG_BADARGS for
  * other widths. Replaces nothing in the reference: lambdaworks' pippenger::msm (call sites src/lib.rs:242,270,329,394)
- * has no precomputation at all. The environment variable LWKZG_DIRECT_BITS=14|15|16|auto makes every
- * load_trusted_setup* call do this itself (a table that does not fit is skipped silently), for consumers that only
- * know the nine reference symbols. */
+ * has no precomputation at all.
+ * What a load_trusted_setup* call selects by itself (for consumers that only know the nine reference symbols):
+ *   LWKZG_DIRECT_BITS unset  the DEFAULT engine: the widest table of 13 .. 10 bits that takes at most a quarter of the
+ *                            device memory free at load time (13 bits on an empty MI355X), else the bucket engine;
+ *   LWKZG_DIRECT_BITS=0      the bucket engine;   =10..16  that width (bucket engine if it does not fit);
+ *   LWKZG_DIRECT_BITS=auto   the widest of 16 .. 10 that fits. */
 C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits);
-int lwkzg_direct_table_bits(const KZGSettings *s);   /* 0 = default path, 14/15/16 = direct table live, -1 = bad settings */
+int lwkzg_direct_table_bits(const KZGSettings *s);   /* 0 = bucket engine, 10..16 = direct table live, -1 = bad settings */
 int lwkzg_direct_num_windows(int window_bits);       /* additions per scalar on the direct path (0 for other widths) */
+
+/* The Fiat-Shamir challenges of device-resident blobs: z_i = compute_challenge(blob_i, commitment_i)
+ * (src/utils.rs:120-154) as n x 32 bytes in the mode's byte order, canonical. This is the hash kernel of
+ * lwkzg_compute_blob_kzg_proof_batch_device on its own (test / pipeline hook); the commitment bytes are hashed as given. */
+C_KZG_RET lwkzg_compute_challenges_device(void *z32_dev, const void *blobs_dev, const void *commitments48_dev, size_t n,
+                                          const KZGSettings *s, void *stream);
 
 /* General G1 multi-scalar multiplication against the first `npoints` setup points:
  * scalars_dev = n_msm x npoints x 32 bytes (big-endian, reduced mod r), out = n_msm x 48 bytes compressed.

@@ -48,6 +48,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows",
+    "lwkzg_compute_challenges_device",
 ]
 
 _lib = None
@@ -80,6 +81,7 @@ def lib():
     l.lwkzg_compute_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
     l.lwkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
+    l.lwkzg_compute_challenges_device.argtypes = [vp, vp, vp, sz, ps, vp]
     l.lwkzg_reserve.argtypes = [ps, sz]
     l.lwkzg_enable_direct_table.argtypes = [ps, ci]
     l.lwkzg_direct_table_bits.argtypes = [ps]
@@ -202,7 +204,8 @@ class TrustedSetup:
         _check("lwkzg_reserve", lib().lwkzg_reserve(self.ref(), n))
 
     def enable_direct_table(self, window_bits):
-        """Opt in to (14 / 15 / 16) or out of (0) the giant-table MSM; raises KzgError(C_KZG_MALLOC) if it does not fit."""
+        """Select the direct-table MSM of that width (10 .. 16) or the bucket engine (0); raises KzgError(C_KZG_MALLOC) if
+        the table does not fit."""
         _check("lwkzg_enable_direct_table", lib().lwkzg_enable_direct_table(self.ref(), window_bits))
 
     def direct_table_bits(self):
@@ -304,6 +307,12 @@ def blob_to_kzg_commitment_batch_device(out_ptr, blobs_ptr, n, ts, stream=None, 
 def compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts, stream=None, status_ptr=None):
     _check("lwkzg_compute_blob_kzg_proof_batch_device",
            lib().lwkzg_compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts.ref(), stream, status_ptr))
+
+
+def compute_challenges_device(z_ptr, blobs_ptr, comm_ptr, n, ts, stream=None):
+    """z_i = compute_challenge(blob_i, commitment_i) for device-resident inputs (n x 32 bytes, mode's byte order)."""
+    _check("lwkzg_compute_challenges_device",
+           lib().lwkzg_compute_challenges_device(z_ptr, blobs_ptr, comm_ptr, n, ts.ref(), stream))
 
 
 def g1_lincomb_setup_device(out_ptr, scalars_be_ptr, n_msm, ts, stream=None):

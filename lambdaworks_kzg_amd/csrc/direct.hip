@@ -27,34 +27,49 @@ struct DirectPlan {
     static constexpr size_t ENTRIES = TOP_BASE + (size_t)kBlobElems * HTOP;
 };
 
-size_t direct_table_entries(int bits) {
-    switch (bits) {
-        case 14: return DirectPlan<14>::ENTRIES;
-        case 15: return DirectPlan<15>::ENTRIES;
-        case 16: return DirectPlan<16>::ENTRIES;
-        default: return 0;
-    }
+// the same plan as run-time values: the table builders and the generic accumulate kernel (widths 10 .. 13) take it as
+// a kernel argument; the three widest widths keep compile-time plans in the hot loop
+struct DirectPlanRt {
+    int c, nw, wtop;
+    uint32_t h, htop;
+    size_t top_base, entries;
+};
+
+static DirectPlanRt make_plan(int bits) {
+    DirectPlanRt p{};
+    if (bits < kDirectMinBits || bits > kDirectMaxBits) return p;
+    p.c = bits;
+    p.nw = (255 + bits - 1) / bits;
+    p.wtop = 255 - bits * (p.nw - 1);
+    p.h = 1u << (bits - 1);
+    p.htop = 1u << p.wtop;
+    p.top_base = (size_t)(p.nw - 1) * kBlobElems * p.h;
+    p.entries = p.top_base + (size_t)kBlobElems * p.htop;
+    return p;
 }
-int direct_num_windows(int bits) {
-    switch (bits) {
-        case 14: return DirectPlan<14>::NW;
-        case 15: return DirectPlan<15>::NW;
-        case 16: return DirectPlan<16>::NW;
-        default: return 0;
+
+template <int C>
+struct PlanOf {  // compile-time plan, converted
+    __host__ __device__ static constexpr DirectPlanRt get() {
+        return DirectPlanRt{C, DirectPlan<C>::NW, DirectPlan<C>::WTOP, (uint32_t)DirectPlan<C>::H, (uint32_t)DirectPlan<C>::HTOP,
+                            DirectPlan<C>::TOP_BASE, DirectPlan<C>::ENTRIES};
     }
-}
+};
+
+size_t direct_table_entries(int bits) { return make_plan(bits).entries; }
+int direct_num_windows(int bits) { return make_plan(bits).nw; }
 
 // ------------------------------------------------------------------------------------------------
 // table build, step 1: Q[j][i] = 2^(C j) P_i in affine hot-loop form (one lane per point)
 
-template <int C>
-__global__ __launch_bounds__(64) void k_direct_qbase(const G1Affine *__restrict__ points, G1Affine29 *__restrict__ qbase) {
+__global__ __launch_bounds__(64) void k_direct_qbase(const G1Affine *__restrict__ points, G1Affine29 *__restrict__ qbase, int C,
+                                                     int NW) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= kBlobElems) return;
     G1Affine29 a = affine_to_29(points[i]);
     qbase[i] = a;
     G1Xyzz29 cur = G1Xyzz29::from_affine(a.x, a.y);
-    for (int j = 1; j < DirectPlan<C>::NW; j++) {
+    for (int j = 1; j < NW; j++) {
         for (int d = 0; d < C; d++) cur = xyzz_dbl(cur);
         qbase[(size_t)j * kBlobElems + i] = xyzz29_to_affine29(cur);  // never infinity: P has prime order r
     }
@@ -70,11 +85,11 @@ __global__ __launch_bounds__(64) void k_direct_qbase(const G1Affine *__restrict_
 
 constexpr int kChunk = 64;
 
-template <int M>  // rows per (window, point) pair in this launch
+// M = rows per (window, point) pair in this launch (a power of two)
 __global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restrict__ qbase_win0, G1Affine29 *__restrict__ out_win0,
-                                                      size_t n_pairs, F29<2> *__restrict__ scratch, size_t n_threads) {
-    constexpr int K = M < kChunk ? M : kChunk;
-    constexpr size_t kChunksPerPair = M / K;
+                                                      size_t n_pairs, F29<2> *__restrict__ scratch, size_t n_threads, int M) {
+    const int K = M < kChunk ? M : kChunk;
+    const size_t kChunksPerPair = (size_t)(M / K);
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n_work = n_pairs * kChunksPerPair;
     // scratch rows: [m][5][lane] -> X, Y, ZZ, ZZZ (weakly reduced to < 2p) and the prefix product
@@ -115,41 +130,34 @@ __global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restri
     }
 }
 
-template <int C>
-static hipError_t build_direct_table_t(const G1Affine *points, G1Affine29 *table, hipStream_t st) {
-    typedef DirectPlan<C> P;
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st) {
+    const DirectPlanRt P = make_plan(bits);
+    if (!P.entries) return hipErrorInvalidValue;
     G1Affine29 *qbase = nullptr;
     F29<2> *scratch = nullptr;
-    const size_t n_threads = 256 * 1024;  // lanes in flight during the build (4.7 GB of scratch)
-    hipError_t e = hipMalloc((void **)&qbase, (size_t)P::NW * kBlobElems * sizeof(G1Affine29));
+    // lanes in flight during the build: 4.7 GB of scratch for the wide tables, a quarter of that (one wave per SIMD) for
+    // the narrow ones (the default engine's table should not need gigabytes of headroom to be built)
+    const size_t n_threads = bits >= 14 ? 256 * 1024 : 64 * 1024;
+    hipError_t e = hipMalloc((void **)&qbase, (size_t)P.nw * kBlobElems * sizeof(G1Affine29));
     if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)kChunk * 5 * n_threads * sizeof(F29<2>));
     if (e == hipSuccess) {
         {
             ProfScope p("k_direct_qbase", st);
-            hipLaunchKernelGGL(k_direct_qbase<C>, dim3(kBlobElems / 64), dim3(64), 0, st, points, qbase);
+            hipLaunchKernelGGL(k_direct_qbase, dim3(kBlobElems / 64), dim3(64), 0, st, points, qbase, P.c, P.nw);
         }
         {
             ProfScope p("k_direct_build", st);
-            hipLaunchKernelGGL((k_direct_build<P::H>), dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase, table,
-                               (size_t)(P::NW - 1) * kBlobElems, scratch, n_threads);
-            hipLaunchKernelGGL((k_direct_build<P::HTOP>), dim3((unsigned)(n_threads / 256)), dim3(256), 0, st,
-                               qbase + (size_t)(P::NW - 1) * kBlobElems, table + P::TOP_BASE, (size_t)kBlobElems, scratch,
-                               n_threads);
+            hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase, table,
+                               (size_t)(P.nw - 1) * kBlobElems, scratch, n_threads, (int)P.h);
+            hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st,
+                               qbase + (size_t)(P.nw - 1) * kBlobElems, table + P.top_base, (size_t)kBlobElems, scratch,
+                               n_threads, (int)P.htop);
         }
         e = hipStreamSynchronize(st);
     }
     if (qbase) hipFree(qbase);
     if (scratch) hipFree(scratch);
     return e;
-}
-
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st) {
-    switch (bits) {
-        case 14: return build_direct_table_t<14>(points, table, st);
-        case 15: return build_direct_table_t<15>(points, table, st);
-        case 16: return build_direct_table_t<16>(points, table, st);
-        default: return hipErrorInvalidValue;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -180,11 +188,14 @@ __device__ __forceinline__ G1Xyzz29 wave_fold(const G1Xyzz29 &in, int lane, int 
     return *(G1Xyzz29 *)&s;
 }
 
-template <int C>
+// CT = the window width as a compile-time constant (14, 15, 16), or 0: the plan is the kernel argument `rt`
+template <int CT>
 __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
                                                                    const uint4 *__restrict__ scalars,
-                                                                   G1Xyzz29 *__restrict__ partials, int scalars_per_lane) {
-    typedef DirectPlan<C> P;
+                                                                   G1Xyzz29 *__restrict__ partials, int scalars_per_lane,
+                                                                   DirectPlanRt rt) {
+    const DirectPlanRt P = CT ? PlanOf<CT ? CT : 16>::get() : rt;  // folds to constants when CT != 0
+    const int C = P.c;
     __shared__ uint32_t limbs[8 * kDirThreads];   // the lane's current scalar, for run-time window indexing
     __shared__ G1Xyzz29 wave_sum[kDirThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     const G1Affine29i *tab = (const G1Affine29i *)table;
     // tiny batches also split the windows of a scalar over gridDim.z workgroups; the signed-digit carry chain is
     // still walked from window 0 (a few integer ops per window), only the gathers and additions are confined
-    const int wper = (P::NW + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int wper = (P.nw + (int)gridDim.z - 1) / (int)gridDim.z;
     const int w_lo = (int)blockIdx.z * wper, w_hi = w_lo + wper;
 
     int q = 0, j = 0;
@@ -216,19 +227,19 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
             const int o = j * C, limb = o >> 5, sh = o & 31;
             uint32_t v = limbs[limb * kDirThreads + tid] >> sh;
             if (sh + C > 32 && limb + 1 < 8) v |= limbs[(limb + 1) * kDirThreads + tid] << (32 - sh);
-            const bool top = j == P::NW - 1;
-            uint32_t raw = (v & ((top ? (1u << P::WTOP) : (1u << C)) - 1u)) + carry;
-            uint32_t ng = (!top && raw > (uint32_t)P::H) ? 1u : 0u;
+            const bool top = j == P.nw - 1;
+            uint32_t raw = (v & ((top ? (1u << P.wtop) : (1u << C)) - 1u)) + carry;
+            uint32_t ng = (!top && raw > P.h) ? 1u : 0u;
             uint32_t mag = ng ? (1u << C) - raw : raw;
             carry = ng;
-            size_t idx = top ? P::TOP_BASE + (size_t)point * P::HTOP + (mag - 1)
-                             : ((size_t)j * kBlobElems + point) * P::H + (mag - 1);
+            size_t idx = top ? P.top_base + (size_t)point * P.htop + (mag - 1)
+                             : ((size_t)j * kBlobElems + point) * P.h + (mag - 1);
             j++;
-            if (j == P::NW) {
+            if (j == P.nw) {
                 j = 0;
                 q++;
             }
-            const int jw = (j == 0 ? P::NW : j) - 1;  // the window this digit belongs to (j was advanced above)
+            const int jw = (j == 0 ? P.nw : j) - 1;  // the window this digit belongs to (j was advanced above)
             if (mag && jw >= w_lo && jw < w_hi) {
                 valid = true;
                 neg = ng;
@@ -271,9 +282,9 @@ __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__
     if (lane == 0) sums[b] = s;
 }
 
-template <int C>
-static void launch_direct_t(const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
-                            size_t n_blobs, hipStream_t st) {
+template <int CT>
+static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials,
+                            G1Xyzz29 *sums, size_t n_blobs, hipStream_t st) {
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
     // 16 workgroups so the chip fills and the dependent chain per lane stays short
     static const int kFill = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 512;
@@ -284,8 +295,8 @@ static void launch_direct_t(const G1Affine29 *table, const uint32_t *scalars_raw
     const int parts = blocks_per_blob * wsplit;
     {
         ProfScope p("k_direct_accumulate", st);
-        hipLaunchKernelGGL(k_direct_accumulate<C>, dim3(blocks_per_blob, (unsigned)n_blobs, wsplit), dim3(kDirThreads), 0, st,
-                           table, (const uint4 *)scalars_raw, parts == 1 ? sums : partials, scalars_per_lane);
+        hipLaunchKernelGGL(k_direct_accumulate<CT>, dim3(blocks_per_blob, (unsigned)n_blobs, wsplit), dim3(kDirThreads), 0, st,
+                           table, (const uint4 *)scalars_raw, parts == 1 ? sums : partials, scalars_per_lane, plan);
     }
     if (parts > 1) {
         ProfScope p("k_direct_fold", st);
@@ -295,11 +306,13 @@ static void launch_direct_t(const G1Affine29 *table, const uint32_t *scalars_raw
 
 void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
                        size_t n_blobs, hipStream_t st) {
+    const DirectPlanRt plan = make_plan(bits);
+    if (!plan.entries) return;
     switch (bits) {
-        case 14: launch_direct_t<14>(table, scalars_raw, partials, sums, n_blobs, st); break;
-        case 15: launch_direct_t<15>(table, scalars_raw, partials, sums, n_blobs, st); break;
-        case 16: launch_direct_t<16>(table, scalars_raw, partials, sums, n_blobs, st); break;
-        default: break;
+        case 14: launch_direct_t<14>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;
+        case 15: launch_direct_t<15>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;
+        case 16: launch_direct_t<16>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;
+        default: launch_direct_t<0>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;  // 10 .. 13
     }
 }
 

@@ -1,8 +1,12 @@
 // engine.h -- per-settings device context and the batch pipelines behind the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/lambdaworks_kzg_amd.h"
 #include "kernels.h"
@@ -25,6 +29,29 @@ const char *get_error();
         }                                                                                     \
     } while (0)
 
+// A piece of host work that runs beside the caller when a thread can be had, and inline when it cannot:
+// std::thread's constructor throws std::system_error under resource exhaustion, and nothing may unwind across the C ABI.
+struct SideTask {
+    std::thread t;
+    SideTask() = default;
+    template <class F>
+    explicit SideTask(F &&f) { start(static_cast<F &&>(f)); }
+    template <class F>
+    void start(F &&f) {
+        try {
+            t = std::thread(f);
+        } catch (...) {
+            f();
+        }
+    }
+    void join() {
+        if (t.joinable()) t.join();
+    }
+    ~SideTask() { join(); }
+    SideTask(const SideTask &) = delete;
+    SideTask &operator=(const SideTask &) = delete;
+};
+
 struct Workspace {
     size_t cap = 0;  // blobs
     uint8_t *blobs = nullptr;        // host-API staging: cap x 131072
@@ -43,6 +70,12 @@ struct Workspace {
     uint8_t *ybytes = nullptr;       // cap x 32
     Fr *z = nullptr;                 // cap
     int32_t *status = nullptr;       // cap
+    // device-resident proof calls longer than one chunk hash / validate ALL their blobs up front (both kernels are
+    // latency chains whose run time does not depend on the batch size); grow-only
+    size_t long_cap = 0;             // blobs
+    Fr *z_long = nullptr;            // long_cap
+    uint8_t *canon_long = nullptr;   // long_cap x 48
+    int32_t *status_long = nullptr;  // long_cap (when the caller passes no status array)
 };
 
 // device-side scratch of one batch verification (points kept between its two GPU phases). The memory belongs to the
@@ -78,6 +111,10 @@ struct Ctx {
     hipStream_t vstream;            // point-validation kernels (a plain stream of their own; see ctx_new on CU masks)
     hipStream_t aux[kMaxSplit];     // sub-batch streams of commit_batch_device
     hipEvent_t ev_fork, ev_join[kMaxSplit];
+    // The workspace is shared by every call on this settings object, whatever stream the caller passes: each call
+    // makes its stream wait for the event the previous user of the workspace recorded (WsUse, engine.hip).
+    hipEvent_t ws_done;
+    hipStream_t ws_last;
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
     G1Affine29 *table;  // kTablePoints, hot-loop representation
     G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled

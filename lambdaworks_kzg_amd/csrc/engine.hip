@@ -10,8 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <map>
+#include <atomic>
 #include <chrono>
+#include <map>
+#include <set>
 #include <thread>
 #include <vector>
 
@@ -38,7 +40,7 @@ struct ProfRec {
     const char *name;
     hipEvent_t e0, e1;
 };
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_pending;
 struct ProfAgg {
@@ -47,7 +49,7 @@ struct ProfAgg {
 };
 static std::map<std::string, ProfAgg> g_prof_agg;
 
-ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), st(s), e0(nullptr), e1(nullptr), on(g_prof_on) {
+ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), st(s), e0(nullptr), e1(nullptr), on(g_prof_on.load(std::memory_order_relaxed)) {
     if (!on) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         on = false;
@@ -81,8 +83,37 @@ static void prof_drain() {
 // context registry (for KZGSettings built by hand: fs == NULL, caller-owned g1_values)
 
 static std::mutex g_reg_mu;
-static std::map<const void *, Ctx *> g_registry;
-static int g_default_device = 0;
+// hand-built settings: keyed by the g1_values pointer, re-checked against a digest of the first and last point so that
+// a caller that frees and reallocates g1_values at the same address does not silently get the stale context
+struct RegEntry {
+    Ctx *ctx;
+    uint64_t digest;
+};
+static std::map<const void *, RegEntry> g_registry;
+static std::set<const void *> g_live_fs;  // every live Ctx (== the fs pointer it handed out)
+static std::atomic<int> g_default_device{0};
+
+static uint64_t g1_values_digest(const g1_t *g1) {
+    uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a over the first and the last setup point
+    const uint8_t *a = (const uint8_t *)&g1[0], *b = (const uint8_t *)&g1[kBlobElems - 1];
+    for (size_t i = 0; i < sizeof(g1_t); i++) h = (h ^ a[i]) * 0x100000001b3ull;
+    for (size_t i = 0; i < sizeof(g1_t); i++) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
+
+// Every call that touches the shared workspace on stream `st` brackets its enqueues with this: the stream first waits
+// for whatever used the workspace last (a no-op on the same stream), and leaves the event for the next user.
+struct WsUse {
+    Ctx *c;
+    hipStream_t st;
+    WsUse(Ctx *c_, hipStream_t st_) : c(c_), st(st_) {
+        if (c->ws_last != st) hipStreamWaitEvent(st, c->ws_done, 0);
+    }
+    ~WsUse() {
+        hipEventRecord(c->ws_done, st);
+        c->ws_last = st;
+    }
+};
 
 static C_KZG_RET dev_alloc(void **p, size_t bytes) {
     LWK_HIP(hipMalloc(p, bytes));
@@ -115,13 +146,20 @@ static void ws_free(Workspace &w) {
     w.cap = 0;
 }
 
+static void ws_long_free(Workspace &w) {
+    dev_free(w.z_long);
+    dev_free(w.canon_long);
+    dev_free(w.status_long);
+    w.long_cap = 0;
+}
+
 C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
     if (n > kMaxChunk) n = kMaxChunk;
     if (n == 0) n = 1;
     Workspace &w = c->ws;
     if (w.cap >= n) return C_KZG_OK;
     LWK_HIP(hipSetDevice(c->device));
-    LWK_HIP(hipStreamSynchronize(c->stream));
+    LWK_HIP(hipDeviceSynchronize());  // work on ANY stream (the caller's included) may still be using the old buffers
     ws_free(w);
     // round up so that repeated small growth does not reallocate every call
     size_t cap = 1;
@@ -159,8 +197,9 @@ void direct_from_env(const KZGSettings *s);
 static void ctx_destroy(Ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    hipDeviceSynchronize();  // every stream of the context, and the callers' streams that ran its work
     ws_free(c->ws);
+    ws_long_free(c->ws);
     vs_free(c);
     dev_free(c->points);
     dev_free(c->table);
@@ -174,10 +213,15 @@ static void ctx_destroy(Ctx *c) {
         if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]);
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ws_done) hipEventDestroy(c->ws_done);
     free(c->fs.expanded_roots_of_unity);
     free(c->fs.reverse_roots_of_unity);
     free(c->fs.roots_of_unity);
     c->magic = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_live_fs.erase((const void *)c);
+    }
     delete c;
 }
 
@@ -200,8 +244,10 @@ static C_KZG_RET ctx_new(Ctx **out) {
     Ctx *c = new Ctx();
     memset(&c->fs, 0, sizeof c->fs);
     c->magic = kCtxMagic;
-    c->device = g_default_device;
+    c->device = g_default_device.load();
     c->stream = nullptr;
+    c->ws_done = nullptr;
+    c->ws_last = nullptr;
     c->vstream = nullptr;
     c->ev_fork = nullptr;
     for (int k = 0; k < kMaxSplit; k++) {
@@ -222,6 +268,7 @@ static C_KZG_RET ctx_new(Ctx **out) {
     // the GPU, and was removed.)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_done, hipEventDisableTiming);
     for (int k = 0; k < kMaxSplit && e == hipSuccess; k++) {
         e = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming);
@@ -234,6 +281,10 @@ static C_KZG_RET ctx_new(Ctx **out) {
         set_error("device context allocation failed: %s", hipGetErrorString(e));
         ctx_destroy(c);
         return C_KZG_MALLOC;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_live_fs.insert((const void *)c);
     }
     *out = c;
     return C_KZG_OK;
@@ -279,18 +330,29 @@ Ctx *ctx_of(const KZGSettings *s) {
         set_error("KZGSettings pointer is NULL");
         return nullptr;
     }
+    // fs is only dereferenced when it is one of OUR contexts: a genuine FFTSettings from another c-kzg-style producer
+    // is 32 bytes long and has no magic word behind it
     if (s->fs) {
-        Ctx *c = (Ctx *)s->fs;
-        if (c->magic == kCtxMagic) return c;
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (g_live_fs.count((const void *)s->fs)) return (Ctx *)s->fs;
     }
     // hand-built settings (the reference's own layout: fs == NULL): build and cache a context from g1_values
     if (!s->g1_values) {
         set_error("KZGSettings has neither an engine context nor g1_values");
         return nullptr;
     }
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    auto it = g_registry.find(s->g1_values);
-    if (it != g_registry.end()) return it->second;
+    const uint64_t digest = g1_values_digest(s->g1_values);
+    Ctx *stale = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_registry.find(s->g1_values);
+        if (it != g_registry.end()) {
+            if (it->second.digest == digest) return it->second.ctx;
+            stale = it->second.ctx;  // same address, other contents: the caller rebuilt its array
+            g_registry.erase(it);
+        }
+    }
+    if (stale) ctx_destroy(stale);
     Ctx *c = nullptr;
     if (ctx_new(&c) != C_KZG_OK) return nullptr;
     uint64_t *d_blst = nullptr;
@@ -320,7 +382,25 @@ Ctx *ctx_of(const KZGSettings *s) {
         ctx_destroy(c);
         return nullptr;
     }
-    g_registry[s->g1_values] = c;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_registry.find(s->g1_values);
+        if (it != g_registry.end()) {  // another thread built one meanwhile: keep the first
+            Ctx *first = it->second.ctx;
+            if (it->second.digest == digest) {
+                // (ctx_destroy takes g_reg_mu itself)
+                stale = c;
+                c = first;
+            } else {
+                stale = first;
+                it->second = {c, digest};
+            }
+        } else {
+            stale = nullptr;
+            g_registry[s->g1_values] = {c, digest};
+        }
+    }
+    if (stale) ctx_destroy(stale);
     return c;
 }
 
@@ -367,13 +447,11 @@ static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode,
 // sub-batches per launch set. The bucket path gains from two (its sort / reduce / inversion tails hide behind the
 // other half's accumulation); the direct path has no such tails and runs as one launch.
 static int split_ways(bool direct) {
-    static int v = -1;
-    if (v < 0) {
+    static const int v = [] {
         const char *e = getenv("LWKZG_SPLIT");
-        v = e ? atoi(e) : 0;
-        if (v < 0) v = 0;
-        if (v > kMaxSplit) v = kMaxSplit;
-    }
+        int x = e ? atoi(e) : 0;
+        return x < 0 ? 0 : x > kMaxSplit ? kMaxSplit : x;
+    }();
     return v ? v : (direct ? 1 : 2);
 }
 
@@ -416,32 +494,58 @@ C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size
     return C_KZG_OK;
 }
 
+// z and the canonical commitment bytes of a proof call longer than one chunk
+static C_KZG_RET ws_long_reserve(Ctx *c, size_t n) {
+    Workspace &w = c->ws;
+    if (w.long_cap >= n) return C_KZG_OK;
+    LWK_HIP(hipDeviceSynchronize());
+    ws_long_free(w);
+    size_t cap = 2 * kMaxChunk;
+    while (cap < n) cap <<= 1;
+    if (hipMalloc((void **)&w.z_long, cap * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&w.canon_long, cap * 48) != hipSuccess ||
+        hipMalloc((void **)&w.status_long, cap * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        ws_long_free(w);
+        set_error("proof batch of %zu blobs: out of device memory for the challenges", n);
+        return C_KZG_MALLOC;
+    }
+    w.long_cap = cap;
+    return C_KZG_OK;
+}
+
 C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode,
                                   hipStream_t st, int32_t *status) {
     C_KZG_RET rc = ctx_reserve(c, n);
     if (rc != C_KZG_OK) return rc;
+    const bool longcall = n > kMaxChunk;
+    if (longcall) {
+        rc = ws_long_reserve(c, n);
+        if (rc != C_KZG_OK) return rc;
+    }
     Workspace &w = c->ws;
     const int le = mode == LWKZG_MODE_CKZG;
+    int32_t *stt = status ? status : longcall ? w.status_long : w.status;
+    Fr *z = longcall ? w.z_long : w.z;
+    uint8_t *canon = longcall ? w.canon_long : w.canon48;
+    LWK_HIP(hipMemsetAsync(stt, 0, n * 4, st));
+    // lib.rs:372-375: the commitment is decompressed (and subgroup-checked) first. Validation (a long scalar
+    // multiplication per lane) and hashing (131 KB per lane pair) are both latency chains whose run time does not depend
+    // on the number of blobs (2 ms and 3.2 ms for anything from 64 blobs to one workgroup per compute unit, 16k), and independent as long as
+    // the caller's bytes are the canonical encoding, which they are except for exotic encodings of infinity: ALL
+    // blobs of the call are hashed optimistically from the caller's bytes on `st` while the validation stream
+    // validates all commitments, then only the lanes whose canonical bytes differ are redone. A call of several chunks
+    // therefore pays the two chains once, not once per chunk.
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
+    launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
+    LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
+    launch_challenge(blobs, comm48, z, le, n, st);
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+    launch_challenge(blobs, canon, z, le, n, st, comm48);
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        int32_t *stt = status ? status + off : w.status;
-        const uint8_t *bl = blobs + off * (size_t)kBlobBytes;
-        const uint8_t *cm = comm48 + 48 * off;
-        LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
-        // lib.rs:372-375: the commitment is decompressed (and subgroup-checked) first. Validation (a long scalar
-        // multiplication per lane) and hashing (131 KB per lane) are both latency-shaped and independent as long as
-        // the caller's bytes are the canonical encoding, which they are except for exotic encodings of infinity:
-        // hash optimistically from the caller's bytes on `st` while an auxiliary stream validates, then redo only
-        // the lanes whose canonical bytes differ.
-        LWK_HIP(hipEventRecord(c->ev_fork, st));
-        LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
-        launch_validate_commitments(cm, w.canon48, stt, le ? kStatusBadArgs : kStatusError, m, c->vstream);
-        LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
-        coefficients_stage(c, bl, m, mode, stt, st);
-        launch_challenge(bl, cm, w.z, le, m, st);
-        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
-        launch_challenge(bl, w.canon48, w.z, le, m, st, cm);
-        launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+        coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt + off, st);
+        launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
         msm_stages(c, w.scalars2, out48 + 48 * off, m, st);
     }
     return C_KZG_OK;
@@ -503,7 +607,7 @@ static void vs_free(Ctx *c) {
 // grow-only verify scratch for n blobs; the caller holds verify_mu
 static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
     if (c->vs_cap >= n) return C_KZG_OK;
-    LWK_HIP(hipStreamSynchronize(c->stream));
+    LWK_HIP(hipDeviceSynchronize());  // the validation / multiples streams included
     vs_free(c);
     size_t cap = 64;
     while (cap < n) cap <<= 1;
@@ -577,8 +681,7 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         hipStream_t sk = nullptr;
         const uint8_t *hb = nullptr, *hc = nullptr;
         std::vector<uint8_t> dig;
-        std::thread hasher;
-        ~Slot() { if (hasher.joinable()) hasher.join(); }
+        SideTask hasher;  // joined by its destructor
     } slots[2];
 
     auto begin = [&](Slot &s, size_t off, size_t m, int idx) -> C_KZG_RET {
@@ -591,7 +694,7 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         s.hc = comm48 + 48 * off;
         s.dig.resize(32 * m);
         Slot *sp = &s;  // digests assume the caller's commitment bytes are canonical; finish() confirms or refutes that
-        s.hasher = std::thread([sp]() { challenge_digests_host(sp->dig.data(), sp->hb, sp->hc, sp->m); });
+        s.hasher.start([sp]() { challenge_digests_host(sp->dig.data(), sp->hb, sp->hc, sp->m); });
         uint8_t *d_blobs = w.blobs + s.base * (size_t)kBlobBytes;
         LWK_HIP(hipMemcpyAsync(d_blobs, s.hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, s.sk));
         LWK_HIP(hipMemsetAsync(w.status + s.base, 0, m * 4, s.sk));
@@ -663,6 +766,19 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
     const int le = mode == LWKZG_MODE_CKZG;
     const int bad = le ? kStatusBadArgs : kStatusError;
     hipStream_t st = c->stream;
+    WsUse wsu(c, st);
+    // No exit of this function may leave a validation / multiples kernel running on the side streams against scratch
+    // that the next verification (or vs_reserve) is about to reuse: an early error return drains them.
+    struct SideDrain {
+        Ctx *c;
+        bool armed = true;
+        ~SideDrain() {
+            if (!armed) return;
+            hipStreamSynchronize(c->vstream);
+            hipStreamSynchronize(c->aux[0]);
+            hipStreamSynchronize(c->aux[1]);
+        }
+    } drain{c};
     {
         C_KZG_RET rcv = vs_reserve(c, n);
         if (rcv != C_KZG_OK) return rcv;
@@ -686,12 +802,8 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         // commitment bytes are canonical; the comparison below confirms or refutes that.
         const uint8_t *hash_comm = trusted_canon_c ? trusted_canon_c + 48 * off : hc;
         const bool hash_beside = m > 64;  // a few blobs: hashing takes microseconds, a thread and its contention do not pay
-        std::thread hasher;
-        if (hash_beside) hasher = std::thread([&, hash_comm]() { challenge_digests_host(dig.data(), hb, hash_comm, m); });
-        struct Joiner {
-            std::thread &t;
-            ~Joiner() { if (t.joinable()) t.join(); }
-        } joiner{hasher};
+        SideTask hasher;  // joined by its destructor on every exit
+        if (hash_beside) hasher.start([&, hash_comm]() { challenge_digests_host(dig.data(), hb, hash_comm, m); });
         LWK_HIP(hipMemcpyAsync(w.comm48, hc, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
         // up to 64 blobs: both point sets are validated on the host threads (0.2 ms per point per thread against a 2 ms
@@ -778,6 +890,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         if (proofs48 && !host_validate)  // the linear combinations (main stream, later) read the multiples
             LWK_HIP(hipStreamWaitEvent(st, c->ev_join[2], 0));
     }
+    drain.armed = false;  // everything on the side streams has been joined into the main stream
     return C_KZG_OK;
 }
 
@@ -828,15 +941,20 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
 
 using namespace lwk;
 
-static int g_mode = -1;
+// Process-wide semantics switch. Every entry point reads it ONCE, at its start; lwkzg_set_mode must not race calls
+// whose result should be in a particular mode (documented in the header).
+static std::atomic<int> g_mode{-1};
 
 static int mode_now() {
-    if (g_mode < 0) {
+    int m = g_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
         const char *e = getenv("LWKZG_MODE");
-        g_mode = (e && (!strcmp(e, "ckzg") || !strcmp(e, "c") || !strcmp(e, "C") || !strcmp(e, "1"))) ? LWKZG_MODE_CKZG
-                                                                                                      : LWKZG_MODE_REFERENCE;
+        m = (e && (!strcmp(e, "ckzg") || !strcmp(e, "c") || !strcmp(e, "C") || !strcmp(e, "1"))) ? LWKZG_MODE_CKZG
+                                                                                                 : LWKZG_MODE_REFERENCE;
+        int expect = -1;
+        if (!g_mode.compare_exchange_strong(expect, m)) m = expect;
     }
-    return g_mode;
+    return m;
 }
 
 extern "C" {
@@ -844,7 +962,7 @@ extern "C" {
 int lwkzg_set_mode(int mode) {
     int prev = mode_now();
     if (mode != LWKZG_MODE_REFERENCE && mode != LWKZG_MODE_CKZG) return -1;
-    g_mode = mode;
+    g_mode.store(mode);
     return prev;
 }
 int lwkzg_get_mode(void) { return mode_now(); }
@@ -860,7 +978,7 @@ int lwkzg_set_device(int ordinal) {
         set_error("lwkzg_set_device(%d): %d device(s) visible", ordinal, n);
         return -1;
     }
-    g_default_device = ordinal;
+    g_default_device.store(ordinal);
     return 0;
 }
 const char *lwkzg_version(void) { return "lambdaworks_kzg_amd 0.1 (gfx950; fixed-base Pippenger c=13, 20 windows)"; }
@@ -870,7 +988,7 @@ int lwkzg_msm_num_windows(void) { return kNumWindows; }
 
 void lwkzg_profile_enable(int on) {
     if (!on) prof_drain();
-    g_prof_on = on != 0;
+    g_prof_on.store(on != 0);
 }
 void lwkzg_profile_reset(void) {
     prof_drain();
@@ -1036,14 +1154,16 @@ C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in) {
 C_KZG_RET free_trusted_setup(KZGSettings *s) {
     if (!s) return C_KZG_OK;
     Ctx *c = nullptr;
-    if (s->fs && ((Ctx *)s->fs)->magic == kCtxMagic) {
-        c = (Ctx *)s->fs;
-    } else {
+    {
         std::lock_guard<std::mutex> lk(g_reg_mu);
-        auto it = g_registry.find(s->g1_values);
-        if (it != g_registry.end()) {
-            c = it->second;
-            g_registry.erase(it);
+        if (s->fs && g_live_fs.count((const void *)s->fs)) {
+            c = (Ctx *)s->fs;
+        } else {
+            auto it = g_registry.find(s->g1_values);
+            if (it != g_registry.end()) {
+                c = it->second.ctx;
+                g_registry.erase(it);
+            }
         }
     }
     ctx_destroy(c);
@@ -1096,6 +1216,7 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
+    WsUse wsu(c, c->stream);
     // (the bucket engine overlaps the tails of its own sub-batches inside commit_batch_device, which a lone 512-blob slice
     // would forgo: it takes the single pass up to a whole chunk)
     if (n < 512 || (!c->direct_table && n <= kMaxChunk)) {  // one launch set, results and verdicts back in one go
@@ -1298,11 +1419,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
         const uint8_t *hb = blobs + off * (size_t)kBlobBytes, *hc = comm48 + 48 * off;
         uint8_t *dig = h_dig.data() + 32 * off;
-        std::thread hasher([=]() { challenge_digests_host(dig, hb, hc, cnt); });
-        struct Joiner {
-            std::thread &t;
-            ~Joiner() { if (t.joinable()) t.join(); }
-        } joiner{hasher};
+        SideTask hasher([=]() { challenge_digests_host(dig, hb, hc, cnt); });
         const auto ta = now();
         LWK_HIP(hipMemcpyAsync(d_blobs, hb, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
         const auto tb = now();
@@ -1354,6 +1471,7 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
+    WsUse wsu(c, c->stream);
     if (n >= kMaxChunk / 2)
         return blob_proofs_sliced(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, n, mode, first_bad);
     for (size_t off = 0; off < n; off += kMaxChunk) {
@@ -1369,11 +1487,7 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
         // this thread for a few milliseconds. The digests assume the caller's commitment bytes are the canonical
         // encoding; the validation's re-compression confirms or refutes that below.
         std::vector<uint8_t> h_canon(m * 48), h_dig(m * 32);
-        std::thread hasher([&]() { challenge_digests_host(h_dig.data(), h_blobs, h_comm, m); });
-        struct Joiner {
-            std::thread &t;
-            ~Joiner() { if (t.joinable()) t.join(); }
-        } joiner{hasher};
+        SideTask hasher([&]() { challenge_digests_host(h_dig.data(), h_blobs, h_comm, m); });
         LWK_HIP(hipMemcpyAsync(w.blobs, h_blobs, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemcpyAsync(w.comm48, h_comm, m * 48, hipMemcpyHostToDevice, st));
         LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
@@ -1434,6 +1548,7 @@ C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, c
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
+    WsUse wsu(c, c->stream);
     if (n >= kMaxChunk / 2)
         return point_proofs_sliced(c, (uint8_t *)proofs_out, (uint8_t *)ys_out, (const uint8_t *)blobs, (const uint8_t *)zs, n, mode,
                                    first_bad);
@@ -1485,30 +1600,38 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
-    LWK_HIP(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < kMaxSplit; k++) LWK_HIP(hipStreamSynchronize(c->aux[k]));
+    LWK_HIP(hipDeviceSynchronize());  // the table may be in use on any stream, the callers' included
     if (window_bits == c->direct_bits) return C_KZG_OK;
-    dev_free(c->direct_table);
-    c->direct_bits = 0;
-    if (window_bits == 0) return C_KZG_OK;
-    const size_t rows = direct_table_entries(window_bits);
-    if (rows == 0) {
-        set_error("lwkzg_enable_direct_table: window_bits must be 0, 14, 15 or 16 (got %d)", window_bits);
+    if (window_bits != 0 && direct_table_entries(window_bits) == 0) {
+        set_error("lwkzg_enable_direct_table: window_bits must be 0 or 10 .. 16 (got %d)", window_bits);
         return C_KZG_BADARGS;
     }
-    G1Affine29 *t = nullptr;
-    hipError_t e = hipMalloc((void **)&t, rows * sizeof(G1Affine29));
-    if (e == hipSuccess) {
-        e = build_direct_table(window_bits, c->points, t, c->stream);
-        if (e != hipSuccess) hipFree(t);
-    }
+    const int old_bits = c->direct_bits;
+    dev_free(c->direct_table);  // (the old and the new table need not fit side by side)
+    c->direct_bits = 0;
+    if (window_bits == 0) return C_KZG_OK;
+    auto build = [&](int bits) -> hipError_t {
+        G1Affine29 *t = nullptr;
+        hipError_t e = hipMalloc((void **)&t, direct_table_entries(bits) * sizeof(G1Affine29));
+        if (e == hipSuccess) {
+            e = build_direct_table(bits, c->points, t, c->stream);
+            if (e != hipSuccess) hipFree(t);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // an out-of-memory here is an answer, not a sticky failure
+            return e;
+        }
+        c->direct_table = t;
+        c->direct_bits = bits;
+        return hipSuccess;
+    };
+    const hipError_t e = build(window_bits);
     if (e != hipSuccess) {
-        (void)hipGetLastError();  // an out-of-memory here is an answer, not a sticky failure
-        set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, rows * sizeof(G1Affine29), hipGetErrorString(e));
+        if (old_bits) (void)build(old_bits);  // the engine the settings had stays in place
+        set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, direct_table_entries(window_bits) * sizeof(G1Affine29),
+                  hipGetErrorString(e));
         return C_KZG_MALLOC;
     }
-    c->direct_table = t;
-    c->direct_bits = window_bits;
     return C_KZG_OK;
 }
 
@@ -1526,6 +1649,7 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void 
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
     return commit_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, n, mode_now(), st, status_dev);
 }
 
@@ -1536,8 +1660,32 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void 
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
     return blob_proof_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev,
                                    n, mode_now(), st, status_dev);
+}
+
+// z_i = compute_challenge(blob_i, commitment_i) (src/utils.rs:120-154) for device-resident blobs, as 32 bytes in the
+// mode's byte order (canonical, reduced mod r): the Fiat-Shamir kernel of the proof path, exposed so that a test can
+// put its output next to hashlib's at any batch size. The commitment bytes are hashed as given (the proof path
+// hashes the canonical re-compression; for canonical inputs the two are the same bytes).
+C_KZG_RET lwkzg_compute_challenges_device(void *z32_dev, const void *blobs_dev, const void *commitments48_dev, size_t n,
+                                          const KZGSettings *s, void *stream) {
+    if (!z32_dev || !blobs_dev || !commitments48_dev) return C_KZG_BADARGS;
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
+    C_KZG_RET rc = ctx_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    if (n > kMaxChunk && (rc = ws_long_reserve(c, n)) != C_KZG_OK) return rc;
+    const int le = mode_now() == LWKZG_MODE_CKZG;
+    Fr *z = n > kMaxChunk ? c->ws.z_long : c->ws.z;
+    launch_challenge((const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev, z, le, n, st);
+    launch_fr_mont_to_bytes(z, (uint8_t *)z32_dev, le, n, st);
+    return C_KZG_OK;
 }
 
 C_KZG_RET lwkzg_g1_lincomb_setup_device(void *out48_dev, const void *scalars_be_dev, size_t n_msm, const KZGSettings *s,
@@ -1547,6 +1695,7 @@ C_KZG_RET lwkzg_g1_lincomb_setup_device(void *out48_dev, const void *scalars_be_
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
     C_KZG_RET rc = ctx_reserve(c, n_msm);
     if (rc != C_KZG_OK) return rc;
     for (size_t off = 0; off < n_msm; off += kMaxChunk) {
@@ -1570,6 +1719,7 @@ C_KZG_RET lwkzg_g1_msm_tiled_device(void *out48_dev, const void *scalars_be_dev,
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
     const size_t tiles = n_terms / kBlobElems;
     C_KZG_RET rc = ctx_reserve(c, tiles);
     if (rc != C_KZG_OK) return rc;
@@ -1591,6 +1741,7 @@ C_KZG_RET lwkzg_fr_ntt4096_device(void *out_dev, const void *in_dev, size_t n, i
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
     C_KZG_RET rc = ctx_reserve(c, n);
     if (rc != C_KZG_OK) return rc;
     Workspace &w = c->ws;
@@ -1681,17 +1832,34 @@ C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev) {
 }  // extern "C"
 
 namespace lwk {
-// LWKZG_DIRECT_BITS = 14 | 15 | 16 | auto: a consumer that only knows the reference's nine symbols opts in to the
-// direct table from its environment; every load then tries to enable it (auto: the widest that fits) and quietly
-// stays on the default engine when it does not fit.
+// Which MSM engine a freshly loaded setup gets. A consumer that only knows the reference's nine symbols never calls
+// lwkzg_enable_direct_table, so the choice is made here, at the end of every load:
+//   LWKZG_DIRECT_BITS unset : the DEFAULT engine = the widest direct table of 13 .. 10 bit windows that takes at most a
+//                             quarter of the device memory that is free right now (13 bits = 36 GB on an empty MI355X:
+//                             20 additions per scalar, no sort, no buckets, no reduction); the bucket engine when
+//                             even the 10-bit table (6 GB) does not pass that test, e.g. beside another process's table
+//   LWKZG_DIRECT_BITS=0     : the bucket engine (9 MB table), whatever is free
+//   LWKZG_DIRECT_BITS=10..16: that width, or the bucket engine when it does not fit
+//   LWKZG_DIRECT_BITS=auto  : the widest of 16 .. 10 that fits at all (what bench.py's headline asks for explicitly)
 void direct_from_env(const KZGSettings *s) {
     const char *v = getenv("LWKZG_DIRECT_BITS");
-    if (!v || !*v) return;
-    if (!strcmp(v, "auto")) {
-        for (int bits = 16; bits >= 14; bits--)
-            if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
+    if (v && *v) {
+        if (!strcmp(v, "auto")) {
+            for (int bits = kDirectMaxBits; bits >= kDirectMinBits; bits--)
+                if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
+            return;
+        }
+        if (atoi(v) != 0) (void)lwkzg_enable_direct_table(s, atoi(v));
         return;
     }
-    (void)lwkzg_enable_direct_table(s, atoi(v));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (int bits = 13; bits >= kDirectMinBits; bits--)
+        if (direct_table_entries(bits) * sizeof(G1Affine29) <= free_b / 4) {
+            if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
+        }
 }
 }  // namespace lwk

@@ -90,11 +90,9 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt4096(const Fr *__restrict__ 
 
 void launch_ntt4096(const Fr *in, Fr *out, const Fr *tw, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st) {
     ProfScope p("k_ntt4096", st);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const hipError_t attr_set =
         hipFuncSetAttribute((const void *)k_ntt4096, hipFuncAttributeMaxDynamicSharedMemorySize, kBlobElems * 32);
-        attr_set = true;
-    }
+    (void)attr_set;
     hipLaunchKernelGGL(k_ntt4096, dim3((unsigned)n_blobs), dim3(kNttThreads), kBlobElems * 32, st, in, out, tw,
                        inverse_scale_to_raw);
 }

@@ -37,7 +37,9 @@ void launch_sum_points(const G1Xyzz29 *in, size_t n, G1Xyzz29 *total, int accumu
 void launch_finalize_compress(const G1Xyzz29 *sums, uint8_t *out48, size_t n, hipStream_t st);
 
 // ---- direct fixed-base MSM (direct.hip): every multiple d * 2^(bits j) * P_i precomputed, no buckets.
-// bits in {14, 15, 16}; the table has direct_table_entries(bits) rows of 112 bytes (68 / 135 / 240 GB).
+// bits in 10 .. 16; the table has direct_table_entries(bits) rows of 112 bytes
+// (6 / 11 / 21 / 36 / 68 / 135 / 240 GB); 0 rows for any other width.
+constexpr int kDirectMinBits = 10, kDirectMaxBits = 16;
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
 hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st);

@@ -372,11 +372,7 @@ __global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz29 *_
 }
 
 static int reduce_lanes_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("LWKZG_REDUCE_LANES");
-        v = e ? atoi(e) : 0;
-    }
+    static const int v = getenv("LWKZG_REDUCE_LANES") ? atoi(getenv("LWKZG_REDUCE_LANES")) : 0;
     return v;
 }
 

@@ -298,8 +298,7 @@ H12 cyclotomic_sqr(const H12 &a) {
 // a^x for the (negative) curve parameter x = -0xd201000000010000, a in the cyclotomic subgroup
 // (where the inverse is the conjugate). LWKZG_PAIRING_GENERIC_SQR=1 squares with the generic product (cross-check).
 H12 exp_by_x(const H12 &a) {
-    static int generic = -1;
-    if (generic < 0) generic = getenv("LWKZG_PAIRING_GENERIC_SQR") ? 1 : 0;
+    static const int generic = getenv("LWKZG_PAIRING_GENERIC_SQR") ? 1 : 0;
     H12 acc = a;  // bit 63
     for (int i = 62; i >= 0; i--) {
         acc = generic ? acc * acc : cyclotomic_sqr(acc);
@@ -316,8 +315,7 @@ H12 exp_by_x(const H12 &a) {
 bool final_exponentiation_is_one(const H12 &f) {
     H12 t = f12conj(f) * f12inv(f);  // f^(p^6 - 1)
     t = frob_p2(t) * t;               // ^(p^2 + 1)
-    static int naive = -1;
-    if (naive < 0) naive = getenv("LWKZG_PAIRING_NAIVE") ? 1 : 0;
+    static const int naive = getenv("LWKZG_PAIRING_NAIVE") ? 1 : 0;
     if (naive) {
         auto m12 = [](const H12 &a, const H12 &b) { return a * b; };
         return f12is_one(pow_big<H12>(t, f12one(), g_c.hard, g_c.hard_n, m12));
@@ -406,8 +404,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
         py[i] = HFp::from_fe(ps[i].y);
     }
     H12 f = f12one();
-    static int on_the_fly = -1;  // LWKZG_PAIRING_NO_PRECOMP=1: the loop below that walks T itself (cross-check)
-    if (on_the_fly < 0) on_the_fly = getenv("LWKZG_PAIRING_NO_PRECOMP") ? 1 : 0;
+    static const int on_the_fly = getenv("LWKZG_PAIRING_NO_PRECOMP") ? 1 : 0;  // =1: the loop below that walks T itself (cross-check)
     if (!on_the_fly) {
         const auto t0 = std::chrono::steady_clock::now();
         std::shared_ptr<const FixedQ> fq[4];
@@ -435,7 +432,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
             // the two pairings of a verification on two threads: each pays its own squarings (36 of the 74 field products
             // of a step), but the loop takes 0.26 ms instead of 0.40 ms
             H12 g1;
-            std::thread side([&]() { g1 = miller(1, 2); });
+            SideTask side([&]() { g1 = miller(1, 2); });  // (runs inline when no thread can be had)
             H12 g0 = miller(0, 1);
             side.join();
             f = g0 * g1;

@@ -8,6 +8,7 @@
 // already in HBM, so one lane per blob streams it through the compression function (16 B loads).
 // SHA-256 is sequential per message: the parallelism is across the blobs of the batch.
 #include <stdlib.h>
+#include <atomic>
 #include "kernels.h"
 
 namespace lwk {
@@ -466,13 +467,13 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
     // validation workgroup) exceed the 160 KB of a compute unit, so the dispatcher has to pick another one. The hash
     // of 1024 blobs takes 3.2 ms instead of 4.3 ms beside it (LWKZG_VALIDATE_LDS_PAD=0 switches the padding off).
     static const unsigned lds_pad = getenv("LWKZG_VALIDATE_LDS_PAD") ? (unsigned)atoi(getenv("LWKZG_VALIDATE_LDS_PAD")) : 112u * 1024u;
-    static bool pad_ok = true;  // a runtime that refuses the footprint gets the plain launch from then on
-    if (lds_pad && pad_ok) {
+    static std::atomic<bool> pad_ok{true};  // a runtime that refuses the footprint gets the plain launch from then on
+    if (lds_pad && pad_ok.load(std::memory_order_relaxed)) {
         (void)hipGetLastError();
         hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), lds_pad, st, comm48, canon48,
                            status, bad_code, n, aff_out, kind_out);
         if (hipGetLastError() == hipSuccess) return;
-        pad_ok = false;
+        pad_ok.store(false);
     }
     hipLaunchKernelGGL(k_validate_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, comm48, canon48, status,
                        bad_code, n, aff_out, kind_out);

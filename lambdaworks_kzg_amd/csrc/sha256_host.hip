@@ -90,9 +90,8 @@ __attribute__((target("sha,sse4.1,ssse3"))) void compress_shani(uint32_t state[8
 }
 
 bool have_shani() {
-    static int v = -1;
-    if (v < 0) v = (__builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3")) ? 1 : 0;
-    return v == 1;
+    static const bool v = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+    return v;
 }
 
 // digest of header(32) | blob(131072) | commitment(48), the compute_challenge message
@@ -198,7 +197,13 @@ namespace {
 class HostPool {
   public:
     explicit HostPool(unsigned workers) : pid_(getpid()) {
-        for (unsigned k = 0; k < workers; k++) std::thread([this]() { worker(); }).detach();
+        for (unsigned k = 0; k < workers; k++) {
+            try {
+                std::thread([this]() { worker(); }).detach();
+            } catch (...) {
+                break;  // fewer workers (none: the caller does everything itself); nothing unwinds across the C ABI
+            }
+        }
     }
     pid_t pid() const { return pid_; }
 

@@ -147,7 +147,7 @@ C_KZG_RET verify_core(bool *ok, const HostPoint &c, const uint32_t z[8], const u
         return C_KZG_ERROR;
     }
     HXyzz zpi;
-    std::thread side([&]() { zpi = scalar_mul(to_xyzz(pi), z); });  // the two scalar multiplications side by side
+    SideTask side([&]() { zpi = scalar_mul(to_xyzz(pi), z); });  // the two scalar multiplications side by side
     HXyzz lhs = xyzz_add(to_xyzz(c), xyzz_neg(scalar_mul(to_xyzz(g), y)));  // C - [y]G
     side.join();
     lhs = xyzz_add(lhs, zpi);                                               //   + [z]pi
@@ -243,7 +243,7 @@ C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Byte
     // order of the reference: commitment, z, y, proof (lib.rs:424-440)
     // (every failure here is the same return code, so the two decompressions may run side by side)
     bool pi_ok = false;
-    std::thread side([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
+    SideTask side([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
     const bool c_ok = host_g1_decompress(c, commitment_bytes->bytes);
     side.join();
     if (!c_ok) { set_error("invalid commitment"); return bad(mode); }
@@ -267,15 +267,8 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     // (utils.rs:138) -- and is repeated with the canonical bytes in the rare case that they are not (an infinity
     // encoding with stray bits). Decompressing here also validates: the GPU pass needs no validation kernel.
     bool pi_ok = false, c_ok = false;
-    std::thread side_pi([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
-    std::thread side_c([&]() { c_ok = host_g1_decompress(c, commitment_bytes->bytes); });
-    struct Joiner {
-        std::thread &a, &b;
-        ~Joiner() {
-            if (a.joinable()) a.join();
-            if (b.joinable()) b.join();
-        }
-    } joiner{side_pi, side_c};
+    SideTask side_pi([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });  // joined by their destructors on
+    SideTask side_c([&]() { c_ok = host_g1_decompress(c, commitment_bytes->bytes); });  // every exit
     Ctx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
     uint8_t zb[32], yb[32], canon[48], canon_in[48];
@@ -404,11 +397,7 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         ys_raw[2 * k + 1] = (uint32_t)(ysum.l[k] >> 32);
     }
     HXyzz ysum_g;
-    std::thread side([&]() { ysum_g = scalar_mul(to_xyzz(g), ys_raw); });
-    struct Joiner {
-        std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } joiner{side};
+    SideTask side([&]() { ysum_g = scalar_mul(to_xyzz(g), ys_raw); });
     // three variable-base linear combinations (g1_lincomb, lib.rs:679-685): on the GPU over the points the validation
     // kernels left there, or on the host threads when the batch was small enough to be validated there
     uint8_t sums[3][96];

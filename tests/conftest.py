@@ -51,11 +51,33 @@ def K():
 
 @pytest.fixture(scope="session")
 def gpu_setup(K):
+    """What a consumer of the nine reference symbols gets: a plain load, engine chosen by the library (on an empty
+    MI355X the 13-bit direct table, engine.hip: direct_from_env)."""
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    assert not os.environ.get("LWKZG_DIRECT_BITS"), "the GPU tests expect the library's own choice of engine"
+    ts = K.TrustedSetup.from_file(SETUP_PATH)
+    ts.default_bits = ts.direct_table_bits()
+    yield ts
+    ts.free()
+
+
+@pytest.fixture(scope="session")
+def bucket_setup(K):
+    """The low-memory engine (9 MB table, Pippenger buckets), forced."""
     import torch
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     ts = K.TrustedSetup.from_file(SETUP_PATH)
+    ts.enable_direct_table(0)
+    assert ts.direct_table_bits() == 0
     yield ts
     ts.free()
+
+
+@pytest.fixture(scope="session", params=["default", "bucket"])
+def engine_setup(request, gpu_setup, bucket_setup):
+    """The two engines a plain load can end up on."""
+    return gpu_setup if request.param == "default" else bucket_setup
 
 
 def tau_closed_form(oracle, scalars):

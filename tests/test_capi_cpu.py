@@ -170,12 +170,14 @@ def test_direct_table_plan_constants(K):
     """window plan of the opt-in direct table: pure host arithmetic, callable without a GPU"""
     from lambdaworks_kzg_amd import capi
     l = K.lib()
-    assert [l.lwkzg_direct_num_windows(b) for b in (13, 14, 15, 16, 17)] == [0, 19, 17, 16, 0]
+    assert [l.lwkzg_direct_num_windows(b) for b in (9, 10, 11, 12, 13, 14, 15, 16, 17)] == [0, 26, 24, 22, 20, 19, 17, 16, 0]
     # 15 signed windows of 2^15 rows + one 15-bit top window of 2^15 rows, per point, 112 bytes per row
     assert capi.direct_table_bytes(16) == (15 * 4096 * 32768 + 4096 * 32768) * 112 == 240518168576
     assert capi.direct_table_bytes(15) == (16 * 4096 * 16384 + 4096 * 32768) * 112
     assert capi.direct_table_bytes(14) == (18 * 4096 * 8192 + 4096 * 8) * 112
-    for bits in (14, 15, 16):   # every scalar bit is covered exactly once: (NW - 1) * bits + top == 255
+    assert capi.direct_table_bytes(13) == (19 * 4096 * 4096 + 4096 * 256) * 112 == 35_819_356_160   # the default engine on an empty MI355X
+    assert capi.direct_table_bytes(10) == (25 * 4096 * 512 + 4096 * 32) * 112
+    for bits in range(10, 17):   # every scalar bit is covered exactly once: (NW - 1) * bits + top == 255
         nw = l.lwkzg_direct_num_windows(bits)
         assert 0 < 255 - bits * (nw - 1) <= bits
 

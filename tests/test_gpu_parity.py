@@ -119,8 +119,9 @@ def test_ntt_roundtrip_and_linearity_batch_256(K, gpu_setup):
         assert _host(d_fs) == want
 
 
-def test_msm_kernel_vs_oracle_and_closed_form(K, gpu_setup, oracle, oracle_setup):
+def test_msm_kernel_vs_oracle_and_closed_form(K, engine_setup, oracle, oracle_setup):
     import torch
+    gpu_setup = engine_setup
     from lambdaworks_kzg_amd import capi
     rnd = random.Random(12)
     sets = [[rnd.randrange(R) for _ in range(4096)],
@@ -161,7 +162,8 @@ def test_lib_test_rs_behaviours(K, gpu_setup, oracle_setup):
     assert K.blob_to_kzg_commitment(bytes(B.BYTES_PER_BLOB), gpu_setup) == bytes([0xc0]) + bytes(47)
 
 
-def test_commitment_reference_mode_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+def test_commitment_reference_mode_vs_oracle(K, engine_setup, oracle, oracle_setup):
+    gpu_setup = engine_setup
     blobs = [B.synthetic_blob(i) for i in range(5)]
     blobs += [B.make_blob(n) for n in ("pow2", "pow3", "pow5", "r_minus_1", "delta_3211", "zero", "all_ff", "r_at_2111")]
     got = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
@@ -265,7 +267,8 @@ def test_compute_blob_kzg_proof_ckzg_vectors(K, gpu_setup, vectors):
     assert n == 10
 
 
-def test_proofs_reference_mode_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+def test_proofs_reference_mode_vs_oracle(K, engine_setup, oracle, oracle_setup):
+    gpu_setup = engine_setup
     blobs = [B.synthetic_blob(40 + i) for i in range(3)] + [B.make_blob("pow2"), B.make_blob("r_minus_1"), B.make_blob("zero")]
     comms = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
     proofs = K.compute_blob_kzg_proof_batch(b"".join(blobs), b"".join(comms), gpu_setup)
@@ -302,9 +305,10 @@ def test_blob_proof_rejects_bad_commitment(K, gpu_setup):
 
 # ---- full-size properties (BASELINE config 2: batch up to 1024) ------------------------------------------
 
-def test_batch_1024_device_resident_closed_form_and_determinism(K, gpu_setup, oracle):
+def test_batch_1024_device_resident_closed_form_and_determinism(K, engine_setup, oracle):
     import numpy as np
     import torch
+    gpu_setup = engine_setup
     n = 1024
     data = B.synthetic_batch(1000, n)
     d_blobs = _dev(data)
@@ -318,8 +322,8 @@ def test_batch_1024_device_resident_closed_form_and_determinism(K, gpu_setup, or
     K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, gpu_setup, None, d_status.data_ptr())
     torch.cuda.synchronize()
     assert _host(d_out) == first
-    # closed form for a spread of blobs, incl. first/last of the batch
-    for i in (0, 1, 63, 64, 511, 1022, 1023):
+    # closed form for EVERY blob of the batch
+    for i in range(n):
         blob = data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
         assert first[48 * i:48 * i + 48] == tau_closed_form(oracle, B.blob_scalars(blob)), i
     # linearity: commit(a) + commit(b) == commit(a + b) -- checked through scalars: blob c = a + b mod r
@@ -351,6 +355,7 @@ def test_setup_image_export_import_roundtrip(K, gpu_setup, oracle):
     blob = B.synthetic_blob(9)
     assert K.blob_to_kzg_commitment(blob, ts2) == tau_closed_form(oracle, B.blob_scalars(blob))
     # what every rank > 0 of the multi-GPU bench does: build its own direct table from the imported points
+    assert ts2.direct_table_bits() == gpu_setup.default_bits     # an imported setup gets the default engine like a loaded one
     ts2.enable_direct_table(14)
     data = B.synthetic_batch(40, 5)
     assert K.blob_to_kzg_commitment_batch(data, ts2) == K.blob_to_kzg_commitment_batch(data, gpu_setup)
@@ -511,9 +516,10 @@ def test_load_free_cycles_and_two_settings(K, oracle, oracle_setup):
     b.free()
 
 
-def test_adversarial_blobs_closed_form(K, gpu_setup, oracle):
+def test_adversarial_blobs_closed_form(K, engine_setup, oracle):
     """digit patterns that stress the bucket machinery: all scalars equal (20 buckets of 4096 entries), two values
     alternating, a single non-zero scalar, scalars whose every window is the signed-digit boundary"""
+    gpu_setup = engine_setup
     c = 13
     boundary = sum((1 << (c - 1)) << (c * j) for j in range(19))        # every window = 2^(c-1)
     boundary1 = sum(((1 << (c - 1)) + 1) << (c * j) for j in range(19))  # every window = 2^(c-1)+1 -> negative digits + carries
@@ -530,10 +536,11 @@ def test_adversarial_blobs_closed_form(K, gpu_setup, oracle):
         assert g == tau_closed_form(oracle, ss)
 
 
-def test_ckzg_mode_random_blobs_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+def test_ckzg_mode_random_blobs_vs_oracle(K, engine_setup, oracle, oracle_setup):
     """c-kzg semantics on random canonical little-endian blobs (not only the formula blobs of the vectors):
     commitment, blob proof and point proof against the oracle, then verification."""
     K.set_mode(K.MODE_CKZG)
+    gpu_setup = engine_setup
     blobs = [B.synthetic_blob(300 + i, big_endian=False) for i in range(3)]
     comms = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
     proofs = K.compute_blob_kzg_proof_batch(b"".join(blobs), b"".join(comms), gpu_setup)
@@ -613,35 +620,45 @@ def test_noncanonical_infinity_commitment_takes_gpu_hash_fallback(K, gpu_setup, 
 
 # ---- opt-in direct (giant table) MSM: bit-identical to the default path --------------------------------------
 
-@pytest.fixture(scope="module", params=[14, 15, 16])
-def direct_setup(request, K, gpu_setup):
+# 13 bits is what a plain load selects on an empty device (gpu_setup); the other widths are opted into here. The two
+# widest tables (135 / 240 GB) do not fit beside the session's default table, which steps aside while they are tested.
+@pytest.fixture(scope="module", params=[10, 12, 14, 15, 16])
+def direct_setup(request, K, gpu_setup, bucket_setup):
     import torch
+    wide = request.param >= 15
+    if wide:
+        gpu_setup.enable_direct_table(0)
     ts = K.TrustedSetup.from_file(SETUP_PATH)
-    assert ts.direct_table_bits() == 0
+    assert ts.direct_table_bits() in (10, 11, 12, 13)           # the library's own choice (engine.hip: direct_from_env)
     try:
         ts.enable_direct_table(request.param)
     except K.KzgError as e:
         ts.free()
+        if wide:
+            gpu_setup.enable_direct_table(gpu_setup.default_bits)
         assert e.rc == K.C_KZG_MALLOC
         pytest.skip("direct table of width %d does not fit on this device" % request.param)
     assert ts.direct_table_bits() == request.param
     yield ts, request.param
     ts.enable_direct_table(0)
     assert ts.direct_table_bits() == 0
-    # back on the default path the same object still answers
+    # on the bucket engine the same object still answers
     blob = B.synthetic_blob(77)
-    assert K.blob_to_kzg_commitment(blob, ts) == K.blob_to_kzg_commitment(blob, gpu_setup)
+    assert K.blob_to_kzg_commitment(blob, ts) == K.blob_to_kzg_commitment(blob, bucket_setup)
     ts.free()
     torch.cuda.empty_cache()
+    if wide:
+        gpu_setup.enable_direct_table(gpu_setup.default_bits)
 
 
 def test_direct_table_bad_width(K, gpu_setup):
-    with pytest.raises(K.KzgError) as e:
-        gpu_setup.enable_direct_table(13)
-    assert e.value.rc == K.C_KZG_BADARGS
-    assert gpu_setup.direct_table_bits() == 0
-    assert K.lib().lwkzg_direct_num_windows(16) == 16 and K.lib().lwkzg_direct_num_windows(15) == 17
-    assert K.lib().lwkzg_direct_num_windows(14) == 19 and K.lib().lwkzg_direct_num_windows(13) == 0
+    for bad in (9, 17, -1, 64):
+        with pytest.raises(K.KzgError) as e:
+            gpu_setup.enable_direct_table(bad)
+        assert e.value.rc == K.C_KZG_BADARGS
+        assert gpu_setup.direct_table_bits() == gpu_setup.default_bits      # the engine it had stays in place
+    nw = K.lib().lwkzg_direct_num_windows
+    assert [nw(b) for b in (9, 10, 11, 12, 13, 14, 15, 16, 17)] == [0, 26, 24, 22, 20, 19, 17, 16, 0]
 
 
 def test_direct_adversarial_digits_closed_form(K, direct_setup, oracle):
@@ -668,15 +685,17 @@ def test_direct_adversarial_digits_closed_form(K, direct_setup, oracle):
 
 
 @pytest.mark.parametrize("n", [1, 3, 64, 200, 700, 1024])
-def test_direct_commitments_match_default_path(K, direct_setup, gpu_setup, oracle, n):
-    """every launch geometry of the direct kernel (16 .. 1 workgroups per blob) against the bucket path"""
+def test_direct_commitments_match_default_path(K, direct_setup, bucket_setup, oracle, n):
+    """every launch geometry of the direct kernel (16 .. 1 workgroups per blob): every commitment against the tau closed
+    form, and against the bucket engine (an independent algorithm)"""
     ts, _ = direct_setup
+    gpu_setup = bucket_setup
     data = B.synthetic_batch(5000 + n, n)
     want = K.blob_to_kzg_commitment_batch(data, gpu_setup)
     got = K.blob_to_kzg_commitment_batch(data, ts)
     assert got == want
-    blob0 = data[:B.BYTES_PER_BLOB]
-    assert got[0] == tau_closed_form(oracle, B.blob_scalars(blob0))
+    for i in range(n):
+        assert got[i] == tau_closed_form(oracle, B.blob_scalars(data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB])), i
     if n >= 700:    # the sliced proof paths on the direct engine (700: the 128 + 384 + rest schedule)
         cm = b"".join(got)
         assert K.compute_blob_kzg_proof_batch(data, cm, ts) == K.compute_blob_kzg_proof_batch(data, cm, gpu_setup)
@@ -684,8 +703,24 @@ def test_direct_commitments_match_default_path(K, direct_setup, gpu_setup, oracl
         assert K.compute_kzg_proof_batch(data, zs, ts) == K.compute_kzg_proof_batch(data, zs, gpu_setup)
 
 
-def test_direct_proofs_both_modes_match_default_path(K, direct_setup, gpu_setup, oracle, oracle_setup):
+@pytest.mark.parametrize("n,first,mode_c", [(70, 21200, False), (256, 22000, False), (256, 22000, True), (1024, 23000, False)])
+def test_direct_device_resident_blob_proofs_every_blob_vs_oracle(K, direct_setup, oracle, n, first, mode_c):
+    """the path `bench.py --op blob_proof` times, on every direct-table width: all proofs of the batch against the CPU
+    oracle (the oracle's results are shared with tests/test_gpu_proof_parity.py, which runs the default and bucket engines)"""
+    from proof_cases import oracle_batch
+    from test_gpu_proof_parity import device_commit_and_prove
     ts, _ = direct_setup
+    K.set_mode(K.MODE_CKZG if mode_c else K.MODE_REFERENCE)
+    blobs, want_c, want_p = oracle_batch(oracle, first, n, mode_c)
+    comms, proofs = device_commit_and_prove(K, ts, b"".join(blobs), n)
+    for i in range(n):
+        assert comms[48 * i:48 * i + 48] == want_c[i], ("commitment", i)
+        assert proofs[48 * i:48 * i + 48] == want_p[i], ("proof", i)
+
+
+def test_direct_proofs_both_modes_match_default_path(K, direct_setup, bucket_setup, oracle, oracle_setup):
+    ts, _ = direct_setup
+    gpu_setup = bucket_setup
     rnd = random.Random(23)
     for mode, be, omode in ((K.MODE_REFERENCE, True, oracle.MODE_R), (K.MODE_CKZG, False, oracle.MODE_C)):
         K.set_mode(mode)
@@ -702,12 +737,13 @@ def test_direct_proofs_both_modes_match_default_path(K, direct_setup, gpu_setup,
         assert K.verify_blob_kzg_proof_batch(joined, b"".join(comms), b"".join(proofs), 5, ts) is True
 
 
-def test_direct_tiled_long_msm(K, direct_setup, gpu_setup, oracle):
+def test_direct_tiled_long_msm(K, direct_setup, bucket_setup, oracle):
     """2^18-term tiled MSM through the direct table == the bucket path == the closed form"""
     import numpy as np
     import torch
     from lambdaworks_kzg_amd import capi
     ts, _ = direct_setup
+    gpu_setup = bucket_setup
     tiles = 64
     data = B.synthetic_batch(7000, tiles)
     d_sc = _dev(data)
@@ -745,19 +781,23 @@ def test_verify_long_batch_pipelined_path(K, gpu_setup):
     assert e.value.rc == K.C_KZG_ERROR
 
 
-def test_direct_table_that_does_not_fit_leaves_the_default_engine(K, direct_setup, gpu_setup):
-    """a second settings object asking for a table the device can no longer hold gets C_KZG_MALLOC and keeps working on
-    the bucket path (only meaningful while the 240 GB table of the fixture is resident)"""
+def test_direct_table_that_does_not_fit_leaves_the_engine_in_place(K, direct_setup, gpu_setup):
+    """a second settings object loaded beside the 240 GB table gets a narrower default engine (a quarter of what is
+    still free) or the bucket engine; asking it for a table the device can no longer hold returns C_KZG_MALLOC and
+    leaves the engine it had (only meaningful while the 240 GB table of the fixture is resident)"""
     ts, bits = direct_setup
     if bits != 16:
         pytest.skip("needs the 240 GB table resident")
     other = K.TrustedSetup.from_file(SETUP_PATH)
+    had = other.direct_table_bits()
+    assert had in (0, 10, 11, 12) and had < gpu_setup.default_bits
     with pytest.raises(K.KzgError) as e:
         other.enable_direct_table(16)
     assert e.value.rc == K.C_KZG_MALLOC
-    assert other.direct_table_bits() == 0
+    assert other.direct_table_bits() == had
     blob = B.synthetic_blob(31337)
     assert K.blob_to_kzg_commitment(blob, other) == K.blob_to_kzg_commitment(blob, ts) == K.blob_to_kzg_commitment(blob, gpu_setup)
+    other.free()
     other.free()
 
 

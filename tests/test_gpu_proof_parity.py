@@ -1,0 +1,123 @@
+"""GPU: the device-resident proof path (what `bench.py --op blob_proof` times, BASELINE configs[2]) against the CPU
+oracle on EVERY blob of the batch, at the benchmark's sizes and at partial-workgroup sizes, on both engines a plain load
+can select and in both modes; the Fiat-Shamir kernel against hashlib at scale.
+Reference: /root/reference/src/lib.rs:361-404, /root/reference/src/utils.rs:120-154."""
+import pytest
+
+import blobs as B
+from conftest import R, tau_closed_form
+from proof_cases import challenge_int, oracle_batch, reference_mode_proof_closed_form
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(data):
+    import torch
+    return torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+
+
+def _host(t):
+    return bytes(t.cpu().numpy().tobytes())
+
+
+@pytest.fixture(autouse=True)
+def _reference_mode(K):
+    K.set_mode(K.MODE_REFERENCE)
+    yield
+    K.set_mode(K.MODE_REFERENCE)
+
+
+def device_commit_and_prove(K, ts, data, n):
+    import torch
+    d_blobs = _dev(data)
+    d_comm = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    d_st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), n, ts, None, d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    d_st.fill_(9)
+    K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, None, d_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum()) == 0
+    return _host(d_comm), _host(d_out)
+
+
+# 64 = one full hash workgroup; 65, 70 = a second, mostly empty one; 256, 1024 = the sizes bench.py quotes
+@pytest.mark.parametrize("n,first", [(64, 21000), (65, 21100), (70, 21200), (256, 22000), (1024, 23000)])
+@pytest.mark.parametrize("mode_c", [False, True], ids=["reference", "ckzg"])
+def test_device_resident_blob_proofs_every_blob_vs_oracle(K, engine_setup, oracle, n, first, mode_c):
+    K.set_mode(K.MODE_CKZG if mode_c else K.MODE_REFERENCE)
+    blobs, want_c, want_p = oracle_batch(oracle, first, n, mode_c)
+    comms, proofs = device_commit_and_prove(K, engine_setup, b"".join(blobs), n)
+    for i in range(n):
+        assert comms[48 * i:48 * i + 48] == want_c[i], ("commitment", i)
+        assert proofs[48 * i:48 * i + 48] == want_p[i], ("proof", i)
+
+
+@pytest.mark.parametrize("n", [70, 1500])
+@pytest.mark.parametrize("mode_c", [False, True], ids=["reference", "ckzg"])
+def test_fiat_shamir_kernel_vs_hashlib(K, gpu_setup, n, mode_c):
+    """k_challenge_pairs at a partial-workgroup size and beyond one chunk, every digest against hashlib."""
+    import torch
+    from lambdaworks_kzg_amd import capi
+    K.set_mode(K.MODE_CKZG if mode_c else K.MODE_REFERENCE)
+    data = B.synthetic_batch(31000, n, big_endian=not mode_c)
+    comms = b"".join(bytes([0x80 | (i % 32)]) + (i * 0x9E3779B97F4A7C15 % (1 << 376)).to_bytes(47, "big") for i in range(n))  # hashed as given
+    d_blobs, d_comm = _dev(data), _dev(comms)
+    d_z = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    capi.compute_challenges_device(d_z.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, gpu_setup)
+    torch.cuda.synchronize()
+    got = _host(d_z)
+    for i in range(n):
+        want = challenge_int(data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB], comms[48 * i:48 * i + 48], mode_c)
+        assert int.from_bytes(got[32 * i:32 * i + 32], "little" if mode_c else "big") == want, i
+
+
+def test_device_resident_proof_call_longer_than_one_chunk(K, engine_setup, oracle, oracle_setup):
+    """n > 1024 in ONE device-resident call: all blobs are hashed and validated up front, then the MSMs run chunk by chunk.
+    Every proof against the hashlib + tau closed form; chunk-boundary blobs against the oracle's own pipeline."""
+    n = 2100
+    data = B.synthetic_batch(40000, n)
+    comms, proofs = device_commit_and_prove(K, engine_setup, data, n)
+    for i in range(n):
+        blob = data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
+        if i % 16 == 0 or i in (1023, 1024, 1025, 2047, 2048, 2099):
+            assert comms[48 * i:48 * i + 48] == tau_closed_form(oracle, B.blob_scalars(blob)), i
+            assert proofs[48 * i:48 * i + 48] == reference_mode_proof_closed_form(oracle, blob, comms[48 * i:48 * i + 48]), i
+    for i in (0, 1023, 1024, 2048, 2099):
+        blob = data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
+        assert oracle.compute_blob_kzg_proof(blob, comms[48 * i:48 * i + 48], oracle_setup, oracle.MODE_R) == (0, proofs[48 * i:48 * i + 48])
+    # no status array: the library keeps its own (the call must still work)
+    import torch
+    d_blobs, d_comm = _dev(data), _dev(comms)
+    d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, engine_setup, None, None)
+    torch.cuda.synchronize()
+    assert _host(d_out) == proofs
+
+
+def test_device_calls_on_two_user_streams_share_the_workspace_safely(K, gpu_setup, oracle):
+    """Two device-resident calls in flight on two different caller streams used to race on the per-settings workspace;
+    the library now chains them by events. Both results must be the single-stream ones, repeatedly."""
+    import torch
+    n = 96
+    a, b = B.synthetic_batch(50000, n), B.synthetic_batch(51000, n)
+    d_a, d_b = _dev(a), _dev(b)
+    want_a = b"".join(K.blob_to_kzg_commitment_batch(a, gpu_setup))
+    want_b = b"".join(K.blob_to_kzg_commitment_batch(b, gpu_setup))
+    assert want_a[:48] == tau_closed_form(oracle, B.blob_scalars(a[:B.BYTES_PER_BLOB]))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(8):
+        o_a = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+        o_b = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+        p_b = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        K.blob_to_kzg_commitment_batch_device(o_a.data_ptr(), d_a.data_ptr(), n, gpu_setup, s1.cuda_stream, None)
+        K.blob_to_kzg_commitment_batch_device(o_b.data_ptr(), d_b.data_ptr(), n, gpu_setup, s2.cuda_stream, None)
+        s2.synchronize()
+        K.compute_blob_kzg_proof_batch_device(p_b.data_ptr(), d_b.data_ptr(), o_b.data_ptr(), n, gpu_setup, s1.cuda_stream, None)
+        torch.cuda.synchronize()
+        assert _host(o_a) == want_a and _host(o_b) == want_b
+        assert _host(p_b)[:48] == reference_mode_proof_closed_form(oracle, b[:B.BYTES_PER_BLOB], want_b[:48])

@@ -8,8 +8,9 @@ from conftest import SETUP_PATH
 pytestmark = pytest.mark.gpu
 
 
-def test_direct_table_opt_in_from_environment(K, gpu_setup):
-    """LWKZG_DIRECT_BITS: how a consumer that only knows the reference's nine symbols opts in (fresh process)."""
+def test_engine_selection_from_environment(K, gpu_setup):
+    """LWKZG_DIRECT_BITS: how a consumer that only knows the reference's nine symbols picks the MSM engine (fresh
+    processes). Unset = the library's default (a table of at most a quarter of the free memory: 13 bits here)."""
     import subprocess
     import sys
     import os
@@ -19,9 +20,13 @@ def test_direct_table_opt_in_from_environment(K, gpu_setup):
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import blobs as B; import lambdaworks_kzg_amd as K; "
             "ts = K.TrustedSetup.from_file(%r); print(ts.direct_table_bits(), K.blob_to_kzg_commitment(B.synthetic_blob(4242), ts).hex())"
             % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH))
-    env = dict(os.environ, LWKZG_DIRECT_BITS="14")
-    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
-    assert out[-2:] == ["14", want]
+    for setting, expect in (("14", "14"), ("0", "0"), (None, str(gpu_setup.default_bits)), ("10", "10")):
+        env = dict(os.environ)
+        env.pop("LWKZG_DIRECT_BITS", None)
+        if setting is not None:
+            env["LWKZG_DIRECT_BITS"] = setting
+        out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
+        assert out[-2:] == [expect, want], (setting, out)
 
 
 def test_plain_hash_kernel_still_agrees(K, gpu_setup):
