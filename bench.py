@@ -166,7 +166,7 @@ def main():
     t_tab0 = time.perf_counter()
     direct_bits = 0
     if args.direct_bits == "auto":
-        for bits in (16, 15, 14):
+        for bits in (16, 15, 14, 13, 12, 11, 10, 0):
             try:
                 ts.enable_direct_table(bits)
                 direct_bits = bits
@@ -174,7 +174,9 @@ def main():
             except capi.KzgError as e:
                 if e.rc != capi.C_KZG_MALLOC:
                     raise
-    elif int(args.direct_bits) != 0:
+    elif args.direct_bits == "default":     # whatever a plain load selected (engine.hip: direct_from_env)
+        direct_bits = ts.direct_table_bits()
+    else:
         ts.enable_direct_table(int(args.direct_bits))
         direct_bits = int(args.direct_bits)
     t_table = time.perf_counter() - t_tab0
