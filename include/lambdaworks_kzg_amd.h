@@ -216,6 +216,31 @@ size_t lwkzg_setup_image_bytes(void);
 C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void *stream);
 C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev);
 
+/* verify_blob_kzg_proof_batch (src/lib.rs:525-692) for a batch SHARDED over several processes / GPUs, as the
+ * reference computes it: ONE Fiat-Shamir scalar r over the whole batch (compute_r_powers, src/utils.rs:166-206), ONE
+ * random linear combination, ONE pairing check. Rank k holds blobs [first_k, first_k + n_k) of the n_total:
+ *   1. lwkzg_verify_shard_begin: per blob on this rank's GPU -- validate C_i and pi_i, z_i = compute_challenge,
+ *      y_i = p_i(z_i); writes the shard's n_k transcript records (C 48 | z 32 | y 32 | pi 48 = 160 bytes each) and keeps
+ *      the decompressed points on the device behind *shard_out;
+ *   2. all-gather the records (160 bytes per blob; lambdaworks_kzg_amd/dist.py does it with torch.distributed);
+ *   3. lwkzg_verify_shard_partial: r from ALL n_total records; this shard's terms of sum r^i pi_i, sum r^i z_i pi_i,
+ *      sum r^i C_i (three affine points) and of sum r^i y_i (one scalar) -> LWKZG_VERIFY_PARTIAL_BYTES bytes;
+ *   4. all-gather the partial sums; lwkzg_verify_shards_finish adds them and does the pairing check (on every rank, or
+ *      on one).
+ * verify_blob_kzg_proof_batch itself is steps 1, 3, 4 with one shard. Errors as there (invalid point / non-canonical
+ * field element: C_KZG_ERROR in reference mode, C_KZG_BADARGS in c-kzg mode); n_total == 0 gives ok = false. A shard may
+ * be empty (n_local = 0). Several shards may be open on one settings object (each owns its device scratch). */
+#define LWKZG_VERIFY_RECORD_BYTES 160
+#define LWKZG_VERIFY_PARTIAL_BYTES 328
+typedef struct LwkzgVerifyShard LwkzgVerifyShard;
+C_KZG_RET lwkzg_verify_shard_begin(LwkzgVerifyShard **shard_out, uint8_t *records_out /* n_local * 160 */, const Blob *blobs,
+                                   const Bytes48 *commitments, const Bytes48 *proofs, size_t n_local, const KZGSettings *s);
+C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out /* 328 */, LwkzgVerifyShard *shard, const uint8_t *records_all /* n_total * 160 */,
+                                     size_t n_total, size_t first_index);
+void lwkzg_verify_shard_free(LwkzgVerifyShard *shard);
+C_KZG_RET lwkzg_verify_shards_finish(bool *ok, const uint8_t *partials /* n_shards * 328 */, size_t n_shards, size_t n_total,
+                                     const KZGSettings *s);
+
 /* Host-only test hook for the verify side: prod_i e(P_i, Q_i) == 1 for up to 4 pairs of ZCash-compressed
  * points (G1 48 bytes, G2 96 bytes; a pair with a point at infinity contributes 1). No GPU, no settings. */
 C_KZG_RET lwkzg_pairing_product_is_one(bool *ok, const uint8_t *g1_compressed, const uint8_t *g2_compressed, size_t n);

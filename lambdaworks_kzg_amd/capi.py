@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows",
     "lwkzg_compute_challenges_device",
+    "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
 ]
 
 _lib = None
@@ -82,6 +83,11 @@ def lib():
     l.lwkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_challenges_device.argtypes = [vp, vp, vp, sz, ps, vp]
+    l.lwkzg_verify_shard_begin.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
+    l.lwkzg_verify_shard_partial.argtypes = [C.c_char_p, vp, C.c_char_p, sz, sz]
+    l.lwkzg_verify_shard_free.argtypes = [vp]
+    l.lwkzg_verify_shard_free.restype = None
+    l.lwkzg_verify_shards_finish.argtypes = [C.POINTER(C.c_bool), C.c_char_p, sz, sz, ps]
     l.lwkzg_reserve.argtypes = [ps, sz]
     l.lwkzg_enable_direct_table.argtypes = [ps, ci]
     l.lwkzg_direct_table_bits.argtypes = [ps]
@@ -262,6 +268,49 @@ def verify_blob_kzg_proof_batch(blobs, commitments_bytes, proofs_bytes, n, ts):
     ok = C.c_bool(False)
     _check("verify_blob_kzg_proof_batch",
            lib().verify_blob_kzg_proof_batch(C.byref(ok), blobs, commitments_bytes, proofs_bytes, n, ts.ref()))
+    return bool(ok.value)
+
+
+# ---- sharded batch verification (one batch, one r, one pairing check; include/lambdaworks_kzg_amd.h) ---------
+
+VERIFY_RECORD_BYTES = 160
+VERIFY_PARTIAL_BYTES = 328
+
+
+class VerifyShard:
+    """This process's shard of a sharded verify_blob_kzg_proof_batch (lwkzg_verify_shard_*)."""
+
+    def __init__(self, blobs, commitments_bytes, proofs_bytes, n_local, ts):
+        assert len(blobs) == n_local * BYTES_PER_BLOB and len(commitments_bytes) == len(proofs_bytes) == 48 * n_local
+        self.n = n_local
+        self.h = C.c_void_p()
+        rec = C.create_string_buffer(VERIFY_RECORD_BYTES * max(n_local, 1))
+        _check("lwkzg_verify_shard_begin",
+               lib().lwkzg_verify_shard_begin(C.byref(self.h), rec, blobs, commitments_bytes, proofs_bytes, n_local, ts.ref()))
+        self.records = rec.raw[:VERIFY_RECORD_BYTES * n_local]
+
+    def partial(self, records_all, n_total, first_index):
+        assert len(records_all) == VERIFY_RECORD_BYTES * n_total
+        out = C.create_string_buffer(VERIFY_PARTIAL_BYTES)
+        _check("lwkzg_verify_shard_partial", lib().lwkzg_verify_shard_partial(out, self.h, records_all, n_total, first_index))
+        return out.raw
+
+    def free(self):
+        if self.h:
+            lib().lwkzg_verify_shard_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def verify_shards_finish(partials, n_shards, n_total, ts):
+    assert len(partials) == VERIFY_PARTIAL_BYTES * n_shards
+    ok = C.c_bool(False)
+    _check("lwkzg_verify_shards_finish", lib().lwkzg_verify_shards_finish(C.byref(ok), partials, n_shards, n_total, ts.ref()))
     return bool(ok.value)
 
 

@@ -96,7 +96,9 @@ struct VerifyBuffers {
     std::vector<G1Affine29> h_aff;
     std::vector<int32_t> h_kind;
     std::unique_lock<std::mutex> hold;
+    bool owned = false;  // the device pointers above belong to this object (verify_buffers_free), not to the context
 };
+void verify_buffers_free(VerifyBuffers &v);
 
 // Up to this many blobs a verification / proof call validates its points on the host threads: ~0.2 ms per point per
 // thread against a 2 ms latency-shaped kernel. 4 per usable hardware thread, at most 64.

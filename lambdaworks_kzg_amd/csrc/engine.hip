@@ -584,8 +584,7 @@ static C_KZG_RET first_status(Ctx *c, const int32_t *d_status, size_t n, hipStre
     return C_KZG_OK;
 }
 
-static void vs_free(Ctx *c) {
-    VerifyBuffers &v = c->vs;
+void verify_buffers_free(VerifyBuffers &v) {
     dev_free(v.pts_c);
     dev_free(v.pts_p);
     dev_free(v.mult_c);
@@ -601,17 +600,15 @@ static void vs_free(Ctx *c) {
     dev_free(v.d_aff);
     dev_free(v.d_part);
     dev_free(v.d_inf);
+}
+
+static void vs_free(Ctx *c) {
+    verify_buffers_free(c->vs);
     c->vs_cap = 0;
 }
 
-// grow-only verify scratch for n blobs; the caller holds verify_mu
-static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
-    if (c->vs_cap >= n) return C_KZG_OK;
-    LWK_HIP(hipDeviceSynchronize());  // the validation / multiples streams included
-    vs_free(c);
-    size_t cap = 64;
-    while (cap < n) cap <<= 1;
-    VerifyBuffers &v = c->vs;
+// device scratch of one batch verification of up to `cap` blobs
+static C_KZG_RET verify_buffers_alloc(VerifyBuffers &v, size_t cap) {
     const size_t nblk = lincomb3_blocks(cap);
     bool ok = hipMalloc((void **)&v.pts_c, cap * sizeof(G1Affine29)) == hipSuccess &&
               hipMalloc((void **)&v.pts_p, cap * sizeof(G1Affine29)) == hipSuccess &&
@@ -626,10 +623,22 @@ static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
               hipMalloc((void **)&v.d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&v.d_inf, 3 * 4) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
-        vs_free(c);
+        verify_buffers_free(v);
         set_error("verify scratch for %zu blobs: out of device memory", cap);
         return C_KZG_MALLOC;
     }
+    return C_KZG_OK;
+}
+
+// grow-only verify scratch for n blobs; the caller holds verify_mu
+static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
+    if (c->vs_cap >= n) return C_KZG_OK;
+    LWK_HIP(hipDeviceSynchronize());  // the validation / multiples streams included
+    vs_free(c);
+    size_t cap = 64;
+    while (cap < n) cap <<= 1;
+    C_KZG_RET rc = verify_buffers_alloc(c->vs, cap);
+    if (rc != C_KZG_OK) return rc;
     c->vs_cap = cap;
     return C_KZG_OK;
 }
@@ -760,7 +769,10 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
 C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n,
                               int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb,
                               const uint8_t *trusted_canon_c) {
-    vb.hold = std::unique_lock<std::mutex>(c->verify_mu);  // released when the caller's VerifyBuffers goes away
+    // vb.owned: the caller's VerifyBuffers brings device scratch of its own (a shard of a sharded verification, which
+    // outlives this call and may coexist with others on the same settings object); otherwise the context's scratch is
+    // lent out under verify_mu, released when the caller's VerifyBuffers goes away
+    if (!vb.owned) vb.hold = std::unique_lock<std::mutex>(c->verify_mu);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     const int le = mode == LWKZG_MODE_CKZG;
@@ -779,7 +791,12 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             hipStreamSynchronize(c->aux[1]);
         }
     } drain{c};
-    {
+    if (vb.owned) {
+        if (!vb.pts_c) {
+            C_KZG_RET rcv = verify_buffers_alloc(vb, n < 64 ? 64 : n);
+            if (rcv != C_KZG_OK) return rcv;
+        }
+    } else {
         C_KZG_RET rcv = vs_reserve(c, n);
         if (rcv != C_KZG_OK) return rcv;
         const VerifyBuffers &v = c->vs;
@@ -901,7 +918,7 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const size_t nblk = lincomb3_blocks(n);
-    if (!vb.hold.owns_lock() || !vb.d_r) {
+    if (!(vb.hold.owns_lock() || vb.owned) || !vb.d_r) {
         set_error("lincomb3_device_host: called without a prepared verification");
         return C_KZG_ERROR;
     }

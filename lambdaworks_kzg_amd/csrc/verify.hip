@@ -298,9 +298,226 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
     return verify_core(ok, c, z, y, pi, s);
 }
 
+// ---- batch verification, in the three steps a sharded run needs -----------------------------------------------------
 // verify_kzg_proof_batch, lib.rs:639-692: r from SHA-256 over
 //   "RCKZGBATCH___V1_" | usize(4096) LE | usize(n) LE | n x (C 48 | z 32 | y 32 | pi 48)      (utils.rs:166-206)
 // powers 1, r, r^2, ...;  rhs = sum r^i (C_i - [y_i]G) + sum r^i z_i pi_i ;  e(rhs, G2) == e(sum r^i pi_i, [tau]G2).
+//
+//   begin   : everything per blob (validate C_i, pi_i; z_i = challenge; y_i = p_i(z_i)) -> the blob's 160-byte record
+//             of the transcript; the decompressed points stay on the device
+//   partial : r from the WHOLE transcript; this shard's terms of the three linear combinations and of sum r^i y_i
+//   finish  : add the shards' partial sums, one pairing check
+// One process: begin, partial(first = 0, n_total = n), finish. Eight GPUs: every rank begins its shard, the records are
+// all-gathered (160 bytes per blob), every rank computes its partial sums with the common r, the partial sums (328
+// bytes per rank) are all-gathered and every rank finishes: SURVEY section 8e, the reference's computation exactly.
+}  // extern "C"
+
+namespace lwk {
+namespace {
+
+constexpr size_t kRecord = LWKZG_VERIFY_RECORD_BYTES;    // C 48 | z 32 | y 32 | pi 48
+constexpr size_t kPartial = LWKZG_VERIFY_PARTIAL_BYTES;  // 3 x (flag 1 | x 48 | y 48) | sum r^i y_i 32 | pad
+
+struct Shard {
+    Ctx *ctx = nullptr;
+    const KZGSettings *s = nullptr;
+    size_t n = 0;
+    int mode = 0;
+    VerifyBuffers vb;
+    std::vector<uint8_t> zs, ys, canon_c, canon_p;
+    ~Shard() {
+        if (vb.owned) {
+            if (ctx) hipSetDevice(ctx->device);
+            hipDeviceSynchronize();
+            verify_buffers_free(vb);
+        }
+    }
+};
+
+C_KZG_RET shard_begin(Shard &sh, const uint8_t *blobs, const uint8_t *comms, const uint8_t *proofs, size_t n, const KZGSettings *s,
+                      int mode, bool own_buffers) {
+    sh.ctx = ctx_of(s);
+    if (!sh.ctx) return C_KZG_ERROR;
+    sh.s = s;
+    sh.n = n;
+    sh.mode = mode;
+    sh.vb.owned = own_buffers;
+    sh.zs.resize(32 * n);
+    sh.ys.resize(32 * n);
+    sh.canon_c.resize(48 * n);
+    sh.canon_p.resize(48 * n);
+    if (n == 0) return C_KZG_OK;
+    // per blob on the GPU: validate C_i and pi_i (decompress + subgroup check + canonical recompression; the
+    // decompressed points stay on the device), z_i = challenge(blob_i, C_i), y_i = p_i(z_i)
+    C_KZG_RET rc = verify_prepare_host(sh.ctx, blobs, comms, proofs, n, mode, sh.zs.data(), sh.ys.data(), sh.canon_c.data(),
+                                       sh.canon_p.data(), sh.vb);
+    if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
+    return C_KZG_OK;
+}
+
+// this shard's records; z and y enter in the mode's byte order, as to_bytes_be / c-kzg's bytes_from_bls_field do
+void shard_records(const Shard &sh, uint8_t *out) {
+    for (size_t i = 0; i < sh.n; i++) {
+        uint8_t *m = out + kRecord * i;
+        memcpy(m, &sh.canon_c[48 * i], 48);
+        memcpy(m + 48, &sh.zs[32 * i], 32);
+        memcpy(m + 80, &sh.ys[32 * i], 32);
+        memcpy(m + 112, &sh.canon_p[48 * i], 48);
+    }
+}
+
+HFr hfr_raw(const uint32_t t[8]) {
+    HFr x;
+    for (int k = 0; k < 4; k++) x.l[k] = (uint64_t)t[2 * k] | ((uint64_t)t[2 * k + 1] << 32);
+    return x;
+}
+void hfr_to_raw(uint32_t t[8], const HFr &x) {
+    for (int k = 0; k < 4; k++) {
+        t[2 * k] = (uint32_t)x.l[k];
+        t[2 * k + 1] = (uint32_t)(x.l[k] >> 32);
+    }
+}
+void hfr_to_be(uint8_t *out, const HFr &x) {
+    uint32_t t[8];
+    hfr_to_raw(t, x);
+    raw_to_be<8>(out, t);
+}
+
+// r (utils.rs:166-206) from the n_total records of the whole batch, in Montgomery form
+HFr batch_challenge_mont(const uint8_t *records, size_t n_total, bool le) {
+    std::vector<uint8_t> msg(32 + n_total * kRecord);
+    memcpy(msg.data(), "RCKZGBATCH___V1_", 16);
+    memset(msg.data() + 16, 0, 16);
+    msg[16] = 0x00;
+    msg[17] = 0x10;  // 4096 LE
+    for (int k = 0; k < 8; k++) msg[24 + k] = (uint8_t)((uint64_t)n_total >> (8 * k));
+    memcpy(msg.data() + 32, records, n_total * kRecord);
+    uint8_t dg[32];
+    sha256_fast(dg, msg.data(), msg.size());
+    uint32_t t[8], rraw[8];
+    if (le) raw_from_le<8>(t, dg); else raw_from_be<8>(t, dg);
+    Fr f = fe_from_raw<FrParams>(t);  // hash_field_unsafe: reduced mod r
+    fe_to_raw<FrParams>(rraw, f);
+    return hfr_raw(rraw) * hfr_raw(FrParams::R2);
+}
+
+// The shard's terms i = first .. first + n - 1 of the batch: out[0] = sum r^i pi_i, out[1] = sum r^i z_i pi_i,
+// out[2] = sum r^i C_i (g1_lincomb, lib.rs:679-685), ysum = sum r^i y_i (raw). `beside(ysum)` (optional) is called once
+// the scalars are known and before the linear combinations run (the single-process path starts [ysum]G there).
+C_KZG_RET shard_partial(Shard &sh, const uint8_t *records_all, size_t n_total, size_t first, HXyzz out[3], HFr &ysum,
+                        const std::function<void(const HFr &)> &beside) {
+    const bool le = sh.mode == LWKZG_MODE_CKZG;
+    const size_t n = sh.n;
+    for (int k = 0; k < 3; k++) out[k] = HXyzz::infinity();
+    ysum = HFr::zero();
+    if (first + n > n_total) {
+        set_error("verify shard [%zu, %zu) does not fit a batch of %zu", first, first + n, n_total);
+        return C_KZG_BADARGS;
+    }
+    if (n && memcmp(records_all + kRecord * first + 48, sh.zs.data(), 32) != 0) {
+        set_error("verify shard: the transcript at index %zu is not this shard's first record", first);
+        return C_KZG_BADARGS;
+    }
+    const HFr r_mont = batch_challenge_mont(records_all, n_total, le);
+    // scalars r^i, r^i z_i (for the GPU) and sum r^i y_i (one host scalar), on the 64-bit host field. The running power
+    // stays in Montgomery form; a Montgomery product with a RAW factor (z_i, y_i, 1) yields the raw product directly.
+    const uint32_t one_limbs[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    const HFr one_raw = hfr_raw(one_limbs);
+    HFr rp = HFr::one();  // r^first, square and multiply
+    {
+        HFr base = r_mont;
+        for (size_t e = first; e; e >>= 1) {
+            if (e & 1) rp = rp * base;
+            base = base * base;
+        }
+    }
+    std::vector<uint8_t> sc_r(32 * n), sc_rz(32 * n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t zr[8], yr[8];
+        if (le) {
+            raw_from_le<8>(zr, &sh.zs[32 * i]);
+            raw_from_le<8>(yr, &sh.ys[32 * i]);
+        } else {
+            raw_from_be<8>(zr, &sh.zs[32 * i]);
+            raw_from_be<8>(yr, &sh.ys[32 * i]);
+        }
+        if (raw_geq<8>(zr, FrParams::MOD) || raw_geq<8>(yr, FrParams::MOD)) return C_KZG_ERROR;  // the GPU wrote canonical values
+        hfr_to_be(&sc_r[32 * i], rp * one_raw);
+        hfr_to_be(&sc_rz[32 * i], rp * hfr_raw(zr));
+        ysum = ysum + rp * hfr_raw(yr);
+        rp = rp * r_mont;
+    }
+    if (beside) beside(ysum);
+    if (n == 0) return C_KZG_OK;
+    // three variable-base linear combinations: on the GPU over the points the validation kernels left there, or on the
+    // host threads when the batch was small enough to be validated there
+    const bool on_host = sh.vb.h_aff.size() == 2 * n && sh.vb.h_kind.size() == 2 * n;
+    if (on_host) {
+        host_lincomb3(out, sh.vb.h_aff.data(), sh.vb.h_kind.data(), sc_r.data(), sc_rz.data(), n);
+        return C_KZG_OK;
+    }
+    uint8_t sums[3][96];
+    int infs[3];
+    C_KZG_RET rc = lincomb3_device_host(sh.ctx, sh.vb, sc_r.data(), sc_rz.data(), n, sums, infs);
+    if (rc != C_KZG_OK) return C_KZG_ERROR;
+    for (int k = 0; k < 3; k++) {
+        if (infs[k]) continue;
+        uint32_t raw[12];
+        G1Affine a;
+        raw_from_be<12>(raw, sums[k]);
+        a.x = fe_from_raw<FpParams>(raw);
+        raw_from_be<12>(raw, sums[k] + 48);
+        a.y = fe_from_raw<FpParams>(raw);
+        out[k] = HXyzz::from_affine(HFp::from_fe(a.x), HFp::from_fe(a.y));
+    }
+    return C_KZG_OK;
+}
+
+// e(sum r^i C_i - [sum r^i y_i]G + sum r^i z_i pi_i, G2) == e(sum r^i pi_i, [tau]G2): kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
+C_KZG_RET batch_verdict(bool *ok, const HXyzz sums[3], const HXyzz &ysum_g, const KZGSettings *s) {
+    HXyzz rhs = xyzz_add(sums[2], xyzz_neg(ysum_g));
+    rhs = xyzz_add(rhs, sums[1]);
+    return pairing_verdict(ok, rhs, sums[0], s);
+}
+
+void point_to_bytes(uint8_t *out97, const HXyzz &p) {
+    memset(out97, 0, 97);
+    if (p.is_inf()) {
+        out97[0] = 1;
+        return;
+    }
+    const G1Affine a = h_to_affine(p);
+    uint32_t raw[12];
+    fe_to_raw<FpParams>(raw, a.x);
+    raw_to_be<12>(out97 + 1, raw);
+    fe_to_raw<FpParams>(raw, a.y);
+    raw_to_be<12>(out97 + 49, raw);
+}
+
+bool point_from_bytes(HXyzz &p, const uint8_t *in97) {
+    if (in97[0] == 1) {
+        p = HXyzz::infinity();
+        return true;
+    }
+    if (in97[0] != 0) return false;
+    uint32_t raw[12];
+    G1Affine a;
+    raw_from_be<12>(raw, in97 + 1);
+    if (raw_geq<12>(raw, FpParams::MOD)) return false;
+    a.x = fe_from_raw<FpParams>(raw);
+    raw_from_be<12>(raw, in97 + 49);
+    if (raw_geq<12>(raw, FpParams::MOD)) return false;
+    a.y = fe_from_raw<FpParams>(raw);
+    if (!g1_on_curve(a)) return false;
+    p = HXyzz::from_affine(HFp::from_fe(a.x), HFp::from_fe(a.y));
+    return true;
+}
+
+}  // namespace
+}  // namespace lwk
+
+extern "C" {
+
 C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
                                       const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s) {
     if (!ok) return C_KZG_BADARGS;
@@ -309,9 +526,6 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     if (n == 1) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);  // lib.rs:544
     const int mode = g_mode_now();
     if (!blobs || !commitments_bytes || !proofs_bytes || !s) return bad(mode);
-    Ctx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    const bool le = mode == LWKZG_MODE_CKZG;
 
     static const bool timing = getenv("LWKZG_TIMING") != nullptr;  // phase wall-clock to stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -319,119 +533,103 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
-    std::vector<uint8_t> zs(32 * n), ys(32 * n), canon_c(48 * n), canon_p(48 * n);
-    // per blob on the GPU: validate C_i and pi_i (decompress + subgroup check + canonical recompression; the
-    // decompressed points stay on the device), z_i = challenge(blob_i, C_i), y_i = p_i(z_i)
-    VerifyBuffers vb;
-    C_KZG_RET rc = verify_prepare_host(ctx, (const uint8_t *)blobs, (const uint8_t *)commitments_bytes,
-                                       (const uint8_t *)proofs_bytes, n, mode, zs.data(), ys.data(), canon_c.data(),
-                                       canon_p.data(), vb);
-    if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
-
+    Shard sh;
+    C_KZG_RET rc = shard_begin(sh, (const uint8_t *)blobs, (const uint8_t *)commitments_bytes, (const uint8_t *)proofs_bytes, n, s,
+                               mode, false);
+    if (rc != C_KZG_OK) return rc;
     const auto t1 = now();
-    // r (utils.rs:166-206). z and y enter in the mode's byte order, as to_bytes_be / c-kzg's bytes_from_bls_field do
-    std::vector<uint8_t> msg(32 + n * 160);
-    memcpy(msg.data(), "RCKZGBATCH___V1_", 16);
-    memset(msg.data() + 16, 0, 16);
-    msg[16] = 0x00;
-    msg[17] = 0x10;  // 4096 LE
-    for (int k = 0; k < 8; k++) msg[24 + k] = (uint8_t)((uint64_t)n >> (8 * k));
-    for (size_t i = 0; i < n; i++) {
-        uint8_t *m = msg.data() + 32 + 160 * i;
-        memcpy(m, &canon_c[48 * i], 48);
-        memcpy(m + 48, &zs[32 * i], 32);
-        memcpy(m + 80, &ys[32 * i], 32);
-        memcpy(m + 112, &canon_p[48 * i], 48);
-    }
-    uint8_t dg[32];
-    sha256_fast(dg, msg.data(), msg.size());
-    uint32_t rraw[8];
-    {
-        uint32_t t[8];
-        if (le) raw_from_le<8>(t, dg); else raw_from_be<8>(t, dg);
-        Fr f = fe_from_raw<FrParams>(t);  // hash_field_unsafe: reduced mod r
-        fe_to_raw<FrParams>(rraw, f);
-    }
-    // scalars r^i, r^i z_i (for the GPU) and sum r^i y_i (one host scalar), on the 64-bit host field. The running power
-    // stays in Montgomery form; a Montgomery product with a RAW factor (z_i, y_i, 1) yields the raw product directly.
-    auto hfr_raw = [](const uint32_t t[8]) {
-        HFr x;
-        for (int k = 0; k < 4; k++) x.l[k] = (uint64_t)t[2 * k] | ((uint64_t)t[2 * k + 1] << 32);
-        return x;
-    };
-    auto hfr_to_be = [](uint8_t *out, const HFr &x) {
-        uint32_t t[8];
-        for (int k = 0; k < 4; k++) {
-            t[2 * k] = (uint32_t)x.l[k];
-            t[2 * k + 1] = (uint32_t)(x.l[k] >> 32);
-        }
-        raw_to_be<8>(out, t);
-    };
-    const uint32_t one_limbs[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-    const HFr one_raw = hfr_raw(one_limbs);
-    const HFr r_mont = hfr_raw(rraw) * hfr_raw(FrParams::R2);
-    HFr rp = HFr::one(), ysum = HFr::zero();  // rp: r^i in Montgomery form; ysum: raw
-    std::vector<uint8_t> sc_r(32 * n), sc_rz(32 * n);
-    for (size_t i = 0; i < n; i++) {
-        uint32_t zr[8], yr[8];
-        if (le) {
-            raw_from_le<8>(zr, &zs[32 * i]);
-            raw_from_le<8>(yr, &ys[32 * i]);
-        } else {
-            raw_from_be<8>(zr, &zs[32 * i]);
-            raw_from_be<8>(yr, &ys[32 * i]);
-        }
-        if (raw_geq<8>(zr, FrParams::MOD) || raw_geq<8>(yr, FrParams::MOD)) return C_KZG_ERROR;  // the GPU wrote canonical values
-        hfr_to_be(&sc_r[32 * i], rp * one_raw);
-        hfr_to_be(&sc_rz[32 * i], rp * hfr_raw(zr));
-        ysum = ysum + rp * hfr_raw(yr);
-        rp = rp * r_mont;
-    }
-    const auto t2 = now();
-    // [sum r^i y_i]G on a thread of its own, beside the linear combinations
+    std::vector<uint8_t> records(kRecord * n);
+    shard_records(sh, records.data());
     HostPoint g;
     if (!setup_generator(g, s)) return C_KZG_ERROR;
-    uint32_t ys_raw[8];
-    for (int k = 0; k < 4; k++) {
-        ys_raw[2 * k] = (uint32_t)ysum.l[k];
-        ys_raw[2 * k + 1] = (uint32_t)(ysum.l[k] >> 32);
-    }
-    HXyzz ysum_g;
-    SideTask side([&]() { ysum_g = scalar_mul(to_xyzz(g), ys_raw); });
-    // three variable-base linear combinations (g1_lincomb, lib.rs:679-685): on the GPU over the points the validation
-    // kernels left there, or on the host threads when the batch was small enough to be validated there
-    uint8_t sums[3][96];
-    int infs[3];
-    HXyzz hsum[3];
-    const bool on_host = vb.h_aff.size() == 2 * n && vb.h_kind.size() == 2 * n;
-    if (on_host) {
-        host_lincomb3(hsum, vb.h_aff.data(), vb.h_kind.data(), sc_r.data(), sc_rz.data(), n);
-    } else {
-        rc = lincomb3_device_host(ctx, vb, sc_r.data(), sc_rz.data(), n, sums, infs);
-        if (rc != C_KZG_OK) return C_KZG_ERROR;
-    }
-    auto load = [&](int k) {
-        if (on_host) return hsum[k];
-        if (infs[k]) return HXyzz::infinity();
-        uint32_t raw[12];
-        G1Affine a;
-        raw_from_be<12>(raw, sums[k]);
-        a.x = fe_from_raw<FpParams>(raw);
-        raw_from_be<12>(raw, sums[k] + 48);
-        a.y = fe_from_raw<FpParams>(raw);
-        return HXyzz::from_affine(HFp::from_fe(a.x), HFp::from_fe(a.y));
-    };
-    const auto t3 = now();
-    HXyzz proof_lincomb = load(0), proof_z_lincomb = load(1), c_lincomb = load(2);
+    // [sum r^i y_i]G on a thread of its own, beside the linear combinations
+    HXyzz ysum_g = HXyzz::infinity();
+    SideTask side;
+    auto t2 = t1;
+    HXyzz sums[3];
+    HFr ysum;
+    rc = shard_partial(sh, records.data(), n, 0, sums, ysum, [&](const HFr &ys) {
+        t2 = now();
+        side.start([&, ys]() {
+            uint32_t ys_raw[8];
+            hfr_to_raw(ys_raw, ys);
+            ysum_g = scalar_mul(to_xyzz(g), ys_raw);
+        });
+    });
     side.join();
-    HXyzz rhs = xyzz_add(c_lincomb, xyzz_neg(ysum_g));
-    rhs = xyzz_add(rhs, proof_z_lincomb);
-    rc = pairing_verdict(ok, rhs, proof_lincomb, s);  // kzg.verify(0, 0, rhs, proof_lincomb), lib.rs:691
+    if (rc != C_KZG_OK) return C_KZG_ERROR;
+    const auto t3 = now();
+    rc = batch_verdict(ok, sums, ysum_g, s);
     if (timing)
         fprintf(stderr, "[lambdaworks_kzg_amd] verify batch n=%zu: prepare (H2D, validate, challenge, evaluate) %.2f ms, "
                         "r powers %.2f ms, lincomb3 %.2f ms, pairing side %.2f ms\n",
                 n, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     return rc;
+}
+
+// ---- the same three steps for a batch sharded over several processes / GPUs (include/lambdaworks_kzg_amd.h) ----------
+
+C_KZG_RET lwkzg_verify_shard_begin(LwkzgVerifyShard **shard_out, uint8_t *records_out, const Blob *blobs, const Bytes48 *commitments,
+                                   const Bytes48 *proofs, size_t n_local, const KZGSettings *s) {
+    if (!shard_out) return C_KZG_BADARGS;
+    *shard_out = nullptr;
+    const int mode = g_mode_now();
+    if (!s || (n_local && (!records_out || !blobs || !commitments || !proofs))) return bad(mode);
+    Shard *sh = new (std::nothrow) Shard();
+    if (!sh) return C_KZG_MALLOC;
+    C_KZG_RET rc = shard_begin(*sh, (const uint8_t *)blobs, (const uint8_t *)commitments, (const uint8_t *)proofs, n_local, s, mode, true);
+    if (rc != C_KZG_OK) {
+        delete sh;
+        return rc;
+    }
+    shard_records(*sh, records_out);
+    *shard_out = (LwkzgVerifyShard *)sh;
+    return C_KZG_OK;
+}
+
+C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out, LwkzgVerifyShard *shard, const uint8_t *records_all, size_t n_total,
+                                     size_t first_index) {
+    if (!partial_out || !shard || (!records_all && n_total)) return C_KZG_BADARGS;
+    Shard &sh = *(Shard *)shard;
+    HXyzz sums[3];
+    HFr ysum;
+    C_KZG_RET rc = shard_partial(sh, records_all, n_total, first_index, sums, ysum, nullptr);
+    if (rc != C_KZG_OK) return rc;
+    memset(partial_out, 0, kPartial);
+    for (int k = 0; k < 3; k++) point_to_bytes(partial_out + 97 * k, sums[k]);
+    hfr_to_be(partial_out + 291, ysum);
+    return C_KZG_OK;
+}
+
+void lwkzg_verify_shard_free(LwkzgVerifyShard *shard) { delete (Shard *)shard; }
+
+C_KZG_RET lwkzg_verify_shards_finish(bool *ok, const uint8_t *partials, size_t n_shards, size_t n_total, const KZGSettings *s) {
+    if (!ok) return C_KZG_BADARGS;
+    *ok = false;
+    if (n_total == 0) return C_KZG_OK;  // lib.rs:538-543: the empty batch is OK with ok = false
+    if (!partials || !n_shards || !s) return C_KZG_BADARGS;
+    HXyzz sums[3] = {HXyzz::infinity(), HXyzz::infinity(), HXyzz::infinity()};
+    HFr ysum = HFr::zero();
+    for (size_t r = 0; r < n_shards; r++) {
+        const uint8_t *p = partials + kPartial * r;
+        for (int k = 0; k < 3; k++) {
+            HXyzz q;
+            if (!point_from_bytes(q, p + 97 * k)) {
+                set_error("lwkzg_verify_shards_finish: partial sum %d of shard %zu is not a curve point", k, r);
+                return C_KZG_BADARGS;
+            }
+            sums[k] = xyzz_add(sums[k], q);
+        }
+        uint32_t t[8];
+        raw_from_be<8>(t, p + 291);
+        if (raw_geq<8>(t, FrParams::MOD)) return C_KZG_BADARGS;
+        ysum = ysum + hfr_raw(t);
+    }
+    HostPoint g;
+    if (!setup_generator(g, s)) return C_KZG_ERROR;
+    uint32_t ys_raw[8];
+    hfr_to_raw(ys_raw, ysum);
+    return batch_verdict(ok, sums, scalar_mul(to_xyzz(g), ys_raw), s);
 }
 
 // sum of compressed points on the host (gathering the per-GPU partial sums of a sharded long MSM: SURVEY 8e,

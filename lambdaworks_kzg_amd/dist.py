@@ -1,9 +1,12 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 
 SURVEY section 8e: batches of blobs are independent units -> contiguous shards, every GPU holds the full
-setup, NO data-path collective. The only collective is ONE broadcast of the prepared setup image
-(g1_values | g2_values | fixed-base table | twiddles, about 8.6 MB) from the rank that loaded and
-validated the trusted setup, over xGMI. torch is plumbing here (device memory + the process group).
+setup, NO data-path collective for commitments and proofs. The only collective there is ONE broadcast of the
+prepared setup image (g1_values | g2_values | fixed-base table | twiddles, about 10 MB) from the rank that loaded
+and validated the trusted setup, over xGMI. Batch verification has the one real exchange of the path: the
+Fiat-Shamir scalar of the random linear combination hashes every blob's (C, z, y, pi), so the ranks all-gather
+160 bytes per blob and 328 bytes of partial sums per rank (verify_blob_kzg_proof_batch_sharded). The 2^20-term MSM
+gathers one 48-byte partial sum per rank. torch is plumbing here (device memory + the process group).
 """
 import torch
 import torch.distributed as dist
@@ -59,8 +62,9 @@ def gather_shards(local, n_items, item_bytes, group=None):
     rank = dist.get_rank(group)
     counts = [shard_range(n_items, world, r)[1] for r in range(world)]
     mx = max(counts) if counts else 0
-    pad = torch.zeros(mx * item_bytes, dtype=torch.uint8, device=local.device)
-    pad[: counts[rank] * item_bytes] = local.reshape(-1)[: counts[rank] * item_bytes]
+    dev = local.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    pad = torch.zeros(mx * item_bytes, dtype=torch.uint8, device=dev)
+    pad[: counts[rank] * item_bytes] = local.reshape(-1)[: counts[rank] * item_bytes].to(dev)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([parts[r][: counts[r] * item_bytes] for r in range(world)])
@@ -82,24 +86,81 @@ def msm_tiled_sharded(scalars_be, n_terms, ts, device, group=None):
     if group is None and not dist.is_initialized():
         return bytes(out.cpu().numpy().tobytes())
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl":     # gloo (single-GPU plumbing tests) gathers host tensors
+        out = out.cpu()
     parts = [torch.empty_like(out) for _ in range(world)]
     dist.all_gather(parts, out, group=group)
     return capi.g1_sum_compressed(b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts))
 
 
-def verify_blob_kzg_proof_batch_sharded(blobs, commitments, proofs, n_local, ts, group=None, _verify=None):
-    """BASELINE config "verify_blob_kzg_proof_batch, 4096 blobs sharded across 8 GPUs": every rank verifies ITS
-    contiguous shard as an independent batch (own Fiat-Shamir challenges, own random linear combination, own pairing
-    check on its host), then the verdicts are AND-ed with one all_reduce of a single byte. Sound because each
-    sub-batch check is sound on its own; no point or scalar crosses GPUs (SURVEY 8e allows the gather variant, this
-    one needs less traffic). `blobs`/`commitments`/`proofs` are this rank's shard as bytes, `n_local` its length."""
-    verify = _verify or capi.verify_blob_kzg_proof_batch
-    ok = True if n_local == 0 else bool(verify(blobs, commitments, proofs, n_local, ts))
-    if group is None and not dist.is_initialized():
-        return ok
-    flag = torch.tensor([1 if ok else 0], dtype=torch.uint8)
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        flag = flag.cuda()
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    return bool(flag.item())
+def _all_gather_bytes(local, counts, item_bytes, device, group=None):
+    """Every rank contributes counts[rank] items of item_bytes bytes (a bytes object); returns the concatenation in
+    rank order on every rank. One all_gather of equal-sized (padded) tensors."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mx = max(max(counts), 1) * item_bytes
+    pad = torch.zeros(mx, dtype=torch.uint8)
+    if counts[rank]:
+        pad[: counts[rank] * item_bytes] = torch.frombuffer(bytearray(local), dtype=torch.uint8)
+    pad = pad.to(device)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return b"".join(bytes(parts[r][: counts[r] * item_bytes].cpu().numpy().tobytes()) for r in range(world))
+
+
+def verify_blob_kzg_proof_batch_sharded(blobs, commitments, proofs, n_local, ts, group=None, _shard=None, _finish=None):
+    """BASELINE config "verify_blob_kzg_proof_batch, 4096 blobs sharded across 8 GPUs" as the reference computes it
+    (/root/reference/src/lib.rs:525-692, src/utils.rs:166-206): ONE batch, ONE Fiat-Shamir scalar r over the transcript
+    of all blobs, ONE random linear combination, ONE pairing check -- SURVEY 8e's gather form.
+
+    `blobs` / `commitments` / `proofs` are THIS rank's contiguous shard (bytes), `n_local` its length; rank k's shard
+    follows rank k - 1's in the batch. Steps: (1) per blob on this rank's GPU: validation of C_i and pi_i, z_i, y_i;
+    (2) all_gather of the 160-byte transcript records; (3) this rank's terms of the three linear combinations with the
+    common r; (4) all_gather of the 328-byte partial sums; every rank adds them and does the pairing check, so every
+    rank returns the same verdict. Two collectives, 160 bytes per blob + 328 bytes per rank.
+
+    Errors: an invalid point or blob on ANY rank makes EVERY rank raise KzgError after the first collective (the
+    verdict of the lowest such rank, as the reference returns at the first offending blob) -- no rank is left waiting
+    in a collective. An empty global batch returns False, as the reference does for n == 0 (lib.rs:538-543)."""
+    make_shard = _shard or capi.VerifyShard
+    finish = _finish or capi.verify_shards_finish
+    distributed = not (group is None and not dist.is_initialized())
+    err_rc = 0
+    shard = None
+    try:
+        shard = make_shard(blobs, commitments, proofs, n_local, ts)
+    except capi.KzgError as e:
+        err_rc = e.rc or capi.C_KZG_ERROR
+        err_first = e
+    try:
+        if not distributed:
+            if err_rc:
+                raise err_first
+            if n_local == 0:
+                return False
+            return bool(finish(shard.partial(shard.records, n_local, 0), 1, n_local, ts))
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        # shard lengths and error codes of every rank: the one small collective every rank always reaches
+        meta = torch.tensor([n_local, err_rc], dtype=torch.int64, device=device)
+        metas = [torch.empty_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta, group=group)
+        counts = [int(m[0]) for m in metas]
+        rcs = [int(m[1]) for m in metas]
+        if any(rcs):
+            bad = next(r for r in range(world) if rcs[r])
+            if err_rc and bad == rank:
+                raise err_first
+            raise capi.KzgError("verify_blob_kzg_proof_batch_sharded (rank %d rejected its shard)" % bad, rcs[bad])
+        n_total = sum(counts)
+        if n_total == 0:
+            return False
+        first = sum(counts[:rank])
+        records_all = _all_gather_bytes(shard.records, counts, capi.VERIFY_RECORD_BYTES, device, group)
+        partial = shard.partial(records_all, n_total, first)
+        partials = _all_gather_bytes(partial, [1] * world, capi.VERIFY_PARTIAL_BYTES, device, group)
+        return bool(finish(partials, world, n_total, ts))
+    finally:
+        if shard is not None:
+            shard.free()

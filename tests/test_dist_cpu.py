@@ -74,28 +74,73 @@ def test_world_size_2_broadcast_and_gather(n_items):
     assert res == [(0, True, True), (1, True, True)]
 
 
-def _verify_worker(rank, world, port, bad_rank, q):
+class _FakeShard:
+    """Stands in for capi.VerifyShard on a machine without a GPU: record i of the batch is 160 bytes derived from the
+    blob's first byte; the partial sum is a digest of (whole transcript, first index, shard length), so the finish step
+    can check that every rank saw the same complete, ordered transcript and its own position in it."""
+
+    def __init__(self, blobs, commitments, proofs, n_local, ts):
+        import hashlib
+        from lambdaworks_kzg_amd import capi
+        if n_local and blobs[:1] == b"\xff":
+            raise capi.KzgError("lwkzg_verify_shard_begin", capi.C_KZG_ERROR)
+        self.n = n_local
+        self.records = b"".join(hashlib.sha256(blobs[i:i + 1] + commitments[i:i + 1]).digest() * 5 for i in range(n_local))
+        self.freed = False
+
+    def partial(self, records_all, n_total, first):
+        import hashlib
+        assert records_all[160 * first:160 * (first + self.n)] == self.records
+        return (hashlib.sha256(records_all + bytes([first, self.n, n_total])).digest() * 11)[:328]
+
+    def free(self):
+        self.freed = True
+
+
+def _verify_worker(rank, world, port, case, q):
+    import hashlib
+    from lambdaworks_kzg_amd import capi
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # the per-shard verdict is injected: the AND across ranks is what this test covers
-        verdict = D.verify_blob_kzg_proof_batch_sharded(b"", b"", b"", 3, None, _verify=lambda *a: rank != bad_rank)
+        # the batch: 5 one-byte "blobs", rank 0 holds 3 of them (shard_range), rank 1 two -- or nothing at all
+        n_total = 0 if case == "empty" else 5
+        start, count = D.shard_range(n_total, world, rank)
+        blobs = bytes(range(10 + start, 10 + start + count))
+        if case == "bad_rank_1" and rank == 1:
+            blobs = b"\xff" + blobs[1:]
+        comms = bytes(range(50 + start, 50 + start + count))
+
+        def finish(partials, n_shards, n_tot, ts):
+            all_rec = b"".join(hashlib.sha256(bytes([10 + i]) + bytes([50 + i])).digest() * 5 for i in range(n_tot))
+            want = b"".join((hashlib.sha256(all_rec + bytes([D.shard_range(n_tot, n_shards, r)[0], D.shard_range(n_tot, n_shards, r)[1], n_tot])).digest() * 11)[:328]
+                            for r in range(n_shards))
+            return partials == want and n_shards == world and n_tot == n_total
+
+        try:
+            verdict = D.verify_blob_kzg_proof_batch_sharded(blobs, comms, comms, count, None, _shard=_FakeShard, _finish=finish)
+        except capi.KzgError as e:
+            verdict = ("error", e.rc)
         q.put((rank, verdict))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bad_rank", [-1, 1])
-def test_sharded_batch_verification_ands_the_shard_verdicts(bad_rank):
+@pytest.mark.parametrize("case", ["honest", "bad_rank_1", "empty"])
+def test_sharded_batch_verification_gathers_one_transcript(case):
+    """world size 2 over gloo: both ranks see the whole transcript in order, the partial sums arrive in rank order, and
+    both return the same verdict; a shard rejected on one rank makes BOTH ranks raise (nobody hangs in a collective); the
+    empty batch is False as in the reference (lib.rs:538-543)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, bad_rank, q)) for r in range(2)]
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, case, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, bad_rank < 0), (1, bad_rank < 0)]
+    want = {"honest": True, "bad_rank_1": ("error", 2), "empty": False}[case]
+    assert res == [(0, want), (1, want)]
