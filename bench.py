@@ -4,16 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (blob bytes -> 48-byte commitments: parse, fixed-base MSM, compress;
-the MSM is the direct-table kernel when the table fits in HBM, else digit sort + bucket accumulate + bucket
-reduce) over one batch of synthetic 4096-element blobs that is already
-resident in HBM. Each GPU works on its own shard (weak scaling: 1024 blobs per GPU per step); the only
-collective is the one broadcast of the prepared trusted setup before the timed region.
+A "step" is one pass of the hot path (blob bytes -> 48-byte commitments: parse, fixed-base MSM, compress) over one batch
+of synthetic 4096-element blobs that is already resident in HBM. Each GPU works on its own shard (weak scaling: 1024
+blobs per GPU per step); the only collective is the one broadcast of the prepared trusted setup before the timed region.
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (k_direct_accumulate / k_bucket_accumulate) against HBM as
-the north star mandates AND gives the integer-multiply picture, because the kernel is integer-ALU bound
-(DESIGN.md section 5). `cpu_baseline` times the CPU oracle (a restatement of the reference's algorithm,
-NOT the reference binary, which cannot be built here) on this box's host cores.
+Rank 0 prints ONE JSON line. Besides the contract's fields it carries
+  roofline        the dominant kernel (k_direct_accumulate / k_bucket_accumulate) priced against HBM as the north star
+                  mandates AND the integer-multiply picture, because the kernel is integer-ALU bound (DESIGN.md section 4);
+                  `traffic` comes from committed PMC passes and says so in `traffic_source`;
+  default_engine  the same workload on the engine a plain load_trusted_setup* selects (what a drop-in consumer gets),
+  bucket_engine   and on the low-memory fallback: short regions of their own, timed like the headline's;
+  host_abi        the same batch through the host-pointer C ABI, PCIe included (never `value`);
+  cpu_baseline    the CPU oracle (a restatement of the reference's algorithm, NOT the reference binary, which cannot be
+                  built here) on this box's host cores, with and without the SRS rebuild the reference pays per call.
 """
 import argparse
 import json
@@ -32,19 +35,30 @@ SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
 
 
 def _cpu_worker(args):
-    lib_path, first, count = args
+    """One host core: `count` calls of the oracle's blob_to_kzg_commitment, each preceded by the per-call SRS rebuild
+    the reference pays (srs.rs:258-280, lib.rs:266-269) when g2_blst is given. Returns (seconds in the commitments,
+    seconds in the rebuilds, outputs)."""
+    lib_path, first, count, g2_blst = args
     from oracle import oracle as O
     l = O.lib(lib_path)
     s = O.Settings.from_file(SETUP, check_subgroup=False, _lib=l)
+    g1_blst = s.g1_blst()
     import blobs as B
     data = [B.synthetic_blob(first + i) for i in range(count)]
-    t0 = time.perf_counter()
+    t_commit = t_rebuild = 0.0
     outs = []
     for b in data:
+        t0 = time.perf_counter()
+        if g2_blst is not None:
+            assert O.srs_rebuild(g1_blst, g2_blst, _lib=l) == 0
+        t1 = time.perf_counter()
         rc, cm = O.blob_to_kzg_commitment(b, s, O.MODE_R)
+        t2 = time.perf_counter()
         assert rc == 0
+        t_rebuild += t1 - t0
+        t_commit += t2 - t1
         outs.append(cm)
-    return time.perf_counter() - t0, outs
+    return t_commit, t_rebuild, outs
 
 
 def usable_cores():
@@ -60,8 +74,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(gpu_outputs):
-    """Time the oracle on the host: all cores, one blob stream per process. Bounded sample."""
+def cpu_baseline(gpu_outputs, g2_blst):
+    """Time the oracle on the host: all cores, one blob stream per process. Bounded sample. Every call is timed in two
+    parts -- the reference's per-call SRS rebuild and the commitment itself -- so that the rate is reported with and
+    without the rebuild."""
     import multiprocessing as mp
     import tempfile
     from oracle import oracle as O
@@ -73,34 +89,96 @@ def cpu_baseline(gpu_outputs):
             lib_path = O.build()
     cores = usable_cores()
     # one thread first: calibrates the per-blob cost and is itself the reference's configuration
-    t1, o1 = _cpu_worker((lib_path, 0, 4))
-    per_blob = t1 / 4
-    per_proc = max(2, min(64, int(12.0 / per_blob)))    # about 12 s of work per core
+    tc1, tr1, o1 = _cpu_worker((lib_path, 0, 4, g2_blst))
+    per_blob, per_rebuild = tc1 / 4, tr1 / 4
+    per_proc = max(2, min(64, int(12.0 / (per_blob + per_rebuild))))    # about 12 s of work per core
     per_proc = min(per_proc, max(2, BLOBS_PER_GPU // cores))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(lib_path, i * per_proc, per_proc) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(lib_path, i * per_proc, per_proc, g2_blst) for i in range(cores)])
     wall = time.perf_counter() - t0
     total = cores * per_proc
-    busy = max(r[0] for r in res)
+    busy_commit = max(r[0] for r in res)
+    busy_both = max(r[0] + r[1] for r in res)
     verified = True
-    flat = [o for r in res for o in r[1]]
+    flat = [o for r in res for o in r[2]]
     for i, cm in enumerate(flat[:len(gpu_outputs)]):
         if gpu_outputs[i] != cm:
             verified = False
     return {
-        "value": total / busy,
+        "value": total / busy_both,
         "unit": "blob_to_kzg_commitment ops/s",
         "cores": cores,
         "kind": "port",
         "sample": "%d synthetic blobs (%d per core x %d cores, one process per core), %.1f s busy, %.1f s wall incl. "
-                  "process start; single-thread rate %.2f ops/s; CPU restatement of lambdaworks_kzg's algorithm "
-                  "(Pippenger w=9, 29 windows, projective adds), SRS rebuild per call NOT included"
-                  % (total, per_proc, cores, busy, wall, 1.0 / per_blob),
-        "single_thread_ops_per_s": 1.0 / per_blob,
+                  "process start; CPU restatement of lambdaworks_kzg's algorithm (Pippenger w=9, 29 windows, projective "
+                  "adds); `value` INCLUDES the SRS rebuild the reference runs on every call (srs.rs:258-280: 4096 + 65 "
+                  "point conversions with curve checks, %.2f ms per call here), `value_without_srs_rebuild` does not"
+                  % (total, per_proc, cores, busy_both, wall, per_rebuild * 1e3),
+        "value_without_srs_rebuild": total / busy_commit,
+        "single_thread_ops_per_s": 1.0 / (per_blob + per_rebuild),
+        "single_thread_ops_per_s_without_srs_rebuild": 1.0 / per_blob,
+        "srs_rebuild_ms_per_call": per_rebuild * 1e3,
         "gpu_outputs_match_oracle": verified,
     }
+
+
+MADS_PER_MIXED_ADD = 6 * 392 + 2 * 301 + 588    # 6 Montgomery products (392 v_mad_u64_u32 each on 14 x 28-bit limbs), 2 squares (301), one fused pair (588)
+INT_MAD_PEAK_MEASURED = 2.93e13                  # tools/ubench.hip on MI355X: v_mad_u64_u32 lane-ops/s at 8 waves/SIMD (profiles/r01_ubench_instruction_rates.jsonl)
+INT_MAD_PEAK_THEORETICAL = 256 * 4 * 64 / 4 * 2.4e9   # 256 CUs x 4 SIMDs x 64 lanes / 4 cycles per wave-instruction x 2.4 GHz = 3.93e13
+GATHER_PEAK_ROWS = 1.31e10                       # tools/gather_bench.hip on MI355X: random 112-byte rows/s out of a 128-200 GiB table
+
+
+def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launch_override=None):
+    """Roofline object of the dominant MSM kernel of one engine, from the library's hipEvent timings of a timed region:
+    `achieved` = algorithmic bytes per launch / average launch duration (524,336 B per 4096-term MSM)."""
+    dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
+    k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
+    avg_ms = k["total_ms"] / max(1, k["launches"])
+    # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
+    # the units one launch processes = blobs per step / launches per step
+    launches_per_step = max(1, round(k["launches"] / max(1, steps)))
+    msms_per_launch = msms_per_launch_override if msms_per_launch_override is not None else n / launches_per_step
+    achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    if direct_bits:
+        nwin = K.lib().lwkzg_direct_num_windows(direct_bits)
+        adds_per_msm = 4096 * nwin * (1 - 2.0 ** -direct_bits)
+    else:
+        nwin = K.lib().lwkzg_msm_num_windows()
+        adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
+    gather = None
+    if direct_bits and avg_ms > 0:
+        rows = msms_per_launch * adds_per_msm
+        gather = {"rows_per_launch": rows, "bytes_per_launch": rows * 112,
+                  "achieved_rows_per_s": rows / (avg_ms * 1e-3), "peak_rows_per_s": GATHER_PEAK_ROWS,
+                  "frac": rows / (avg_ms * 1e-3) / GATHER_PEAK_ROWS,
+                  "note": "the direct path really reads one random 112-byte table row per mixed addition from HBM "
+                          "(table far larger than every cache); ceiling measured by tools/gather_bench.hip"}
+    mads_per_launch = msms_per_launch * adds_per_msm * MADS_PER_MIXED_ADD
+    mad_rate = mads_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+    return {
+        "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": msms_per_launch * ALGO_BYTES_PER_MSM,
+        "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+        "concurrency_note": "the %d launches of a step run concurrently on separate streams, each on a share of "
+                            "the CUs: per-launch rates are per share; multiply by %d for the rate while both run"
+                            % (launches_per_step, launches_per_step) if launches_per_step > 1 else "one launch per step",
+        "note": "integer-ALU bound, not HBM bound (about 440-600 32-bit multiply-adds per algorithmic byte): see int_mad",
+        "gather": gather,
+        "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
+                    "achieved_Gmad_per_s": mad_rate / 1e9,
+                    "peak_Gmad_per_s": INT_MAD_PEAK_MEASURED / 1e9,
+                    "peak_note": "measured v_mad_u64_u32 issue rate (tools/ubench.hip, 8 waves per SIMD, the clock the chip holds under that load)",
+                    "frac": mad_rate / INT_MAD_PEAK_MEASURED,
+                    "peak_theoretical_Gmad_per_s": INT_MAD_PEAK_THEORETICAL / 1e9,
+                    "peak_theoretical_note": "256 CUs x 4 SIMDs x 64 lanes / 4 cycles per wave-instruction at the 2.4 GHz maximum clock; "
+                                             "the kernel holds ~2.08 GHz (GRBM_GUI_ACTIVE, profiles/r02_pmc_*)",
+                    "frac_of_theoretical": mad_rate / INT_MAD_PEAK_THEORETICAL,
+                    # all multiply-adds of a step over the step's wall time (every kernel, all streams):
+                    "frac_whole_step": mads_per_launch * launches_per_step / (elapsed / steps) / INT_MAD_PEAK_MEASURED},
+    }, nwin
 
 
 def main():
@@ -110,13 +188,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BLOBS_PER_GPU, help="blobs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short untimed-region legs of the commit bench: default engine, bucket engine, host-pointer ABI")
     ap.add_argument("--op", default="commit", choices=["commit", "blob_proof", "verify_batch", "tiled_msm"],
                     help="commit = the headline (BASELINE configs[1]); blob_proof = configs[2]; verify_batch = configs[3], host-pointer ABI; tiled_msm = configs[4], one 2^20-term MSM split over the GPUs (strong scaling)")
     ap.add_argument("--mode", default="reference", choices=["reference", "ckzg"],
                     help="reference = lambdaworks_kzg semantics (default, the headline); ckzg = c-kzg-4844 semantics (adds the inverse NTT)")
     ap.add_argument("--direct-bits", default="auto",
-                    help="direct fixed-base table (lwkzg_enable_direct_table): auto = widest of 16/15/14 that fits in HBM, "
-                         "else the bucket path; 0 = bucket path; 14/15/16 = that width or fail")
+                    help="MSM engine of the timed region (lwkzg_enable_direct_table): auto = the widest direct table of 16 .. 10 bits "
+                         "that fits in HBM, else the bucket engine; default = what a plain load selected; 0 = bucket engine; "
+                         "10 .. 16 = that width or fail")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
 
@@ -147,12 +228,14 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    # trusted setup: rank 0 parses + validates + builds the fixed-base table, one RCCL broadcast delivers it
+    # trusted setup: rank 0 parses + validates + builds the fixed-base table, one RCCL broadcast delivers it; every rank
+    # then holds the engine a plain load selects (the default engine: engine.hip, direct_from_env)
     t_load0 = time.perf_counter()
     ts = K.TrustedSetup.from_file(SETUP) if rank == 0 else None
     if world > 1:
         ts = D.broadcast_trusted_setup(ts, dev, src=0)
     t_load = time.perf_counter() - t_load0
+    default_bits = ts.direct_table_bits()
 
     n = args.batch
     first = rank * n                       # shard: blob k of the job lives on GPU floor(k / n)
@@ -162,7 +245,72 @@ def main():
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
     d_comm = None
     ts.reserve(n)
-    # every rank builds its own direct table from the (broadcast) setup points: a few seconds, once, outside the timed region
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    h_blobs = h_comms = h_proofs = None
+    d_tiles = None
+    tiles_total = 256                      # 2^20 terms over the setup tiled 256 times
+
+    def step():
+        if args.op == "tiled_msm":      # each rank sums its share of the tiles, one all_gather of 48-byte partial sums
+            D.msm_tiled_sharded(d_tiles, int(d_tiles.numel()) // 32, ts, dev)
+        elif args.op == "verify_batch":   # ONE batch over all ranks: one transcript, one r, one pairing check (dist.py)
+            assert D.verify_blob_kzg_proof_batch_sharded(h_blobs, h_comms, h_proofs, n, ts)
+        elif args.op == "commit":
+            K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
+        else:
+            K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, stream,
+                                                  d_status.data_ptr())
+
+    def timed_region(steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        capi.profile_reset()
+        capi.profile_enable(True)             # hipEvent pairs around every kernel, on the launch stream
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        capi.profile_enable(False)
+        pr = capi.profile_report()
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        assert int(d_status.abs().sum().item()) == 0, "a blob was rejected"
+        return el, pr
+
+    def engine_leg(bits, label):
+        """the same workload on another engine, a short region of its own before the headline's (same timing rules)"""
+        el, pr = timed_region(5, 2)
+        roof, nwin = engine_picture(K, capi, bits, pr, el, 5, n)
+        return {"engine": label, "direct_bits": bits, "value": n * world * 5 / el, "unit": "ops/s", "steps": 5, "warmup": 2,
+                "ms_per_step": el / 5 * 1e3,
+                "table_bytes": capi.direct_table_bytes(bits) if bits else 20 * 4096 * 112,
+                "kernels": {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in pr.items()},
+                "roofline": roof}
+
+    extra = {}
+    if args.op == "commit" and not args.no_extra_legs:
+        # (a) what a consumer of the nine reference symbols gets: the engine the load selected, untouched
+        extra["default_engine"] = engine_leg(default_bits, "what load_trusted_setup* selects by itself (LWKZG_DIRECT_BITS unset): the widest "
+                                             "direct table of 13..10 bits within a quarter of the free HBM, else buckets")
+        extra["default_engine"]["setup_load_s_incl_table_build"] = t_load
+        # (b) the low-memory fallback
+        ts.enable_direct_table(0)
+        extra["bucket_engine"] = engine_leg(0, "Pippenger buckets over the 9 MB fixed-base table (LWKZG_DIRECT_BITS=0, or no memory for a table)")
+        ts.enable_direct_table(default_bits)
+
+    # the engine of the timed region. Every rank builds its own table from the (broadcast) setup points, once, outside the
+    # timed region; the seconds are reported per rank below.
     t_tab0 = time.perf_counter()
     direct_bits = 0
     if args.direct_bits == "auto":
@@ -175,32 +323,19 @@ def main():
                 if e.rc != capi.C_KZG_MALLOC:
                     raise
     elif args.direct_bits == "default":     # whatever a plain load selected (engine.hip: direct_from_env)
-        direct_bits = ts.direct_table_bits()
+        direct_bits = default_bits
     else:
         ts.enable_direct_table(int(args.direct_bits))
         direct_bits = int(args.direct_bits)
     t_table = time.perf_counter() - t_tab0
-    direct_bits_min = direct_bits
+    direct_bits_min, t_table_max = direct_bits, t_table
     if world > 1:   # every rank should have got the same width; report it if one did not
         tb = torch.tensor([direct_bits], dtype=torch.int32, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)
         direct_bits_min = int(tb.item())
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    h_blobs = h_comms = h_proofs = None
-    d_tiles = None
-    tiles_total = 256                      # 2^20 terms over the setup tiled 256 times
-
-    def step():
-        if args.op == "tiled_msm":      # each rank sums its share of the tiles, one all_gather of 48-byte partial sums
-            D.msm_tiled_sharded(d_tiles, int(d_tiles.numel()) // 32, ts, dev)
-        elif args.op == "verify_batch":   # each rank verifies its shard as an independent batch, one all_reduce of the verdict
-            assert D.verify_blob_kzg_proof_batch_sharded(h_blobs, h_comms, h_proofs, n, ts)
-        elif args.op == "commit":
-            K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
-        else:
-            K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, stream,
-                                                  d_status.data_ptr())
+        tt = torch.tensor([t_table], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_table_max = float(tt.item())
 
     if args.op == "blob_proof":
         d_comm = torch.empty(48 * n, dtype=torch.uint8, device=dev)
@@ -216,75 +351,54 @@ def main():
         h_comms = b"".join(K.blob_to_kzg_commitment_batch(h_blobs, ts))
         h_proofs = b"".join(K.compute_blob_kzg_proof_batch(h_blobs, h_comms, ts))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
+    elapsed, prof = timed_region(args.steps, args.warmup)
 
-    capi.profile_reset()
-    capi.profile_enable(True)             # hipEvent pairs around every kernel, on the launch stream
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    capi.profile_enable(False)
-    prof = capi.profile_report()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert int(d_status.abs().sum().item()) == 0, "a blob was rejected"
+    if args.op == "commit" and not args.no_extra_legs and rank == 0:
+        # (c) the same batch through the host-pointer C ABI (blobs in pageable host memory: H2D of 128 KiB per blob and D2H
+        # of the 48-byte results inside the clock). Never `value`.
+        hb = host.tobytes()
+        K.blob_to_kzg_commitment_batch(hb, ts)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            got = K.blob_to_kzg_commitment_batch(hb, ts)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        assert b"".join(got) == bytes(d_out.cpu().numpy().tobytes())
+        extra["host_abi"] = {"symbol": "lwkzg_blob_to_kzg_commitment_batch", "blobs_per_call": n, "direct_bits": direct_bits,
+                             "value": n / times[len(times) // 2], "unit": "ops/s", "ms_per_call_median": times[len(times) // 2] * 1e3,
+                             "ms_per_call_best": times[0] * 1e3, "calls": len(times),
+                             "note": "PCIe-inclusive wall clock on rank 0: pageable host blobs in, 48-byte commitments out, one GPU; "
+                                     "results equal to the device-resident path's"}
 
     if rank == 0:
         total_blobs = n * world * args.steps
         value = total_blobs / elapsed
         if args.op == "tiled_msm":
             value = tiles_total * 4096 * args.steps / elapsed      # terms per second, whole job
-        dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
+        override = None
+        if args.op == "tiled_msm":    # a tile is one 4096-term MSM; rank 0's share of the tiles per launch
+            k0 = prof.get("k_direct_accumulate" if direct_bits else "k_bucket_accumulate", {"launches": 0})
+            override = D.shard_range(tiles_total, world, 0)[1] / max(1, round(k0["launches"] / max(1, args.steps)))
+        roofline, nwin = engine_picture(K, capi, direct_bits, prof, elapsed, args.steps, n, override)
+        dom = roofline["kernel"]
         if args.op == "verify_batch":   # no MSM here: the longest kernel of the per-blob pass is the one priced
             dom = max(prof, key=lambda kk: prof[kk]["total_ms"]) if prof else dom
-        k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
-        avg_ms = k["total_ms"] / max(1, k["launches"])
-        # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
-        # the units one launch processes = blobs per step / launches per step
-        launches_per_step = max(1, round(k["launches"] / max(1, args.steps)))
-        msms_per_launch = n / launches_per_step
-        if args.op == "tiled_msm":    # a tile is one 4096-term MSM; rank 0's share of the tiles per launch
-            msms_per_launch = D.shard_range(tiles_total, world, 0)[1] / launches_per_step
-        achieved = msms_per_launch * ALGO_BYTES_PER_MSM / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline["kernel"] = dom
         kernels = {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in prof.items()}
-        # integer picture: a mixed add is 6 Montgomery products (392 v_mad_u64_u32 each on 14 limbs of 28 bits), 2 squares
-        # (301 each) and one fused product pair a*b - c*d with a single reduction (588); peak = v_mad_u64_u32 issue rate measured by tools/ubench.hip on MI355X
-        # (profiles/r01_ubench_instruction_rates.jsonl: 2.93e13 lane-mads/s at 8 waves/SIMD)
-        if direct_bits:
-            nwin = K.lib().lwkzg_direct_num_windows(direct_bits)
-            adds_per_msm = 4096 * nwin * (1 - 2.0 ** -direct_bits)
-        else:
-            nwin = K.lib().lwkzg_msm_num_windows()
-            adds_per_msm = 4096 * nwin * (1 - 2.0 ** -K.lib().lwkzg_msm_window_bits())
-        GATHER_PEAK_ROWS = 1.31e10     # tools/gather_bench.hip on MI355X: random 112-byte rows/s out of a 128-200 GiB table
-        gather = None
-        if direct_bits and avg_ms > 0:
-            rows = msms_per_launch * adds_per_msm
-            gather = {"rows_per_launch": rows, "bytes_per_launch": rows * 112,
-                      "achieved_rows_per_s": rows / (avg_ms * 1e-3), "peak_rows_per_s": GATHER_PEAK_ROWS,
-                      "frac": rows / (avg_ms * 1e-3) / GATHER_PEAK_ROWS,
-                      "note": "the direct path really reads one random 112-byte table row per mixed addition from HBM "
-                              "(table far larger than every cache); ceiling measured by tools/gather_bench.hip"}
-        mads_per_launch = msms_per_launch * adds_per_msm * (6 * 392 + 2 * 301 + 588)
-        INT_MAD_PEAK = 2.93e13
-        traffic = None
-        try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size only
+        traffic, traffic_source = None, None
+        try:   # PMC passes are separate rocprofv3 runs (tools/pmc_summary.py); valid for the same batch size and engine only
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("batch_blobs_per_launch") == msms_per_launch and args.op == "commit" and pmc.get("direct_bits", 0) == direct_bits:
+            if pmc.get("batch_blobs_per_launch") == n / roofline["launches_per_step"] and args.op == "commit" and pmc.get("direct_bits", 0) == direct_bits:
                 traffic = pmc["kernels"][dom]["traffic_bytes"]
+                traffic_source = "profiles/pmc_traffic.json (round %s): committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in this run" % pmc.get("round")
         except Exception:
             traffic = None
+        roofline["traffic"] = traffic
+        roofline["traffic_source"] = traffic_source
+        roofline["traffic_note"] = ("bytes per launch at the L2's memory side from rocprofv3 FETCH_SIZE (raw) + WRITE_SIZE, separate passes; " +
+                                    ("random 112-byte row gathers out of the direct table, see DESIGN.md section 4" if direct_bits else
+                                     "mostly Infinity-Cache-served re-reads of the 9.2 MB fixed-base table, see DESIGN.md section 4"))
         res = {
             "metric": {"commit": "blob_to_kzg_commitment ops/sec (4096-elem blobs)",
                        "blob_proof": "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
@@ -304,41 +418,31 @@ def main():
             "config": {"workload": {"commit": "BASELINE configs[1]: single-GPU 4096-scalar G1 MSM (blob -> commitment), batch=%d synthetic blobs "
                                              "per GPU per step, device-resident, bit-exact vs CPU",
                                    "blob_proof": "BASELINE configs[2]: compute_blob_kzg_proof (Fiat-Shamir hash, quotient, MSM), batch=%d synthetic "
-                                                 "blobs per GPU per step, device-resident",
-                                   "verify_batch": "BASELINE configs[3]: verify_blob_kzg_proof_batch, %d synthetic blobs per GPU per step verified as "
-                                                   "one batch per GPU, blobs in host memory (H2D inside the timed region)",
+                                                 "blobs per GPU per step, device-resident, one call per step",
+                                   "verify_batch": "BASELINE configs[3]: verify_blob_kzg_proof_batch, %d synthetic blobs per GPU per step; all ranks' blobs "
+                                                   "form ONE batch (one transcript, one r, one pairing check; records and partial sums all-gathered), "
+                                                   "blobs in host memory (H2D inside the timed region)",
                                    "tiled_msm": "BASELINE configs[4]: one 2^20-term G1 MSM over the setup tiled 256 times, tiles split over "
                                                 "the GPUs, partial sums gathered and added on the host (%d is unused here)"}[args.op] % n,
                        "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch at the L2's memory side from rocprofv3 FETCH_SIZE (raw) + WRITE_SIZE, "
-                                         "separate passes (profiles/pmc_traffic.json); " +
-                                         ("random 112-byte row gathers out of the direct table, see DESIGN.md section 4" if direct_bits else
-                                          "mostly Infinity-Cache-served re-reads of the 9.2 MB fixed-base table, see DESIGN.md section 4"),
-                         "gather": gather,
-                         "algorithmic_bytes_per_launch": msms_per_launch * ALGO_BYTES_PER_MSM,
-                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-                         "concurrency_note": "the %d launches of a step run concurrently on separate streams, each on a share of "
-                                             "the CUs: per-launch rates are per share; multiply by %d for the rate while both run"
-                                             % (launches_per_step, launches_per_step) if launches_per_step > 1 else "one launch per step",
-                         "note": "integer-ALU bound, not HBM bound (about 600 int-ops per algorithmic byte): see int_mad",
-                         "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
-                                     "achieved_Gmad_per_s": mads_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                                     "peak_Gmad_per_s": INT_MAD_PEAK / 1e9,
-                                     "frac": (mads_per_launch / (avg_ms * 1e-3) / INT_MAD_PEAK) if avg_ms > 0 else 0.0,
-                                     # all multiply-adds of a step over the step's wall time (every kernel, all streams):
-                                     "frac_whole_step": mads_per_launch * launches_per_step / (elapsed / args.steps) / INT_MAD_PEAK}},
+            "roofline": roofline,
             "kernels": kernels,
             "setup_load_s": t_load,
             "msm_path": ("direct table, %d-bit windows, %d windows, %.0f GB resident" % (
                 direct_bits, nwin, capi.direct_table_bytes(direct_bits) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
+            "engine_note": "the timed region runs on the widest direct table that fits (--direct-bits auto, an explicit lwkzg_enable_direct_table "
+                           "call); `default_engine` is the same workload on the engine a plain load selects, `bucket_engine` on the low-memory fallback",
             "direct_table_build_s": t_table if direct_bits else None,
+            "direct_table_build_s_max_over_ranks": t_table_max if direct_bits else None,
+            "direct_table_build_note": "every rank builds its own table from the broadcast setup points, once, outside the timed region" if direct_bits else None,
         }
+        res.update(extra)
+        if world > 1:
+            res["scaling_note"] = "per-GPU work is fixed (weak scaling); multi-GPU throughput is unmeasured on hardware by the builder (one-GPU boxes only)"
         if world == 1 and not args.no_cpu_baseline and args.mode == "reference":
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
-            res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)])
+            res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)], ts.g2_values_bytes())
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -38,9 +38,11 @@ def lib(path=None):
     if path is not None:
         return _bind(C.CDLL(path))
     if _LIB is None:
-        p = os.path.join(_HERE, "liboracle_kzg.so")
-        if not os.path.exists(p):
-            build()
+        p = os.environ.get("LWKZG_ORACLE_LIBRARY")   # e.g. the AddressSanitizer build (tests/test_oracle_golden.py)
+        if not p:
+            p = os.path.join(_HERE, "liboracle_kzg.so")
+            if not os.path.exists(p):
+                build()
         _LIB = _bind(C.CDLL(p))
     return _LIB
 
@@ -60,6 +62,7 @@ def _bind(l):
         getattr(l, f).restype = vp
     l.orc_settings_g1_blst.argtypes = [vp, vp]
     l.orc_settings_g1_blst.restype = None
+    l.orc_srs_rebuild.argtypes = [cp, ci, cp, ci]
     l.orc_blob_to_kzg_commitment.argtypes = [cp, cp, vp, ci, ci]
     l.orc_compute_kzg_proof.argtypes = [cp, cp, cp, cp, vp, ci, ci]
     l.orc_compute_blob_kzg_proof.argtypes = [cp, cp, cp, vp, ci, ci]
@@ -134,6 +137,14 @@ def blob_to_kzg_commitment(blob, s, mode=MODE_R, algo=ALGO_PIPPENGER):
     out = C.create_string_buffer(48)
     rc = s._l.orc_blob_to_kzg_commitment(out, blob, s.h, mode, algo)
     return rc, (out.raw if rc == OK else None)
+
+
+def srs_rebuild(g1_blst, g2_blst=b"", _lib=None):
+    """kzgsettings_to_structured_reference_string (/root/reference/src/srs.rs:258-280), the conversion + curve checks the
+    reference repeats on every API call, over the C arrays as the reference lays them out (144 bytes per blst_p1, 288 per
+    blst_p2). Returns the return code."""
+    assert len(g1_blst) % 144 == 0 and len(g2_blst) % 288 == 0
+    return (_lib or lib()).orc_srs_rebuild(g1_blst, len(g1_blst) // 144, g2_blst, len(g2_blst) // 288)
 
 
 def compute_kzg_proof(blob, z, s, mode=MODE_R, algo=ALGO_PIPPENGER):

@@ -352,6 +352,68 @@ EXPORT void orc_settings_g1_blst(const orc_settings *s, uint64_t *out) {
     }
 }
 
+/* kzgsettings_to_structured_reference_string, /root/reference/src/srs.rs:258-280, which the reference runs at the
+ * start of EVERY blob_to_kzg_commitment / compute_*_proof / verify_* call (lib.rs:266-269 and the like): the two C
+ * arrays are copied by value (`*s.g1_values.cast()`, 589,824 + 18,720 bytes), every blst_p1 goes through
+ * blst_p1_to_g1_point (srs.rs:155-172: limbs -> big-endian bytes -> from_bytes_be (into Montgomery form) -> from_affine,
+ * which checks y^2 = x^3 + 4) and every blst_p2 through blst_p2_to_g2_point (srs.rs:215-247: four such conversions and
+ * the twist-curve check y^2 = x^3 + 4(1 + i) over Fp2). The result is a fresh Vec of projective points per call; only
+ * g2[0], g2[1] are kept. Restated here so that bench.py's cpu_baseline can time the reference's per-call cost with and
+ * without it. Returns RET_OK, or RET_ERROR if a point fails its curve check (as the reference's `?` would). */
+static int fp_from_blst_limbs(fp_t *o, const uint64_t *l_be) {
+    uint8_t be[48];
+    for (int k = 0; k < 6; k++)             /* e.to_be_bytes() of each limb, most significant limb first */
+        for (int b = 0; b < 8; b++) be[8 * k + b] = (uint8_t)(l_be[k] >> (56 - 8 * b));
+    uint64_t raw[6];
+    for (int k = 0; k < 6; k++) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v = (v << 8) | be[8 * (5 - k) + b];
+        raw[k] = v;
+    }
+    fp_from_raw(o, raw);                    /* from_bytes_be: the integer times R^2, Montgomery-reduced */
+    return 0;
+}
+
+EXPORT int orc_srs_rebuild(const uint64_t *blst_p1, int n1, const uint64_t *blst_p2, int n2) {
+    uint64_t *copy1 = malloc((size_t)n1 * 18 * 8), *copy2 = malloc((size_t)n2 * 36 * 8);
+    g1_t *pts = malloc((size_t)n1 * sizeof(g1_t));
+    int rc = RET_OK;
+    if (!copy1 || !copy2 || !pts) { rc = RET_MALLOC; goto out; }
+    memcpy(copy1, blst_p1, (size_t)n1 * 18 * 8);   /* the by-value copies of srs.rs:261-262 */
+    memcpy(copy2, blst_p2, (size_t)n2 * 36 * 8);
+    for (int i = 0; i < n1; i++) {
+        fp_t x, y;
+        fp_from_blst_limbs(&x, copy1 + 18 * (size_t)i);
+        fp_from_blst_limbs(&y, copy1 + 18 * (size_t)i + 6);
+        if (!g1_on_curve_affine(&x, &y)) { rc = RET_ERROR; goto out; }   /* from_affine */
+        g1_from_affine(&pts[i], &x, &y);
+    }
+    for (int i = 0; i < n2; i++) {
+        fp_t x0, x1, y0, y1;
+        const uint64_t *p = copy2 + 36 * (size_t)i;
+        fp_from_blst_limbs(&x0, p);
+        fp_from_blst_limbs(&x1, p + 6);
+        fp_from_blst_limbs(&y0, p + 12);
+        fp_from_blst_limbs(&y1, p + 18);
+        /* y^2 == x^3 + 4(1 + i) in Fp[i]/(i^2 + 1) */
+        fp_t a, b, t, u, l0, l1, r0, r1, four;
+        fp_sqr(&a, &y0); fp_sqr(&b, &y1); fp_sub(&l0, &a, &b);            /* y^2 = (y0^2 - y1^2) + 2 y0 y1 i */
+        fp_mul(&l1, &y0, &y1); fp_add(&l1, &l1, &l1);
+        fp_sqr(&a, &x0); fp_sqr(&b, &x1); fp_sub(&t, &a, &b);              /* x^2 = t + u i */
+        fp_mul(&u, &x0, &x1); fp_add(&u, &u, &u);
+        fp_mul(&a, &t, &x0); fp_mul(&b, &u, &x1); fp_sub(&r0, &a, &b);    /* x^3 = (t x0 - u x1) + (t x1 + u x0) i */
+        fp_mul(&a, &t, &x1); fp_mul(&b, &u, &x0); fp_add(&r1, &a, &b);
+        fp_set_u64(&four, 4);
+        fp_add(&r0, &r0, &four); fp_add(&r1, &r1, &four);
+        if (!fp_eq(&l0, &r0) || !fp_eq(&l1, &r1)) { rc = RET_ERROR; goto out; }
+    }
+out:
+    free(copy1);
+    free(copy2);
+    free(pts);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ MSM */
 
 /* lambdaworks_math::msm::pippenger::msm (un-vendored; call sites

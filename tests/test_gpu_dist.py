@@ -87,7 +87,7 @@ def test_verify_batch_4096_blobs_single_and_8_shards(K, gpu_setup):
     assert _sharded_verdict(capi, D, data, comms, sw(proofs, 48), n, 8, gpu_setup) is False
 
 
-@pytest.mark.parametrize("n,world", [(2, 2), (5, 8), (64, 3), (200, 8), (1100, 2)])
+@pytest.mark.parametrize("n,world", [(2, 2), (5, 8), (64, 3), (200, 8), (2300, 2)])
 def test_sharded_verification_equals_single_batch(K, gpu_setup, n, world):
     """shard counts that leave some ranks empty (5 blobs on 8 ranks), every validation route (host threads up to 64 blobs
     per shard, GPU kernels above, the pipelined path above 1024), in both modes; invalid input on one shard is an error"""

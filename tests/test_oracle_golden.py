@@ -215,3 +215,44 @@ def test_ntt_roundtrip_and_definition(oracle):
     for k in (0, 1, 5, 4095):       # X_k = sum x_j w^(jk)
         want = sum(v * pow(w, j * k, R) for j, v in enumerate(vals)) % R
         assert int.from_bytes(fwd[32 * k:32 * k + 32], "big") == want
+
+
+def test_srs_rebuild_restatement(oracle, oracle_setup):
+    """kzgsettings_to_structured_reference_string (src/srs.rs:258-280), the per-call conversion + curve checks that
+    bench.py's cpu_baseline times: accepts the setup's own blst_p1 array, rejects an off-curve point (as `?` would)"""
+    g1 = oracle_setup.g1_blst()
+    assert len(g1) == 4096 * 144
+    assert oracle.srs_rebuild(g1) == oracle.OK
+    bad = bytearray(g1)
+    bad[144 * 1234 + 90] ^= 4
+    assert oracle.srs_rebuild(bytes(bad)) == oracle.ERROR
+    # G2: the generator of the twist in the reference's blst_p2 layout (x.c0, x.c1, y.c0, y.c1; limbs most significant first)
+    g2 = [0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+          0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e,
+          0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+          0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be]
+    import struct
+    def limbs(v):
+        return struct.pack("<6Q", *[(v >> (64 * (5 - k))) & 0xFFFFFFFFFFFFFFFF for k in range(6)])
+    p2 = b"".join(limbs(v) for v in g2) + bytes(96)
+    assert oracle.srs_rebuild(g1[:144], p2) == oracle.OK
+    assert oracle.srs_rebuild(g1[:144], limbs(g2[0] ^ 1) + p2[48:]) == oracle.ERROR
+
+
+def test_oracle_golden_vectors_under_address_sanitizer():
+    """SURVEY section 5 (sanitizers): the oracle built with -fsanitize=address,undefined (oracle/Makefile) re-runs its
+    golden-vector tests in a child process; any report aborts it. CPU only: GPU sanitizers are not available here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "liboracle_kzg_asan.so"])
+    asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    ubsan_rt = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"]).decode().strip()
+    env = dict(os.environ, LWKZG_ORACLE_LIBRARY=os.path.join(root, "oracle", "liboracle_kzg_asan.so"),
+               LD_PRELOAD=asan_rt + ":" + ubsan_rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    sel = "compression or lib_test or smoke or closed_form or noncanonical or blob_to_kzg_commitment or blob_kzg_proof or ntt or srs_rebuild or sha256"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
+                         env=env, capture_output=True, timeout=900)
+    assert out.returncode == 0, out.stdout.decode()[-3000:] + out.stderr.decode()[-3000:]
+    assert b"passed" in out.stdout and b"AddressSanitizer" not in out.stderr and b"runtime error" not in out.stderr
