@@ -198,6 +198,9 @@ def main():
                     help="MSM engine of the timed region (lwkzg_enable_direct_table): auto = the widest direct table of 16 .. 10 bits "
                          "that fits in HBM, else the bucket engine; default = what a plain load selected; 0 = bucket engine; "
                          "10 .. 16 = that width or fail")
+    ap.add_argument("--scalars", default="31byte", choices=["31byte", "full"],
+                    help="31byte = the BASELINE workload (31 random bytes per element, SURVEY 8d); full = 32 random bytes per element, "
+                         "reduced mod r by the parse kernel (reference mode only): every window of every scalar is busy")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
 
@@ -239,7 +242,7 @@ def main():
 
     n = args.batch
     first = rank * n                       # shard: blob k of the job lives on GPU floor(k / n)
-    host = np.frombuffer(B.synthetic_batch(first, n, big_endian=(args.mode == "reference")), dtype=np.uint8)
+    host = np.frombuffer(B.synthetic_batch(first, n, big_endian=(args.mode == "reference"), full_range=(args.scalars == "full")), dtype=np.uint8)
     d_blobs = torch.from_numpy(host.copy()).to(dev)
     d_out = torch.empty(48 * n, dtype=torch.uint8, device=dev)
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -424,7 +427,7 @@ def main():
                                                    "blobs in host memory (H2D inside the timed region)",
                                    "tiled_msm": "BASELINE configs[4]: one 2^20-term G1 MSM over the setup tiled 256 times, tiles split over "
                                                 "the GPUs, partial sums gathered and added on the host (%d is unused here)"}[args.op] % n,
-                       "blobs_per_gpu_per_step": n, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
+                       "blobs_per_gpu_per_step": n, "scalars": args.scalars, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": roofline,
             "kernels": kernels,
@@ -440,7 +443,7 @@ def main():
         res.update(extra)
         if world > 1:
             res["scaling_note"] = "per-GPU work is fixed (weak scaling); multi-GPU throughput is unmeasured on hardware by the builder (one-GPU boxes only)"
-        if world == 1 and not args.no_cpu_baseline and args.mode == "reference":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "reference" and args.scalars == "31byte":
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
             res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)], ts.g2_values_bytes())
         print(json.dumps(res), flush=True)

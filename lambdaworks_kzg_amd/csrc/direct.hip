@@ -234,6 +234,9 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
             carry = ng;
             size_t idx = top ? P.top_base + (size_t)point * P.htop + (mag - 1)
                              : ((size_t)j * kBlobElems + point) * P.h + (mag - 1);
+#ifdef LWK_DIRECT_IDX_MASK  // experiment builds only: confine the gathers to a cache-resident part of the table (WRONG results)
+            idx &= (size_t)LWK_DIRECT_IDX_MASK;
+#endif
             j++;
             if (j == P.nw) {
                 j = 0;

@@ -104,6 +104,38 @@ void verify_buffers_free(VerifyBuffers &v);
 // thread against a 2 ms latency-shaped kernel. 4 per usable hardware thread, at most 64.
 size_t host_small_batch_limit();
 
+// Coalescing front of the single-blob symbols (engine.hip: combine_commit). The reference's KZGSettings is read-only
+// after load, so any number of threads may call blob_to_kzg_commitment on one settings object at once
+// (/root/reference/src/lib.rs:253-283, SURVEY 8b "Threading"); a GPU call per blob would serialise them at one launch
+// set each. Callers that arrive while a launch set is in flight are merged into the next one: each copies its blob into
+// a pinned staging slot, one of them (the "leader") uploads the batch, launches, waits and hands every caller its 48
+// bytes. Two lanes (streams + workspace halves) are in flight at most, so one batch uploads while the other computes.
+constexpr int kCombineLanes = 2;
+constexpr size_t kCombineSlots = 128;     // pinned 128 KiB staging slots (16 MiB)
+constexpr size_t kCombineMaxBatch = 64;   // requests per launch set
+
+struct CombineReq {
+    enum State { QUEUED, TAKEN, DONE };
+    int slot = -1;          // pinned staging slot holding the blob
+    int mode = 0;
+    uint8_t *out48 = nullptr;
+    C_KZG_RET rc = C_KZG_OK;
+    State state = QUEUED;
+};
+
+struct Combiner {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<CombineReq *> queue;
+    int leaders = 0;
+    bool lane_busy[kCombineLanes] = {false, false};
+    uint8_t *pinned_blobs = nullptr;                  // kCombineSlots x 131072, hipHostMalloc
+    uint8_t *pinned_out[kCombineLanes] = {nullptr, nullptr};     // kCombineMaxBatch x 48
+    int32_t *pinned_status[kCombineLanes] = {nullptr, nullptr};  // kCombineMaxBatch
+    std::vector<int> free_slots;
+    bool ready = false, failed = false;
+};
+
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {
     FFTSettings fs;
@@ -117,6 +149,8 @@ struct Ctx {
     // makes its stream wait for the event the previous user of the workspace recorded (WsUse, engine.hip).
     hipEvent_t ws_done;
     hipStream_t ws_last;
+    hipEvent_t lane_done[kCombineLanes];  // last use of a workspace half by a lane of the coalescing front
+    Combiner comb;
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
     G1Affine29 *table;  // kTablePoints, hot-loop representation
     G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled

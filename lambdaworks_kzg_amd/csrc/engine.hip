@@ -108,10 +108,23 @@ struct WsUse {
     hipStream_t st;
     WsUse(Ctx *c_, hipStream_t st_) : c(c_), st(st_) {
         if (c->ws_last != st) hipStreamWaitEvent(st, c->ws_done, 0);
+        for (int k = 0; k < kCombineLanes; k++) hipStreamWaitEvent(st, c->lane_done[k], 0);  // (never recorded: no-op)
     }
     ~WsUse() {
         hipEventRecord(c->ws_done, st);
         c->ws_last = st;
+    }
+};
+
+// A lane of the coalescing front uses ONE half of the workspace on its own stream: it waits for the last user of the
+// whole workspace and leaves an event of its own; the two lanes do not wait for each other.
+struct WsLaneUse {
+    Ctx *c;
+    int lane;
+    WsLaneUse(Ctx *c_, int lane_) : c(c_), lane(lane_) { hipStreamWaitEvent(c->aux[lane], c->ws_done, 0); }
+    ~WsLaneUse() {
+        hipEventRecord(c->lane_done[lane], c->aux[lane]);
+        c->ws_last = nullptr;  // the next whole-workspace user must wait for its predecessor's event again: a lane ran between
     }
 };
 
@@ -214,6 +227,12 @@ static void ctx_destroy(Ctx *c) {
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ws_done) hipEventDestroy(c->ws_done);
+    for (int k = 0; k < kCombineLanes; k++) {
+        if (c->lane_done[k]) hipEventDestroy(c->lane_done[k]);
+        if (c->comb.pinned_out[k]) hipHostFree(c->comb.pinned_out[k]);
+        if (c->comb.pinned_status[k]) hipHostFree(c->comb.pinned_status[k]);
+    }
+    if (c->comb.pinned_blobs) hipHostFree(c->comb.pinned_blobs);
     free(c->fs.expanded_roots_of_unity);
     free(c->fs.reverse_roots_of_unity);
     free(c->fs.roots_of_unity);
@@ -248,6 +267,7 @@ static C_KZG_RET ctx_new(Ctx **out) {
     c->stream = nullptr;
     c->ws_done = nullptr;
     c->ws_last = nullptr;
+    for (int k = 0; k < kCombineLanes; k++) c->lane_done[k] = nullptr;
     c->vstream = nullptr;
     c->ev_fork = nullptr;
     for (int k = 0; k < kMaxSplit; k++) {
@@ -269,6 +289,7 @@ static C_KZG_RET ctx_new(Ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_done, hipEventDisableTiming);
+    for (int k = 0; k < kCombineLanes && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming);
     for (int k = 0; k < kMaxSplit && e == hipSuccess; k++) {
         e = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming);
@@ -1225,12 +1246,148 @@ static size_t slice_len(size_t k, size_t remaining, size_t n) {
     return remaining < want ? remaining : want;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Coalescing front of blob_to_kzg_commitment (engine.h: Combiner). Contract matched: concurrent callers on one
+// KZGSettings, /root/reference/src/lib.rs:253-283 + SURVEY 8b "Threading".
+
+static bool combiner_init(Ctx *c) {  // caller holds comb.m
+    Combiner &cb = c->comb;
+    if (cb.ready || cb.failed) return cb.ready;
+    hipSetDevice(c->device);
+    bool ok = hipHostMalloc((void **)&cb.pinned_blobs, kCombineSlots * (size_t)kBlobBytes, hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; k < kCombineLanes && ok; k++)
+        ok = hipHostMalloc((void **)&cb.pinned_out[k], kCombineMaxBatch * 48, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void **)&cb.pinned_status[k], kCombineMaxBatch * 4, hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        cb.failed = true;  // callers fall back to one launch set each
+        return false;
+    }
+    for (int k = (int)kCombineSlots - 1; k >= 0; k--) cb.free_slots.push_back(k);
+    cb.ready = true;
+    return true;
+}
+
+// one launch set for `batch` (all of one mode) on lane `lane`; fills every request's rc and output
+static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch) {
+    Combiner &cb = c->comb;
+    const size_t n = batch.size();
+    const int mode = batch[0]->mode;
+    const size_t lo = (size_t)lane * kCombineMaxBatch;  // this lane's slice of the workspace
+    hipStream_t sk = c->aux[lane];
+    C_KZG_RET rc = C_KZG_OK;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);  // enqueue only: the wait below happens outside
+        bool ok = hipSetDevice(c->device) == hipSuccess;
+        if (ok) {
+            rc = ctx_reserve(c, kCombineLanes * kCombineMaxBatch);
+            ok = rc == C_KZG_OK;
+        }
+        if (ok) {
+            WsLaneUse use(c, lane);
+            Workspace &w = c->ws;
+            uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
+            for (size_t i = 0; i < n && ok; i++)
+                ok = hipMemcpyAsync(d_blobs + i * (size_t)kBlobBytes, cb.pinned_blobs + (size_t)batch[i]->slot * kBlobBytes, kBlobBytes,
+                                    hipMemcpyHostToDevice, sk) == hipSuccess;
+            ok = ok && hipMemsetAsync(w.status + lo, 0, n * 4, sk) == hipSuccess;
+            if (ok) {
+                coefficients_stage(c, d_blobs, n, mode, w.status + lo, sk, lo);
+                msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, n, sk, lo);
+                ok = hipMemcpyAsync(cb.pinned_out[lane], w.out48 + 48 * lo, n * 48, hipMemcpyDeviceToHost, sk) == hipSuccess &&
+                     hipMemcpyAsync(cb.pinned_status[lane], w.status + lo, n * 4, hipMemcpyDeviceToHost, sk) == hipSuccess;
+            }
+        }
+        if (!ok && rc == C_KZG_OK) {
+            set_error("blob_to_kzg_commitment (coalesced): %s", hipGetErrorString(hipGetLastError()));
+            rc = C_KZG_ERROR;
+        }
+    }
+    if (rc == C_KZG_OK && hipStreamSynchronize(sk) != hipSuccess) {
+        set_error("blob_to_kzg_commitment (coalesced): %s", hipGetErrorString(hipGetLastError()));
+        rc = C_KZG_ERROR;
+    }
+    for (size_t i = 0; i < n; i++) {
+        CombineReq *r = batch[i];
+        if (rc != C_KZG_OK) {
+            r->rc = rc;
+        } else if (cb.pinned_status[lane][i] != 0) {
+            r->rc = map_rc((C_KZG_RET)cb.pinned_status[lane][i], mode);
+        } else {
+            memcpy(r->out48, cb.pinned_out[lane] + 48 * i, 48);
+            r->rc = C_KZG_OK;
+        }
+    }
+}
+
+// blob_to_kzg_commitment for one blob, merged with whatever other callers are waiting. Returns false when the front is
+// unavailable (no pinned memory): the caller then takes the plain path.
+static bool combine_commit(Ctx *c, uint8_t *out48, const uint8_t *blob, int mode, C_KZG_RET *rc_out) {
+    Combiner &cb = c->comb;
+    CombineReq req;
+    req.mode = mode;
+    req.out48 = out48;
+    std::unique_lock<std::mutex> lk(cb.m);
+    if (!combiner_init(c)) return false;
+    cb.cv.wait(lk, [&] { return !cb.free_slots.empty(); });
+    req.slot = cb.free_slots.back();
+    cb.free_slots.pop_back();
+    lk.unlock();
+    memcpy(cb.pinned_blobs + (size_t)req.slot * kBlobBytes, blob, kBlobBytes);  // every caller stages its own blob, in parallel
+    lk.lock();
+    cb.queue.push_back(&req);
+    for (;;) {
+        if (req.state == CombineReq::DONE) break;
+        if (req.state == CombineReq::QUEUED && cb.leaders < kCombineLanes) {
+            // lead: take every waiting request of this mode (this one included), up to one launch set
+            int lane = cb.lane_busy[0] ? 1 : 0;
+            cb.lane_busy[lane] = true;
+            cb.leaders++;
+            std::vector<CombineReq *> batch;
+            for (auto it = cb.queue.begin(); it != cb.queue.end() && batch.size() < kCombineMaxBatch;) {
+                if ((*it)->mode == mode) {
+                    (*it)->state = CombineReq::TAKEN;
+                    batch.push_back(*it);
+                    it = cb.queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lk.unlock();
+            combine_run(c, lane, batch);
+            lk.lock();
+            for (CombineReq *r : batch) {
+                r->state = CombineReq::DONE;
+                cb.free_slots.push_back(r->slot);
+            }
+            cb.lane_busy[lane] = false;
+            cb.leaders--;
+            cb.cv.notify_all();
+            continue;  // req is DONE now: it was part of its own batch
+        }
+        cb.cv.wait(lk);
+    }
+    *rc_out = req.rc;
+    return true;
+}
+
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s,
                                              size_t *first_bad) {
     const int mode = mode_now();
     if (!out || !blobs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    if (n == 1) {  // the reference's symbol: merged with the other callers of the moment
+        static const bool coalesce = !(getenv("LWKZG_COALESCE") && atoi(getenv("LWKZG_COALESCE")) == 0);
+        C_KZG_RET rc1;
+        uint8_t tmp[48];
+        if (coalesce && combine_commit(c, tmp, (const uint8_t *)blobs, mode, &rc1)) {
+            if (rc1 == C_KZG_OK) memcpy(out, tmp, 48);
+            else if (first_bad) *first_bad = 0;
+            if (rc1 != C_KZG_OK && !get_error()[0]) set_error("blob 0 rejected");
+            return rc1;
+        }
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     WsUse wsu(c, c->stream);

@@ -76,14 +76,16 @@ def _splitmix64(state):
     return state, z ^ (z >> 31)
 
 
-def synthetic_blob(index, big_endian=True):
+def synthetic_blob(index, big_endian=True, full_range=False):
     """Blob `index` of the bench workload: every element is 31 bytes of a SplitMix64 stream
     seeded 0x4B5A47 + index, with one zero byte at the most-significant end of the 32 bytes
     (offset 0 big-endian / offset 31 little-endian) so every element is canonical (< 2^248 < r).
     Same construction as the reference's fuzz corpus generator (fuzz/gen_corpus/main.go:16-29)."""
+    # full_range=True keeps all 32 random bytes: elements are then arbitrary 256-bit integers, which reference mode
+    # reduces mod r (utils.rs:27-41) and c-kzg mode would reject -- the stress workload for the MSM's top window
     try:
         import numpy as np
-        return _synthetic_blob_np(index, big_endian, np)
+        return _synthetic_blob_np(index, big_endian, np, full_range)
     except ImportError:
         pass
     st = (0x4B5A47 + index) & 0xFFFFFFFFFFFFFFFF
@@ -93,12 +95,13 @@ def synthetic_blob(index, big_endian=True):
         words.append(v)
     raw = struct.pack("<%dQ" % (N * 4), *words)
     out = bytearray(raw)
-    for n in range(N):
-        out[32 * n + (0 if big_endian else 31)] = 0
+    if not full_range:
+        for n in range(N):
+            out[32 * n + (0 if big_endian else 31)] = 0
     return bytes(out)
 
 
-def _synthetic_blob_np(index, big_endian, np):
+def _synthetic_blob_np(index, big_endian, np, full_range=False):
     n = N * 4
     with np.errstate(over="ignore"):
         st = np.uint64((0x4B5A47 + index) & 0xFFFFFFFFFFFFFFFF) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, n + 1, dtype=np.uint64)
@@ -107,12 +110,13 @@ def _synthetic_blob_np(index, big_endian, np):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     out = z.astype("<u8").view(np.uint8).reshape(N, 32).copy()
-    out[:, 0 if big_endian else 31] = 0
+    if not full_range:
+        out[:, 0 if big_endian else 31] = 0
     return out.tobytes()
 
 
-def synthetic_batch(first, count, big_endian=True):
-    return b"".join(synthetic_blob(first + i, big_endian) for i in range(count))
+def synthetic_batch(first, count, big_endian=True, full_range=False):
+    return b"".join(synthetic_blob(first + i, big_endian, full_range) for i in range(count))
 
 
 def blob_scalars(blob, big_endian=True):

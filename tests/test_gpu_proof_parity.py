@@ -121,3 +121,67 @@ def test_device_calls_on_two_user_streams_share_the_workspace_safely(K, gpu_setu
         torch.cuda.synchronize()
         assert _host(o_a) == want_a and _host(o_b) == want_b
         assert _host(p_b)[:48] == reference_mode_proof_closed_form(oracle, b[:B.BYTES_PER_BLOB], want_b[:48])
+
+
+@pytest.mark.parametrize("which", ["default", "bucket"])
+def test_sixteen_threads_on_the_reference_symbol_are_coalesced(K, gpu_setup, bucket_setup, oracle, oracle_setup, which):
+    """The reference's contract is lock-free concurrent calls on one KZGSettings (src/lib.rs:253-283, SURVEY 8b
+    "Threading"). Sixteen threads hammering blob_to_kzg_commitment -- one blob per call -- are merged into shared launch
+    sets by the library: every answer is the closed form's / the oracle's, and on the default engine the aggregate rate is
+    above the north star's 10k ops/s although no caller ever passes more than one blob."""
+    import threading
+    import time
+    ts = gpu_setup if which == "default" else bucket_setup
+    n_threads, per_thread = 16, 150
+    blobs = [B.synthetic_blob(90000 + i) for i in range(64)]
+    want = [tau_closed_form(oracle, B.blob_scalars(b)) for b in blobs]
+    for i in (0, 63):
+        assert oracle.blob_to_kzg_commitment(blobs[i], oracle_setup, oracle.MODE_R) == (0, want[i])
+    assert K.blob_to_kzg_commitment(blobs[0], ts) == want[0]          # warm: workspace, pinned staging
+    errors, done = [], []
+
+    def worker(t):
+        try:
+            for it in range(per_thread):
+                i = (t * 7 + it * 13) % 64
+                assert K.blob_to_kzg_commitment(blobs[i], ts) == want[i], (t, it, i)
+            done.append(t)
+        except Exception as e:      # pragma: no cover - reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    el = time.perf_counter() - t0
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert errors == [] and len(done) == n_threads
+    rate = n_threads * per_thread / el
+    print("coalesced single-blob calls, %s engine: %.0f ops/s from %d threads" % (which, rate, n_threads))
+    if which == "default":
+        assert rate >= 10000, rate
+    # an invalid blob among valid ones (c-kzg mode: non-canonical element) is rejected for its caller only
+    K.set_mode(K.MODE_CKZG)
+    good = B.synthetic_blob(91000, big_endian=False)
+    want_good = K.blob_to_kzg_commitment(good, ts)
+    res = {}
+
+    def mixed(t):
+        try:
+            if t % 4 == 0:
+                K.blob_to_kzg_commitment(B.make_blob("all_ff"), ts)
+                res[t] = "accepted"
+            else:
+                res[t] = K.blob_to_kzg_commitment(good, ts)
+        except K.KzgError as e:
+            res[t] = e.rc
+
+    threads = [threading.Thread(target=mixed, args=(t,)) for t in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for t in range(12):
+        assert res[t] == (K.C_KZG_BADARGS if t % 4 == 0 else want_good), (t, res[t])
