@@ -201,6 +201,12 @@ def main():
     ap.add_argument("--scalars", default="31byte", choices=["31byte", "full"],
                     help="31byte = the BASELINE workload (31 random bytes per element, SURVEY 8d); full = 32 random bytes per element, "
                          "reduced mod r by the parse kernel (reference mode only): every window of every scalar is busy")
+    ap.add_argument("--caller-streams", type=int, default=1,
+                    help="commit / blob_proof: consecutive steps alternate between this many caller streams (each with its own output "
+                         "buffer), as a pipelined producer would issue them; the library then overlaps the latency-shaped head of one "
+                         "call with the MSM of the other (engine.hip: pick_ctx). 1 = every step on one stream, strictly in series")
+    ap.add_argument("--idle-ms", type=float, default=0.0,
+                    help="experiment: the host synchronizes and sleeps this long before every step (is a kernel slower after an idle gap?)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
 
@@ -249,6 +255,11 @@ def main():
     d_comm = None
     ts.reserve(n)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    n_cs = max(1, args.caller_streams)
+    cstreams = [torch.cuda.Stream(device=dev) for _ in range(n_cs)] if n_cs > 1 else []
+    couts = [torch.empty(48 * n, dtype=torch.uint8, device=dev) for _ in range(n_cs)] if n_cs > 1 else []
+    cstats = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(n_cs)] if n_cs > 1 else []
+    step_no = [0]
 
     h_blobs = h_comms = h_proofs = None
     d_tiles = None
@@ -259,6 +270,14 @@ def main():
             D.msm_tiled_sharded(d_tiles, int(d_tiles.numel()) // 32, ts, dev)
         elif args.op == "verify_batch":   # ONE batch over all ranks: one transcript, one r, one pairing check (dist.py)
             assert D.verify_blob_kzg_proof_batch_sharded(h_blobs, h_comms, h_proofs, n, ts)
+        elif n_cs > 1:                    # step k on caller stream k mod N, into that stream's own output buffer
+            k = step_no[0] % n_cs
+            step_no[0] += 1
+            if args.op == "commit":
+                K.blob_to_kzg_commitment_batch_device(couts[k].data_ptr(), d_blobs.data_ptr(), n, ts, cstreams[k].cuda_stream, cstats[k].data_ptr())
+            else:
+                K.compute_blob_kzg_proof_batch_device(couts[k].data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts,
+                                                      cstreams[k].cuda_stream, cstats[k].data_ptr())
         elif args.op == "commit":
             K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
         else:
@@ -277,6 +296,9 @@ def main():
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
+            if args.idle_ms > 0:
+                torch.cuda.synchronize(dev)
+                time.sleep(args.idle_ms * 1e-3)
             step()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -289,6 +311,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         assert int(d_status.abs().sum().item()) == 0, "a blob was rejected"
+        for k in range(len(cstats)):
+            assert int(cstats[k].abs().sum().item()) == 0, "a blob was rejected"
+            if k > 0:
+                assert torch.equal(couts[k], couts[0]), "the caller streams disagree"
         return el, pr
 
     def engine_leg(bits, label):
@@ -427,7 +453,7 @@ def main():
                                                    "blobs in host memory (H2D inside the timed region)",
                                    "tiled_msm": "BASELINE configs[4]: one 2^20-term G1 MSM over the setup tiled 256 times, tiles split over "
                                                 "the GPUs, partial sums gathered and added on the host (%d is unused here)"}[args.op] % n,
-                       "blobs_per_gpu_per_step": n, "scalars": args.scalars, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
+                       "blobs_per_gpu_per_step": n, "caller_streams": n_cs, "scalars": args.scalars, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": roofline,
             "kernels": kernels,

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__
                                                     int per_blob) {
     const size_t b = blockIdx.x;
     const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(2);  // a short latency chain: it should not queue behind another call's MSM waves (engine.hip: pick_ctx)
     G1Xyzz29 s = lane < per_blob ? partials[b * per_blob + lane] : G1Xyzz29::infinity();
     s = wave_fold(s, lane);
     if (lane == 0) sums[b] = s;
@@ -287,10 +288,14 @@ __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__
 
 template <int CT>
 static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials,
-                            G1Xyzz29 *sums, size_t n_blobs, hipStream_t st) {
+                            G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
-    // 16 workgroups so the chip fills and the dependent chain per lane stays short
-    static const int kFill = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 512;
+    // 16 workgroups so the chip fills and the dependent chain per lane stays short. `fill` = the number of workgroups
+    // to aim for: 512 (two per compute unit, one round) when the kernel has the chip alone; 2048 when the settings
+    // object runs two overlapping pipelines (engine.hip: pick_ctx), where workgroups of a quarter of the length keep the
+    // tail short although another call's waves take compute-unit slots away (60k instead of 53k proofs/s at 256 blobs)
+    static const int kFillEnv = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 0;
+    const int kFill = kFillEnv ? kFillEnv : fill ? fill : 512;
     int blocks_per_blob = 1, wsplit = 1;
     while (blocks_per_blob < 16 && n_blobs * blocks_per_blob < (size_t)kFill) blocks_per_blob <<= 1;
     while (wsplit < 4 && n_blobs * blocks_per_blob * wsplit * 8 <= (size_t)kFill) wsplit <<= 1;  // only for a handful of blobs
@@ -308,14 +313,14 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, c
 }
 
 void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
-                       size_t n_blobs, hipStream_t st) {
+                       size_t n_blobs, hipStream_t st, int fill) {
     const DirectPlanRt plan = make_plan(bits);
     if (!plan.entries) return;
     switch (bits) {
-        case 14: launch_direct_t<14>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;
-        case 15: launch_direct_t<15>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;
-        case 16: launch_direct_t<16>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;
-        default: launch_direct_t<0>(plan, table, scalars_raw, partials, sums, n_blobs, st); break;  // 10 .. 13
+        case 14: launch_direct_t<14>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;
+        case 15: launch_direct_t<15>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;
+        case 16: launch_direct_t<16>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;
+        default: launch_direct_t<0>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;  // 10 .. 13
     }
 }
 

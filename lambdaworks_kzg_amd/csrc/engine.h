@@ -151,6 +151,17 @@ struct Ctx {
     hipStream_t ws_last;
     hipEvent_t lane_done[kCombineLanes];  // last use of a workspace half by a lane of the coalescing front
     Combiner comb;
+    // A second set of streams + workspace over the SAME tables (engine.hip: pick_ctx): device-resident calls that arrive
+    // on another caller stream while this context's workspace is still busy run there, so that the latency-shaped head
+    // of one call (Fiat-Shamir hash, commitment validation) overlaps the ALU-bound MSM of the other.
+    Ctx *twin = nullptr;
+    bool is_twin = false;
+    // Left alone, two proof pipelines that share the GPU fall into step (both hash, then both MSMs fight for the chip).
+    // The ALU-bound phase of a proof call therefore takes turns across the two contexts: it waits for this event (the
+    // previous call's phase, whichever context ran it) and records it again. Lives in the primary context.
+    Ctx *primary = nullptr;
+    hipEvent_t heavy_done = nullptr;
+    std::mutex heavy_mu;
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
     G1Affine29 *table;  // kTablePoints, hot-loop representation
     G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled

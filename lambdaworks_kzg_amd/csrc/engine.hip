@@ -211,9 +211,19 @@ static void ctx_destroy(Ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();  // every stream of the context, and the callers' streams that ran its work
+    if (c->twin) {
+        ctx_destroy(c->twin);
+        c->twin = nullptr;
+    }
     ws_free(c->ws);
     ws_long_free(c->ws);
     vs_free(c);
+    if (c->is_twin) {  // the tables belong to the context this one shadows
+        c->points = nullptr;
+        c->table = nullptr;
+        c->direct_table = nullptr;
+        c->tw_fwd = c->tw_inv = nullptr;
+    }
     dev_free(c->points);
     dev_free(c->table);
     dev_free(c->direct_table);
@@ -227,6 +237,7 @@ static void ctx_destroy(Ctx *c) {
     }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ws_done) hipEventDestroy(c->ws_done);
+    if (c->heavy_done) hipEventDestroy(c->heavy_done);
     for (int k = 0; k < kCombineLanes; k++) {
         if (c->lane_done[k]) hipEventDestroy(c->lane_done[k]);
         if (c->comb.pinned_out[k]) hipHostFree(c->comb.pinned_out[k]);
@@ -258,12 +269,14 @@ static void fr_raw_to_blst(blst_fr *o, const uint32_t raw[8]) {
     for (int k = 0; k < 4; k++) o->l[3 - k] = (uint64_t)raw[2 * k] | ((uint64_t)raw[2 * k + 1] << 32);
 }
 
-static C_KZG_RET ctx_new(Ctx **out) {
+static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
     if (!gpu_available()) return C_KZG_ERROR;
     Ctx *c = new Ctx();
     memset(&c->fs, 0, sizeof c->fs);
     c->magic = kCtxMagic;
-    c->device = g_default_device.load();
+    c->device = twin_of ? twin_of->device : g_default_device.load();
+    c->is_twin = twin_of != nullptr;
+    c->primary = twin_of ? const_cast<Ctx *>(twin_of) : c;
     c->stream = nullptr;
     c->ws_done = nullptr;
     c->ws_last = nullptr;
@@ -289,26 +302,56 @@ static C_KZG_RET ctx_new(Ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->vstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws_done, hipEventDisableTiming);
+    if (e == hipSuccess && !twin_of) e = hipEventCreateWithFlags(&c->heavy_done, hipEventDisableTiming);
     for (int k = 0; k < kCombineLanes && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming);
     for (int k = 0; k < kMaxSplit && e == hipSuccess; k++) {
         e = hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&c->points, (size_t)kBlobElems * sizeof(G1Affine));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine29));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->tw_inv, (size_t)(kBlobElems / 2) * sizeof(Fr));
+    if (twin_of) {  // same read-only tables, own streams / events / workspace / locks
+        c->points = twin_of->points;
+        c->table = twin_of->table;
+        c->direct_table = twin_of->direct_table;
+        c->direct_bits = twin_of->direct_bits;
+        c->tw_fwd = twin_of->tw_fwd;
+        c->tw_inv = twin_of->tw_inv;
+    } else {
+        if (e == hipSuccess) e = hipMalloc((void **)&c->points, (size_t)kBlobElems * sizeof(G1Affine));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine29));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->tw_inv, (size_t)(kBlobElems / 2) * sizeof(Fr));
+    }
     if (e != hipSuccess) {
         set_error("device context allocation failed: %s", hipGetErrorString(e));
         ctx_destroy(c);
         return C_KZG_MALLOC;
     }
-    {
+    if (!twin_of) {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         g_live_fs.insert((const void *)c);
     }
     *out = c;
     return C_KZG_OK;
+}
+
+// Which of the settings' two contexts a device-resident call on caller stream `st` runs on. The engine's own stream and
+// a stream that used this context last stay here (stream order is all the synchronisation they need); a call on another
+// stream goes to the twin while this context's workspace is still busy, so that the two calls overlap on the GPU.
+static Ctx *pick_ctx(Ctx *c, hipStream_t st) {
+    static const bool off = getenv("LWKZG_TWIN") && atoi(getenv("LWKZG_TWIN")) == 0;
+    if (off || !st || st == c->stream) return c;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->ws_last == st || c->ws_last == nullptr || hipEventQuery(c->ws_done) == hipSuccess) {
+        (void)hipGetLastError();
+        return c;
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is an answer
+    if (!c->twin) {
+        Ctx *t = nullptr;
+        if (ctx_new(&t, c) != C_KZG_OK) return c;
+        c->twin = t;
+    }
+    return c->twin;
 }
 
 // twiddles on device + the genuine FFTSettings tables on the host
@@ -403,6 +446,7 @@ Ctx *ctx_of(const KZGSettings *s) {
         ctx_destroy(c);
         return nullptr;
     }
+    bool ours = true;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         auto it = g_registry.find(s->g1_values);
@@ -412,6 +456,7 @@ Ctx *ctx_of(const KZGSettings *s) {
                 // (ctx_destroy takes g_reg_mu itself)
                 stale = c;
                 c = first;
+                ours = false;
             } else {
                 stale = first;
                 it->second = {c, digest};
@@ -422,6 +467,7 @@ Ctx *ctx_of(const KZGSettings *s) {
         }
     }
     if (stale) ctx_destroy(stale);
+    if (ours) direct_from_env(s);  // a context of our own making: it gets the engine a loaded setup would get
     return c;
 }
 
@@ -438,7 +484,7 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
     G1Xyzz29 *sums = w.sums + base;
     if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
-        launch_direct_msm(c->direct_bits, c->direct_table, scalars_raw, buckets, sums, n, st);
+        launch_direct_msm(c->direct_bits, c->direct_table, scalars_raw, buckets, sums, n, st, c->primary->twin ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
@@ -560,14 +606,39 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
     LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
     launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
     LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
+    {   // experiment: LWKZG_KEEPWARM="blocks,iters" spins that many workgroups beside the hash (see fr_ops.hip)
+        static const char *kw = getenv("LWKZG_KEEPWARM");
+        if (kw) {
+            int blocks = 512, iters = 200000;
+            sscanf(kw, "%d,%d", &blocks, &iters);
+            LWK_HIP(hipStreamWaitEvent(c->aux[2], c->ev_fork, 0));
+            launch_keepwarm((uint32_t *)w.status_long ? (uint32_t *)w.status_long : (uint32_t *)w.status, blocks, iters, c->aux[2]);
+        }
+    }
     launch_challenge(blobs, comm48, z, le, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
     launch_challenge(blobs, canon, z, le, n, st, comm48);
+    // the ALU-bound phase: in turns with the settings' other context (engine.h: heavy_done), so that THIS call's hash
+    // above ran beside the other call's MSM and the other call's next hash runs beside this one
+    Ctx *pr = c->primary;
+    // (up to half a chunk: there the MSM is about as long as the hash and the two pipelines would phase-lock; a longer
+    // MSM covers the other call's hash by itself, and taking turns only adds bubbles -- 81k against 90k proofs/s at 1024)
+    static const int hs_env = getenv("LWKZG_HEAVY_SERIAL") ? atoi(getenv("LWKZG_HEAVY_SERIAL")) : -1;
+    const bool heavy_serial = hs_env >= 0 ? hs_env != 0 : n <= kMaxChunk / 2;
+    if (heavy_serial) {
+        std::lock_guard<std::mutex> hk(pr->heavy_mu);
+        LWK_HIP(hipStreamWaitEvent(st, pr->heavy_done, 0));
+    }
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt + off, st);
         launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
-        msm_stages(c, w.scalars2, out48 + 48 * off, m, st);
+        G1Xyzz29 *sums = msm_sums_stage(c, w.scalars2, m, st);
+        if (heavy_serial && off + kMaxChunk >= n) {  // the last accumulation is in the queue: the other context's phase may follow it
+            std::lock_guard<std::mutex> hk(pr->heavy_mu);
+            LWK_HIP(hipEventRecord(pr->heavy_done, st));
+        }
+        launch_finalize_compress(sums, out48 + 48 * off, m, st);
     }
     return C_KZG_OK;
 }
@@ -1783,6 +1854,10 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
     const int old_bits = c->direct_bits;
     dev_free(c->direct_table);  // (the old and the new table need not fit side by side)
     c->direct_bits = 0;
+    if (c->twin) {
+        c->twin->direct_table = nullptr;
+        c->twin->direct_bits = 0;
+    }
     if (window_bits == 0) return C_KZG_OK;
     auto build = [&](int bits) -> hipError_t {
         G1Affine29 *t = nullptr;
@@ -1797,6 +1872,10 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
         }
         c->direct_table = t;
         c->direct_bits = bits;
+        if (c->twin) {
+            c->twin->direct_table = t;
+            c->twin->direct_bits = bits;
+        }
         return hipSuccess;
     };
     const hipError_t e = build(window_bits);
@@ -1820,6 +1899,7 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void 
                                                     void *stream, int32_t *status_dev) {
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    c = pick_ctx(c, (hipStream_t)stream);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -1831,6 +1911,7 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void 
                                                     size_t n, const KZGSettings *s, void *stream, int32_t *status_dev) {
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    c = pick_ctx(c, (hipStream_t)stream);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;

@@ -43,9 +43,10 @@ constexpr int kDirectMinBits = 10, kDirectMaxBits = 16;
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
 hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st);
-// sums[b] = sum_i scalars[b][i] * P_i. `partials` needs 16 * n_blobs entries when n_blobs < 1024 (unused otherwise).
+// sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused otherwise).
+// fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
 void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
-                       size_t n_blobs, hipStream_t st);
+                       size_t n_blobs, hipStream_t st, int fill = 0);
 
 // ---- setup (setup.hip)
 // 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check
@@ -78,6 +79,8 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
                           size_t n_blobs, hipStream_t st);
 // z bytes -> Montgomery. le = 0: big-endian, reduced. le = 1: little-endian, must be canonical else BADARGS.
 void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, int le, size_t n, hipStream_t st);
+
+void launch_keepwarm(uint32_t *sink, int blocks, int iters, hipStream_t st);  // experiment, see fr_ops.hip
 
 // ---- Fiat-Shamir (sha256.hip)
 // validate + canonicalise commitments (decompress incl. subgroup check, recompress), then

@@ -420,6 +420,7 @@ __global__ __launch_bounds__(64) void k_finalize_compress(const G1Xyzz29 *__rest
                                                           size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    __builtin_amdgcn_s_setprio(2);  // one inversion per lane, a pure latency chain at the end of every call (see k_direct_fold)
     uint8_t b[48];
     g1_compress(b, sums[i]);
     uint32_t *o = (uint32_t *)(out48 + 48 * i);

@@ -223,12 +223,15 @@ __global__ __launch_bounds__(128) void k_challenge(const uint8_t *__restrict__ b
 
 __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
                                                          Fr *__restrict__ z_mont, int le, size_t n,
-                                                         const uint8_t *__restrict__ only_if_differs_from) {
+                                                         const uint8_t *__restrict__ only_if_differs_from, int prio) {
     // waves 0, 1: producers (all 64 blobs each; wave 0 expands the even blocks, wave 1 the odd ones, half a block
     // per barrier interval, so a block has two intervals to get ready); waves 2, 3: consumers (32 blobs each, two
     // lanes per blob). Block b is written in intervals b and b + 1 and read in interval b + 2: three LDS buffers.
     __shared__ uint4 wk[3][16][64];
     __shared__ uint4 zero4;  // what the a halves read in place of W + K
+    // a latency chain of a few dozen waves: where one of them shares a SIMD with the throughput-bound MSM waves of
+    // another call (engine.hip: pick_ctx), it should issue whenever it can -- the MSM fills the gaps
+    if (prio) __builtin_amdgcn_s_setprio(2);
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const bool producer = role < 2;
     const bool a_half = !producer && ((lane >> 3) & 1);
@@ -350,10 +353,11 @@ void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, 
                       const uint8_t *only_if_differs_from) {
     if (n == 0) return;
     static const bool pairs = !(getenv("LWKZG_HASH_PAIRS") && atoi(getenv("LWKZG_HASH_PAIRS")) == 0);
+    static const int prio = getenv("LWKZG_HASH_PRIO") ? atoi(getenv("LWKZG_HASH_PRIO")) : 1;
     ProfScope p(only_if_differs_from ? "k_challenge_fixup" : "k_challenge", st);
     if (pairs)
         hipLaunchKernelGGL(k_challenge_pairs, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, canon48, z_mont, le, n,
-                           only_if_differs_from);
+                           only_if_differs_from, prio);
     else
         hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st, blobs, canon48, z_mont, le, n,
                            only_if_differs_from);
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
                                                              int32_t *__restrict__ kind_out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    __builtin_amdgcn_s_setprio(2);  // a latency chain, like the hash kernel it runs beside (see there)
     G1Affine29 aff;
     aff.x = F29<2>::zero();
     aff.y = F29<2>::zero();

@@ -72,6 +72,31 @@ def test_hand_built_settings_without_context(K, gpu_setup, oracle, oracle_setup)
     assert out.raw == oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_R)[1]
 
 
+def test_hand_built_settings_rebuilt_in_place_get_a_fresh_context(K, gpu_setup, oracle_setup):
+    """the context cached for a hand-built KZGSettings is keyed by the g1_values pointer AND a digest of its first and
+    last point: a caller that rewrites the array in place (here: first and last setup point exchanged) must not get the
+    stale table. A genuine 32-byte FFTSettings behind fs (another producer's) is never dereferenced past its end."""
+    g1 = bytearray(oracle_setup.g1_blst())
+    buf = (C.c_uint8 * len(g1)).from_buffer(g1)
+    fs_foreign = (C.c_uint64 * 4)(4096, 0, 0, 0)            # a c-kzg style FFTSettings that is not ours: exactly 32 bytes
+    s = K.KZGSettings()
+    s.fs, s.g1_values, s.g2_values = C.cast(fs_foreign, C.c_void_p), C.cast(buf, C.c_void_p), gpu_setup.s.g2_values
+    one = (1).to_bytes(32, "big")
+    blob_first = one + bytes(B.BYTES_PER_BLOB - 32)          # p(x) = 1        -> commitment = g1[0]
+    blob_last = bytes(B.BYTES_PER_BLOB - 32) + one           # p(x) = x^4095   -> commitment = g1[4095]
+    comp = oracle_setup.g1_compressed()
+    out = C.create_string_buffer(48)
+    assert K.lib().blob_to_kzg_commitment(out, blob_first, C.byref(s)) == K.C_KZG_OK and out.raw == comp[:48]
+    assert K.lib().blob_to_kzg_commitment(out, blob_last, C.byref(s)) == K.C_KZG_OK and out.raw == comp[48 * 4095:]
+    g1[:144], g1[144 * 4095:] = bytes(g1[144 * 4095:]), bytes(g1[:144])      # same address, other contents
+    assert K.lib().blob_to_kzg_commitment(out, blob_first, C.byref(s)) == K.C_KZG_OK and out.raw == comp[48 * 4095:]
+    assert K.lib().blob_to_kzg_commitment(out, blob_last, C.byref(s)) == K.C_KZG_OK and out.raw == comp[:48]
+    # releasing the hand-built settings through the library would free() caller memory: drop the cached context by
+    # restoring the contents instead (the registry entry is replaced again) -- the arrays stay the caller's
+    g1[:144], g1[144 * 4095:] = bytes(g1[144 * 4095:]), bytes(g1[:144])
+    assert K.lib().blob_to_kzg_commitment(out, blob_first, C.byref(s)) == K.C_KZG_OK and out.raw == comp[:48]
+
+
 # ---- stage level: NTT, MSM -------------------------------------------------------------------------
 
 def test_ntt_kernel_vs_oracle(K, gpu_setup, oracle):

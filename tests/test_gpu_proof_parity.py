@@ -97,30 +97,44 @@ def test_device_resident_proof_call_longer_than_one_chunk(K, engine_setup, oracl
     assert _host(d_out) == proofs
 
 
-def test_device_calls_on_two_user_streams_share_the_workspace_safely(K, gpu_setup, oracle):
-    """Two device-resident calls in flight on two different caller streams used to race on the per-settings workspace;
-    the library now chains them by events. Both results must be the single-stream ones, repeatedly."""
+def test_device_calls_on_two_caller_streams_overlap_safely(K, oracle):
+    """Two device-resident calls in flight on two different caller streams: the first runs on the settings' context, the
+    second -- arriving while that workspace is busy -- on its twin (own streams and workspace, same tables), so that the
+    hash of one overlaps the MSM of the other; a third call on the first stream chains behind the first by events. All
+    results must be the single-stream ones, repeatedly, and across an engine switch and the final free."""
     import torch
+    from conftest import SETUP_PATH
+    ts = K.TrustedSetup.from_file(SETUP_PATH)
     n = 96
     a, b = B.synthetic_batch(50000, n), B.synthetic_batch(51000, n)
     d_a, d_b = _dev(a), _dev(b)
-    want_a = b"".join(K.blob_to_kzg_commitment_batch(a, gpu_setup))
-    want_b = b"".join(K.blob_to_kzg_commitment_batch(b, gpu_setup))
-    assert want_a[:48] == tau_closed_form(oracle, B.blob_scalars(a[:B.BYTES_PER_BLOB]))
+    want_a = b"".join(K.blob_to_kzg_commitment_batch(a, ts))
+    want_b = b"".join(K.blob_to_kzg_commitment_batch(b, ts))
+    for i in (0, n - 1):
+        assert want_a[48 * i:48 * i + 48] == tau_closed_form(oracle, B.blob_scalars(a[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]))
+    want_pa = [reference_mode_proof_closed_form(oracle, a[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB], want_a[48 * i:48 * i + 48]) for i in range(n)]
+    want_pb = [reference_mode_proof_closed_form(oracle, b[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB], want_b[48 * i:48 * i + 48]) for i in range(n)]
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
-    for _ in range(8):
-        o_a = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
-        o_b = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
-        p_b = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        K.blob_to_kzg_commitment_batch_device(o_a.data_ptr(), d_a.data_ptr(), n, gpu_setup, s1.cuda_stream, None)
-        K.blob_to_kzg_commitment_batch_device(o_b.data_ptr(), d_b.data_ptr(), n, gpu_setup, s2.cuda_stream, None)
-        s2.synchronize()
-        K.compute_blob_kzg_proof_batch_device(p_b.data_ptr(), d_b.data_ptr(), o_b.data_ptr(), n, gpu_setup, s1.cuda_stream, None)
-        torch.cuda.synchronize()
-        assert _host(o_a) == want_a and _host(o_b) == want_b
-        assert _host(p_b)[:48] == reference_mode_proof_closed_form(oracle, b[:B.BYTES_PER_BLOB], want_b[:48])
+    for engine in (None, 12, 0):
+        if engine is not None:
+            ts.enable_direct_table(engine)      # with the twin alive: both contexts must see the new table
+        for _ in range(4):
+            o_a = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+            o_b = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+            p_a = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+            p_b = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            K.blob_to_kzg_commitment_batch_device(o_a.data_ptr(), d_a.data_ptr(), n, ts, s1.cuda_stream, None)
+            K.blob_to_kzg_commitment_batch_device(o_b.data_ptr(), d_b.data_ptr(), n, ts, s2.cuda_stream, None)
+            K.compute_blob_kzg_proof_batch_device(p_a.data_ptr(), d_a.data_ptr(), o_a.data_ptr(), n, ts, s1.cuda_stream, None)
+            K.compute_blob_kzg_proof_batch_device(p_b.data_ptr(), d_b.data_ptr(), o_b.data_ptr(), n, ts, s2.cuda_stream, None)
+            s2.synchronize()
+            K.compute_blob_kzg_proof_batch_device(p_b.data_ptr(), d_b.data_ptr(), o_b.data_ptr(), n, ts, s1.cuda_stream, None)   # crosses streams
+            torch.cuda.synchronize()
+            assert _host(o_a) == want_a and _host(o_b) == want_b
+            assert _host(p_a) == b"".join(want_pa) and _host(p_b) == b"".join(want_pb)
+    ts.free()
 
 
 @pytest.mark.parametrize("which", ["default", "bucket"])

@@ -1,21 +1,41 @@
+# Collects the round's measurement artifacts on the GPU box (one gpurun call); tools/publish_profiles.sh copies the
+# summaries into profiles/. Counters are collected in their own rocprofv3 runs (--pmc only), never with trace flags.
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01b
-mkdir -p $O
+O=$R/gpurun_out/final
+rm -rf $O; mkdir -p $O
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench_err.txt
-python bench.py --direct-bits 0 --no-cpu-baseline > $O/bench_line_bucket_path.json 2>> $O/bench_err.txt
-python bench.py --mode ckzg --no-cpu-baseline > $O/bench_line_ckzg_mode.json 2>> $O/bench_err.txt
+python bench.py --scalars full --no-cpu-baseline --no-extra-legs > $O/bench_line_full_range_scalars.json 2>> $O/bench_err.txt
+python bench.py --mode ckzg --no-cpu-baseline --no-extra-legs > $O/bench_line_ckzg_mode.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 256 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 1024 --no-cpu-baseline > $O/bench_line_blob_proof_b1024.json 2>> $O/bench_err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_line.json 2> $O/kt_err.txt
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch_line.json 2> $O/fetch_err.txt
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write_line.json 2> $O/write_err.txt
+python bench.py --op blob_proof --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_blob_proof_b4096.json 2>> $O/bench_err.txt
+python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_verify_batch_b4096.json 2>> $O/bench_err.txt
+python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
+# per-kernel time of the headline command, of the default engine and of the bucket engine
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_line.json 2> $O/kt_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --direct-bits default > $O/kt_default_line.json 2> $O/kt_default_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bucket -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --direct-bits 0 > $O/kt_bucket_line.json 2> $O/kt_bucket_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_proof -o kt -- python3 bench.py --op blob_proof --batch 1024 --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_proof_line.json 2> $O/kt_proof_err.txt
+# HBM-side traffic: FETCH_SIZE and WRITE_SIZE in separate passes, headline engine and bucket engine
+P="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- $P > $O/fetch_line.json 2> $O/fetch_err.txt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- $P > $O/write_line.json 2> $O/write_err.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_bucket -o fetch -- $P --direct-bits 0 > $O/fetch_bucket_line.json 2> $O/fetch_bucket_err.txt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_bucket -o write -- $P --direct-bits 0 > $O/write_bucket_line.json 2> $O/write_bucket_err.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_default -o fetch -- $P --direct-bits default > $O/fetch_default_line.json 2> $O/fetch_default_err.txt
+# issue-side counters of the headline kernel (SQ: 8 slots per pass; GRBM apart)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_sq1 -o sq -- $P > $O/pmc_sq1_line.json 2> $O/pmc_sq1_err.txt
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq2 -o sq -- $P > $O/pmc_sq2_line.json 2> $O/pmc_sq2_err.txt
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d $O/pmc_sq3 -o sq -- $P > $O/pmc_sq3_line.json 2> $O/pmc_sq3_err.txt
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/pmc_grbm -o grbm -- $P > $O/pmc_grbm_line.json 2> $O/pmc_grbm_err.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_bucket -o sq -- $P --direct-bits 0 > $O/pmc_sq_bucket_line.json 2> $O/pmc_sq_bucket_err.txt
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm_bucket -o grbm -- $P --direct-bits 0 > $O/pmc_grbm_bucket_line.json 2> $O/pmc_grbm_bucket_err.txt
 python tools/host_api_timing.py > $O/host_api_timing.txt 2>&1
 python tools/config_sweep.py --direct-bits 16 > $O/config_sweep_direct16.json 2> $O/sweep_err.txt
+python tools/config_sweep.py --direct-bits default > $O/config_sweep_default.json 2>> $O/sweep_err.txt
 python tools/config_sweep.py --direct-bits 0 --max-verify 1024 > $O/config_sweep_bucket.json 2>> $O/sweep_err.txt
-python tools/verify_timing.py > $O/verify_timing.txt 2>&1
-LWKZG_DIRECT=16 python tools/host_api_timing.py > $O/host_api_timing_direct.txt 2>&1
-find $O -name "*.csv" | head -30
+find $O -name "*.csv" | wc -l
 du -sh $O

@@ -36,7 +36,7 @@ def median_ms(fn, sync, warm=3, runs=11):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--direct-bits", type=int, default=16)
+    ap.add_argument("--direct-bits", default="16", help="10..16 = that direct table, 0 = bucket engine, default = what the load selected")
     ap.add_argument("--max-verify", type=int, default=4096)
     args = ap.parse_args()
     import torch
@@ -46,8 +46,9 @@ def main():
 
     ts = K.TrustedSetup.from_file(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"))
     ts.reserve(1024)
-    if args.direct_bits:
-        ts.enable_direct_table(args.direct_bits)
+    if args.direct_bits != "default":
+        ts.enable_direct_table(int(args.direct_bits))
+    args.direct_bits = ts.direct_table_bits()
     sync = torch.cuda.synchronize
     out = {"direct_bits": args.direct_bits, "device": torch.cuda.get_device_name(0), "commit": [], "blob_proof": [],
            "verify_batch": [], "tiled_msm": None}

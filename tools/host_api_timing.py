@@ -4,6 +4,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests/golden')
 import blobs as B
 import lambdaworks_kzg_amd as K
 ts = K.TrustedSetup.from_file('tests/golden/trusted_setup.txt')
+print('engine after load: direct_bits = %d' % ts.direct_table_bits())
 if os.environ.get('LWKZG_DIRECT'):
     ts.reserve(256)
     t = time.perf_counter(); ts.enable_direct_table(int(os.environ['LWKZG_DIRECT']))
