@@ -142,6 +142,12 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
 int lwkzg_set_mode(int mode); /* returns the previous mode, or -1 if `mode` is invalid */
 int lwkzg_get_mode(void);
 
+/* For a KZGSettings filled in by hand (fs == NULL and caller-owned g1_values / g2_values, the reference's own layout,
+ * src/lib.rs:754-758): the library builds a device context for it on first use and caches it by the g1_values pointer
+ * (re-checked against a digest of the first and last point). free_trusted_setup() would free() the caller's arrays; this
+ * releases only the cached device context. C_KZG_BADARGS for a setup the library loaded itself. */
+C_KZG_RET lwkzg_release_context(const KZGSettings *s);
+
 /* Batched host-pointer forms of src/lib.rs:253 / :361 / :300: n blobs in, n results out, one launch
  * set. On failure nothing useful is in `out`; `first_bad` (may be NULL) receives the index of the
  * first offending blob. */

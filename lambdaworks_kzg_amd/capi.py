@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows",
     "lwkzg_compute_challenges_device",
-    "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
+    "lwkzg_release_context", "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
 ]
 
 _lib = None
@@ -88,6 +88,7 @@ def lib():
     l.lwkzg_verify_shard_free.argtypes = [vp]
     l.lwkzg_verify_shard_free.restype = None
     l.lwkzg_verify_shards_finish.argtypes = [C.POINTER(C.c_bool), C.c_char_p, sz, sz, ps]
+    l.lwkzg_release_context.argtypes = [ps]
     l.lwkzg_reserve.argtypes = [ps, sz]
     l.lwkzg_enable_direct_table.argtypes = [ps, ci]
     l.lwkzg_direct_table_bits.argtypes = [ps]

@@ -1284,6 +1284,24 @@ C_KZG_RET free_trusted_setup(KZGSettings *s) {
     return C_KZG_OK;
 }
 
+// A KZGSettings filled in by hand (fs == NULL, caller-owned arrays: the reference's own layout) gets a device context
+// on first use, cached by its g1_values pointer. free_trusted_setup would free() the caller's arrays; this drops only
+// the cached context (tables, workspace, streams). The settings stay usable: the next call builds a new one.
+C_KZG_RET lwkzg_release_context(const KZGSettings *s) {
+    if (!s) return C_KZG_BADARGS;
+    Ctx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (s->fs && g_live_fs.count((const void *)s->fs)) return C_KZG_BADARGS;  // a loaded setup: free_trusted_setup owns it
+        auto it = g_registry.find(s->g1_values);
+        if (it == g_registry.end()) return C_KZG_OK;
+        c = it->second.ctx;
+        g_registry.erase(it);
+    }
+    ctx_destroy(c);
+    return C_KZG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-pointer entry points
 

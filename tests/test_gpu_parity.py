@@ -70,6 +70,12 @@ def test_hand_built_settings_without_context(K, gpu_setup, oracle, oracle_setup)
     out = C.create_string_buffer(48)
     assert K.lib().blob_to_kzg_commitment(out, blob, C.byref(s)) == K.C_KZG_OK
     assert out.raw == oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_R)[1]
+    assert K.lib().lwkzg_direct_table_bits(C.byref(s)) == gpu_setup.default_bits     # the engine a loaded setup would get
+    assert K.lib().lwkzg_release_context(C.byref(s)) == K.C_KZG_OK                     # the arrays stay the caller's
+    assert K.lib().lwkzg_release_context(gpu_setup.ref()) == K.C_KZG_BADARGS           # a loaded setup is freed, not released
+    assert K.lib().blob_to_kzg_commitment(out, blob, C.byref(s)) == K.C_KZG_OK         # still usable: a new context is built
+    assert out.raw == oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_R)[1]
+    assert K.lib().lwkzg_release_context(C.byref(s)) == K.C_KZG_OK
 
 
 def test_hand_built_settings_rebuilt_in_place_get_a_fresh_context(K, gpu_setup, oracle_setup):
@@ -91,10 +97,7 @@ def test_hand_built_settings_rebuilt_in_place_get_a_fresh_context(K, gpu_setup, 
     g1[:144], g1[144 * 4095:] = bytes(g1[144 * 4095:]), bytes(g1[:144])      # same address, other contents
     assert K.lib().blob_to_kzg_commitment(out, blob_first, C.byref(s)) == K.C_KZG_OK and out.raw == comp[48 * 4095:]
     assert K.lib().blob_to_kzg_commitment(out, blob_last, C.byref(s)) == K.C_KZG_OK and out.raw == comp[:48]
-    # releasing the hand-built settings through the library would free() caller memory: drop the cached context by
-    # restoring the contents instead (the registry entry is replaced again) -- the arrays stay the caller's
-    g1[:144], g1[144 * 4095:] = bytes(g1[144 * 4095:]), bytes(g1[:144])
-    assert K.lib().blob_to_kzg_commitment(out, blob_first, C.byref(s)) == K.C_KZG_OK and out.raw == comp[:48]
+    assert K.lib().lwkzg_release_context(C.byref(s)) == K.C_KZG_OK      # (free_trusted_setup would free() the caller's arrays)
 
 
 # ---- stage level: NTT, MSM -------------------------------------------------------------------------
@@ -662,7 +665,11 @@ def direct_setup(request, K, gpu_setup, bucket_setup):
         if wide:
             gpu_setup.enable_direct_table(gpu_setup.default_bits)
         assert e.rc == K.C_KZG_MALLOC
-        pytest.skip("direct table of width %d does not fit on this device" % request.param)
+        from lambdaworks_kzg_amd import capi
+        free_b = torch.cuda.mem_get_info()[0]
+        # on a device with room for it, "does not fit" is a leak somewhere in this suite, not a reason to skip
+        assert free_b < capi.direct_table_bytes(request.param) + (12 << 30), (request.param, free_b)
+        pytest.skip("direct table of width %d does not fit on this device (%d GB free)" % (request.param, free_b >> 30))
     assert ts.direct_table_bits() == request.param
     yield ts, request.param
     ts.enable_direct_table(0)

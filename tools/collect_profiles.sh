@@ -12,6 +12,8 @@ python bench.py --mode ckzg --no-cpu-baseline --no-extra-legs > $O/bench_line_ck
 python bench.py --op blob_proof --batch 256 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 1024 --no-cpu-baseline > $O/bench_line_blob_proof_b1024.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_blob_proof_b4096.json 2>> $O/bench_err.txt
+python bench.py --op blob_proof --batch 256 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b256_two_streams.json 2>> $O/bench_err.txt
+python bench.py --op blob_proof --batch 1024 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b1024_two_streams.json 2>> $O/bench_err.txt
 python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_verify_batch_b4096.json 2>> $O/bench_err.txt
 python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
 # per-kernel time of the headline command, of the default engine and of the bucket engine
@@ -19,6 +21,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 b
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --direct-bits default > $O/kt_default_line.json 2> $O/kt_default_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bucket -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --direct-bits 0 > $O/kt_bucket_line.json 2> $O/kt_bucket_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_proof -o kt -- python3 bench.py --op blob_proof --batch 1024 --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_proof_line.json 2> $O/kt_proof_err.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/kt_two_streams -o kt -- python3 bench.py --op blob_proof --batch 256 --caller-streams 2 --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_two_streams_line.json 2> $O/kt_two_streams_err.txt
+LWKZG_HEAVY_SERIAL=0 LWKZG_HASH_PRIO=0 LWKZG_DIRECT_FILL=512 rocprofv3 --kernel-trace --output-format csv -d $O/kt_two_streams_untuned -o kt -- python3 bench.py --op blob_proof --batch 256 --caller-streams 2 --steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_two_streams_untuned_line.json 2> $O/kt_two_streams_untuned_err.txt
 # HBM-side traffic: FETCH_SIZE and WRITE_SIZE in separate passes, headline engine and bucket engine
 P="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- $P > $O/fetch_line.json 2> $O/fetch_err.txt

@@ -1,21 +1,48 @@
 #!/bin/bash
-# Copies what tools/collect_profiles.sh left under gpurun_out/r01b into profiles/ (tracked), keeping only our kernels' rows.
+# Copies what tools/collect_profiles.sh left under gpurun_out/final into profiles/ (tracked), keeping only our kernels' rows.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/r01b; P=profiles; TAG=${1:-r01}
-for f in bench_line bench_line_bucket_path bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024; do tail -1 $O/$f.json > $P/${TAG}_$f.json; done
-cp $O/config_sweep_direct16.json $P/${TAG}_config_sweep_direct16.json; cp $O/config_sweep_bucket.json $P/${TAG}_config_sweep_bucket.json
-grep -v "amdgpu.ids" $O/verify_timing.txt > $P/${TAG}_verify_timing.txt
+O=gpurun_out/final; P=profiles; TAG=${1:-r02}
+for f in bench_line bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
+         bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_verify_batch_b4096 bench_line_tiled_msm; do
+  [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${TAG}_$f.json
+done
+for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
+grep -v "amdgpu.ids" $O/host_api_timing.txt > $P/${TAG}_host_api_timing.txt || true
 python3 - "$TAG" <<'PY'
-import csv, sys
+import csv, glob, os, sys
 tag = sys.argv[1]
-rows = list(csv.reader(open('gpurun_out/r01b/kt/kt_kernel_stats.csv')))
-out = [rows[0]] + [r for r in rows[1:] if 'lwk::' in r[0] or 'rocclr' in r[0]]
-csv.writer(open('profiles/%s_bench_kernel_stats.csv' % tag, 'w'), quoting=csv.QUOTE_ALL).writerows(out)
-for t in ('fetch', 'write'):
-    rows = list(csv.reader(open('gpurun_out/r01b/%s/%s_counter_collection.csv' % (t, t))))
-    keep = [rows[0]] + [r for r in rows[1:] if 'lwk::' in r[8]]
-    csv.writer(open('profiles/%s_pmc_%s_size.csv' % (tag, t), 'w'), quoting=csv.QUOTE_ALL).writerows(keep)
+O = 'gpurun_out/final'
+def ours(rows, col):
+    return [rows[0]] + [r for r in rows[1:] if 'lwk::' in r[col] or 'rocclr' in r[col]]
+for d, name in (('kt', 'bench_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats')):
+    f = '%s/%s/kt_kernel_stats.csv' % (O, d)
+    if os.path.exists(f):
+        rows = list(csv.reader(open(f)))
+        csv.writer(open('profiles/%s_%s.csv' % (tag, name), 'w'), quoting=csv.QUOTE_ALL).writerows(ours(rows, 0))
+# PMC passes: one file per engine, all counters of our kernels
+def pmc(dirs, out):
+    hdr, keep = None, []
+    for d in dirs:
+        for f in glob.glob('%s/%s/*_counter_collection.csv' % (O, d)):
+            rows = list(csv.reader(open(f)))
+            hdr = rows[0]
+            ki = hdr.index('Kernel_Name')
+            keep += [r for r in rows[1:] if 'lwk::' in r[ki]]
+    if hdr:
+        csv.writer(open(out, 'w'), quoting=csv.QUOTE_ALL).writerows([hdr] + keep)
+pmc(['pmc_sq1', 'pmc_sq2', 'pmc_sq3', 'pmc_grbm'], 'profiles/%s_pmc_sq_counters.csv' % tag)
+pmc(['pmc_sq_bucket', 'pmc_grbm_bucket'], 'profiles/%s_pmc_bucket_sq_counters.csv' % tag)
+pmc(['fetch'], 'profiles/%s_pmc_fetch_size.csv' % tag)
+pmc(['write'], 'profiles/%s_pmc_write_size.csv' % tag)
+pmc(['fetch_bucket'], 'profiles/%s_pmc_bucket_fetch_size.csv' % tag)
+pmc(['write_bucket'], 'profiles/%s_pmc_bucket_write_size.csv' % tag)
+pmc(['fetch_default'], 'profiles/%s_pmc_default_engine_fetch_size.csv' % tag)
 PY
-python3 tools/pmc_summary.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv $TAG 1024 16 | grep direct_acc
-{ echo "# default engine (bucket path)"; grep -v amdgpu $O/host_api_timing.txt; echo; echo "# LWKZG_DIRECT=16 (direct table)"; grep -v amdgpu $O/host_api_timing_direct.txt; } > $P/${TAG}_host_api_timing.txt
+python3 tools/pmc_summary.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv $TAG 1024 16 | grep -E "direct_acc|wrote"
+python3 tools/pmc_issue_summary.py k_direct_accumulate $P/${TAG}_issue_summary.json $O/pmc_sq1/sq_counter_collection.csv $O/pmc_sq2/sq_counter_collection.csv $O/pmc_sq3/sq_counter_collection.csv $O/pmc_grbm/grbm_counter_collection.csv > /dev/null
+python3 tools/pmc_issue_summary.py k_bucket_accumulate $P/${TAG}_issue_summary_bucket.json $O/pmc_sq_bucket/sq_counter_collection.csv $O/pmc_grbm_bucket/grbm_counter_collection.csv > /dev/null
+ls $P | grep $TAG | wc -l
+[ -s $O/kt_two_streams/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_timeline.txt
+[ -s $O/kt_two_streams_untuned/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams_untuned/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_untuned_timeline.txt
+true
