@@ -1330,8 +1330,10 @@ static C_KZG_RET map_rc(C_KZG_RET rc, int mode) {
 // starts with 128 + 384 instead, so that the GPU is at work after a quarter of the first upload (6.4 instead of 7.1 ms
 // for 512 commitments); from a whole chunk on, the smaller launches cost what the earlier start gains.
 static size_t slice_len(size_t k, size_t remaining, size_t n) {
+    static const size_t first_long = getenv("LWKZG_SLICE0") ? (size_t)atoi(getenv("LWKZG_SLICE0")) : 0;  // experiment: first slice of long batches
     size_t want = kMaxChunk / 2;
     if (n < kMaxChunk && k < 2) want = k == 0 ? kMaxChunk / 8 : kMaxChunk / 2 - kMaxChunk / 8;
+    else if (n >= kMaxChunk && first_long && k < 2) want = k == 0 ? first_long : kMaxChunk / 2 - first_long;
     return remaining < want ? remaining : want;
 }
 

@@ -199,3 +199,73 @@ def test_sixteen_threads_on_the_reference_symbol_are_coalesced(K, gpu_setup, buc
         t.join(timeout=300)
     for t in range(12):
         assert res[t] == (K.C_KZG_BADARGS if t % 4 == 0 else want_good), (t, res[t])
+
+
+def test_everything_at_once_on_one_settings_object(K, gpu_setup, oracle):
+    """Threads of every kind on ONE KZGSettings for a few seconds: coalesced single-blob commitments, host-pointer batches,
+    device-resident commitments + proofs on two caller streams (main context and twin), batch verification. Every answer
+    must be the single-threaded one; nothing may deadlock between the context, verify and coalescing locks."""
+    import threading
+    import time
+    import torch
+    ts = gpu_setup
+    blobs = [B.synthetic_blob(95000 + i) for i in range(48)]
+    joined = b"".join(blobs)
+    want_c = K.blob_to_kzg_commitment_batch(joined, ts)
+    for i in (0, 47):
+        assert want_c[i] == tau_closed_form(oracle, B.blob_scalars(blobs[i]))
+    cj = b"".join(want_c)
+    want_p = K.compute_blob_kzg_proof_batch(joined, cj, ts)
+    for i in (0, 47):
+        assert want_p[i] == reference_mode_proof_closed_form(oracle, blobs[i], want_c[i])
+    pj = b"".join(want_p)
+    d_blobs = _dev(joined)
+    d_comm = _dev(cj)
+    stop = time.time() + 4.0
+    errors, counts = [], {}
+
+    def run(name, fn):
+        k = 0
+        try:
+            while time.time() < stop:
+                fn(k)
+                k += 1
+        except Exception as e:      # pragma: no cover - reported below
+            errors.append("%s: %r" % (name, e))
+        counts[name] = counts.get(name, 0) + k
+
+    def single(k):
+        i = k % 48
+        assert K.blob_to_kzg_commitment(blobs[i], ts) == want_c[i]
+
+    def host_batch(k):
+        lo = (k * 5) % 32
+        assert K.blob_to_kzg_commitment_batch(joined[lo * B.BYTES_PER_BLOB:(lo + 16) * B.BYTES_PER_BLOB], ts) == want_c[lo:lo + 16]
+        assert K.compute_blob_kzg_proof_batch(joined[lo * B.BYTES_PER_BLOB:(lo + 4) * B.BYTES_PER_BLOB], cj[48 * lo:48 * (lo + 4)], ts) == want_p[lo:lo + 4]
+
+    def device(stream):
+        o = torch.zeros(48 * 48, dtype=torch.uint8, device="cuda")
+        p = torch.zeros(48 * 48, dtype=torch.uint8, device="cuda")
+
+        def fn(k):
+            K.blob_to_kzg_commitment_batch_device(o.data_ptr(), d_blobs.data_ptr(), 48, ts, stream.cuda_stream, None)
+            K.compute_blob_kzg_proof_batch_device(p.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), 48, ts, stream.cuda_stream, None)
+            stream.synchronize()
+            assert _host(o) == cj and _host(p) == pj
+        return fn
+
+    def verify(k):
+        assert K.verify_blob_kzg_proof_batch(joined[:8 * B.BYTES_PER_BLOB], cj[:48 * 8], pj[:48 * 8], 8, ts) is True
+        assert K.verify_blob_kzg_proof_batch(joined[:8 * B.BYTES_PER_BLOB], cj[:48 * 8], pj[48:48 * 9], 8, ts) is False
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    jobs = [("single", single)] * 4 + [("host_batch", host_batch)] * 2 + [("device_s1", device(s1)), ("device_s2", device(s2)), ("verify", verify)]
+    threads = [threading.Thread(target=run, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert errors == [], errors
+    assert all(counts.get(n, 0) > 0 for n, _ in jobs), counts
+    print("mixed concurrency: " + ", ".join("%s x%d" % kv for kv in sorted(counts.items())))

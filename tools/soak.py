@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential soak on the GPU: direct-table path vs bucket path vs the tau = 1337 closed form, on inputs the unit tests
+"""Differential soak on the GPU: wide direct table vs a narrow one (the generic-plan kernel) vs the bucket engine vs the tau = 1337 closed form, on inputs the unit tests
 do not sweep: full-range random 32-byte elements (values >= r included: reference mode reduces them), sparse blobs,
 blobs with few distinct scalars, and proofs. Prints one JSON summary; exit code 1 on any mismatch.
 
@@ -33,6 +33,9 @@ def main():
     TAU = 1337
     setup = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
     ts_b = K.TrustedSetup.from_file(setup)
+    ts_b.enable_direct_table(0)              # the bucket engine, forced (a plain load selects a direct table by itself)
+    ts_m = K.TrustedSetup.from_file(setup)
+    ts_m.enable_direct_table(12)             # a narrow table: the kernel that takes its window plan as an argument
     ts_d = K.TrustedSetup.from_file(setup)
     ts_b.reserve(args.batch)
     ts_d.reserve(args.batch)
@@ -49,6 +52,7 @@ def main():
     rng = np.random.default_rng(20240)
     d_out_b = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
     d_out_d = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+    d_out_m = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
     d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
     blobs_done = mismatches = closed_checked = proofs_checked = 0
     t0 = time.time()
@@ -67,10 +71,12 @@ def main():
         d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
         capi.blob_to_kzg_commitment_batch_device(d_out_b.data_ptr(), d_in.data_ptr(), n, ts_b, None, d_st.data_ptr())
         capi.blob_to_kzg_commitment_batch_device(d_out_d.data_ptr(), d_in.data_ptr(), n, ts_d, None, d_st.data_ptr())
+        capi.blob_to_kzg_commitment_batch_device(d_out_m.data_ptr(), d_in.data_ptr(), n, ts_m, None, d_st.data_ptr())
         torch.cuda.synchronize()
         a, b = bytes(d_out_b.cpu().numpy().tobytes()), bytes(d_out_d.cpu().numpy().tobytes())
-        if a != b:
-            mismatches += sum(a[48 * i:48 * i + 48] != b[48 * i:48 * i + 48] for i in range(n))
+        mm = bytes(d_out_m.cpu().numpy().tobytes())
+        if a != b or mm != b:
+            mismatches += sum(a[48 * i:48 * i + 48] != b[48 * i:48 * i + 48] or mm[48 * i:48 * i + 48] != b[48 * i:48 * i + 48] for i in range(n))
         for i in (0, n - 1):
             if b[48 * i:48 * i + 48] != closed(data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]):
                 mismatches += 1
