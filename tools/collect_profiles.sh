@@ -43,3 +43,10 @@ python tools/config_sweep.py --direct-bits default > $O/config_sweep_default.jso
 python tools/config_sweep.py --direct-bits 0 --max-verify 1024 > $O/config_sweep_bucket.json 2>> $O/sweep_err.txt
 find $O -name "*.csv" | wc -l
 du -sh $O
+timeout 2400 python -m pytest tests -m gpu -q --durations=15 > $O/gpu_test_log.txt 2>&1
+echo "pytest rc=$?" >> $O/gpu_test_log.txt
+timeout 1500 python tools/soak.py --batches 300 --direct-bits 16 > $O/soak.json 2> $O/soak_err.txt
+echo "{\"soak_rc\": $?}" >> $O/soak.json
+LWKZG_DIRECT=16 timeout 400 python tools/soak_verify.py 180 2> $O/soak_verify_err.txt | tail -1 > $O/soak_verify_direct16.json
+timeout 400 python tools/soak_verify.py 180 2>> $O/soak_verify_err.txt | tail -1 > $O/soak_verify_default.json
+du -sh $O
