@@ -1000,3 +1000,38 @@ def test_verify_single_blob_noncanonical_infinity_commitment(K, gpu_setup):
         with pytest.raises(K.KzgError) as e:
             K.verify_blob_kzg_proof(blob, badc, badp, gpu_setup)
         assert e.value.rc == K.C_KZG_ERROR
+
+
+def test_verify_kzg_proof_random_differential_vs_oracle(K, gpu_setup, oracle, oracle_setup):
+    """verify_kzg_proof on random inputs, the way the reference's fuzz harnesses drive it (fuzz/*/fuzz.c): honest proofs at
+    random points, then one field perturbed -- y off by one, z replaced, commitment / proof replaced by another subgroup point,
+    infinity in either place, a point outside the subgroup, non-canonical scalars. Verdict AND return code against the
+    oracle's closed-form verifier (the setup's tau is known); both modes."""
+    rnd = random.Random(4844)
+    inf = bytes([0xc0]) + bytes(47)
+    not_in_g1 = bytes([0x80]) + bytes(47)                     # (0, 2): on the curve, not in the subgroup (compression.rs:155-165)
+    cases = agree = 0
+    for mode, be, omode in ((K.MODE_REFERENCE, True, oracle.MODE_R), (K.MODE_CKZG, False, oracle.MODE_C)):
+        K.set_mode(mode)
+        order = "big" if be else "little"
+        blobs = [B.synthetic_blob(97000 + i, big_endian=be) for i in range(3)] + [bytes(B.BYTES_PER_BLOB)]
+        comms = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
+        for b, c in zip(blobs, comms):
+            for _ in range(6):
+                z = rnd.randrange(R).to_bytes(32, order)
+                pr, y = K.compute_kzg_proof(b, z, gpu_setup)
+                other = oracle.g1_generator_mul(rnd.randrange(2, R))
+                yy = ((int.from_bytes(y, order) + 1) % R).to_bytes(32, order)
+                variants = [(c, z, y, pr), (c, z, yy, pr), (c, rnd.randrange(R).to_bytes(32, order), y, pr), (other, z, y, pr),
+                            (c, z, y, other), (inf, z, y, pr), (c, z, y, inf), (not_in_g1, z, y, pr), (c, z, y, not_in_g1),
+                            (c, (R + 5).to_bytes(32, order), y, pr), (c, z, b"\xff" * 32, pr)]
+                for cm, zz, yv, pf in variants:
+                    want_rc, want_ok = oracle.verify_kzg_proof_known_tau(cm, zz, yv, pf, TAU, omode)
+                    try:
+                        got = (0, K.verify_kzg_proof(cm, zz, yv, pf, gpu_setup))
+                    except K.KzgError as e:
+                        got = (e.rc, False)
+                    assert got == (want_rc, want_ok), (mode, cm.hex()[:8], zz.hex()[:8], got, (want_rc, want_ok))
+                    cases += 1
+                    agree += int(got[1])
+    assert cases == 2 * 4 * 6 * 11 and agree >= 2 * 4 * 6       # every honest proof accepted, at least
