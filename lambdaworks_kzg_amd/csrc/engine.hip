@@ -1090,7 +1090,7 @@ int lwkzg_set_device(int ordinal) {
     g_default_device.store(ordinal);
     return 0;
 }
-const char *lwkzg_version(void) { return "lambdaworks_kzg_amd 0.1 (gfx950; fixed-base Pippenger c=13, 20 windows)"; }
+const char *lwkzg_version(void) { return "lambdaworks_kzg_amd 0.2 (gfx950; direct-table MSM, 10..16-bit windows; bucket fallback c=13, 20 windows)"; }
 const char *lwkzg_last_error(void) { return get_error(); }
 int lwkzg_msm_window_bits(void) { return kWindowBits; }
 int lwkzg_msm_num_windows(void) { return kNumWindows; }
