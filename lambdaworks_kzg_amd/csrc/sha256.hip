@@ -182,42 +182,43 @@ __global__ __launch_bounds__(128) void k_challenge(const uint8_t *__restrict__ b
 }
 
 // ---- lane-pair variant ---------------------------------------------------------------------------------------
-// The consumer's 15-16 instructions per round shrink to 12 (no wait states left over) when a blob's state is split over two neighbouring lanes:
-// the "e half" (e, f, g, h) and the "a half" (a, b, c, d) run the SAME instruction stream on different data --
-//     Sigma(r0) with per-lane rotation amounts (6, 11, 25 | 2, 13, 22),
-//     Ch(e, f, g) = bfi(e, f, g) and Maj(a, b, c) = bfi(a ^ c, b, c) as one bfi(r0 ^ (r2 & a_half), r1, r2),
-//     t = Sigma + select + (W + K | 0), plus h on the e half only (a bank-masked DPP add),
+// The consumer's 15-16 instructions per round shrink to TEN when a blob's state is split over two neighbouring lanes: the
+// "e half" (e, f, g, h) and the "a half" (a, b, c, d) run the SAME instruction stream on different data --
+//     Sigma(r0): three rotations with per-lane amounts (6, 11, 25 | 2, 13, 22) joined by ONE v_bitop3_b32 (truth table 0x96 =
+//                three-way xor; gfx950 has the three-input boolean instruction),
+//     Ch(e, f, g) = bfi(e, f, g) and Maj(a, b, c) = bfi(a ^ c, b, c) as one bfi(r0 ^ (r2 & a_half), r1, r2), the selector
+//                again ONE v_bitop3_b32 (0x78 = a ^ (b & c)),
+//     t = Sigma + select + u, where u = h + (W + K) on the e half and 0 on the a half is computed ONE ROUND AHEAD by a
+//                bank-masked DPP add (the next round's h is this round's g) -- which also is the independent instruction
+//                that fills the wait state between the write of t and its DPP read two instructions later,
 // and exchange T1 / d through DPP operands: e' = d + T1, a' = T1 + T2. Within a row of 16 lanes, lanes 0-7 are
 // the e halves of eight blobs and lanes 8-15 their a halves (partner = lane ^ 8 = row_ror:8; DPP banks 0-1 | 2-3).
 // Two producer waves (even / odd blocks, half a block per barrier interval each) feed two consumer waves (32 blobs
 // each); the consumers preload the sixteen LDS words of a block before its first round. LWKZG_HASH_PAIRS=0 selects
-// the plain kernel.
-// one round on state registers named R0..R3 (asm operand names), W + K in WK; the new r0 lands in R3's register (the
-// roles rotate through the four registers, back to the start after four rounds). `ta` = r2 & a_half mask is
-// computed one round ahead: the AND fills the wait state the last DPP add needs after t1 is written.
-#define LWK_SHA_PAIR_RND(R0, R1, R2, R3, WK)                                                       \
+// the plain kernel. (Round 1: 12 instructions with two xors and a separate + h; 3.3 ms per batch.)
+// One round on state registers named R0..R3 (asm operand names); WKN = the NEXT round's W + K; the new r0 lands in R3's
+// register (the roles rotate through the four registers, back to the start after four rounds).
+#define LWK_SHA_PAIR_RND(R0, R1, R2, R3, WKN)                                                      \
     "v_alignbit_b32 %[t1], %[" R0 "], %[" R0 "], %[s1]\n"                                           \
     "v_alignbit_b32 %[t2], %[" R0 "], %[" R0 "], %[s2]\n"                                           \
     "v_alignbit_b32 %[t3], %[" R0 "], %[" R0 "], %[s3]\n"                                           \
-    "v_xor_b32 %[t1], %[t1], %[t2]\n"                                                               \
-    "v_xor_b32 %[t1], %[t1], %[t3]\n"                                                               \
-    "v_xor_b32 %[t2], %[ta], %[" R0 "]\n"                                                           \
+    "v_bitop3_b32 %[t1], %[t1], %[t2], %[t3] bitop3:0x96\n"                                         \
+    "v_bitop3_b32 %[t2], %[" R0 "], %[" R2 "], %[bm] bitop3:0x78\n"                                 \
     "v_bfi_b32 %[t2], %[t2], %[" R1 "], %[" R2 "]\n"                                                \
-    "v_add3_u32 %[t1], %[t1], %[t2], %[" WK "]\n"                                                   \
-    "v_add_u32_dpp %[t1], %[" R3 "], %[t1] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n"        \
+    "v_add3_u32 %[t1], %[t1], %[t2], %[u]\n"                                                       \
     "v_add_u32_dpp %[" R3 "], %[" R3 "], %[t1] row_ror:8 row_mask:0xf bank_mask:0x3\n"              \
-    "v_and_b32 %[ta], %[" R1 "], %[bm]\n"                                                           \
+    "v_add_u32_dpp %[u], %[" R2 "], %[" WKN "] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n"    \
     "v_add_u32_dpp %[" R3 "], %[t1], %[t1] row_ror:8 row_mask:0xf bank_mask:0xc\n"
 
-// four rounds = one 16-byte word of W + K; state in (r0, r1, r2, r3) before and after
-#define LWK_SHA_PAIR_ROUNDS4(V)                                                                              \
+// four rounds = one 16-byte word of W + K (V; N = the first word of the next one); state in (r0, r1, r2, r3) before and after
+#define LWK_SHA_PAIR_ROUNDS4(V, N)                                                                           \
     {                                                                                                        \
         uint32_t t1, t2, t3;                                                                                 \
-        asm volatile(LWK_SHA_PAIR_RND("a0", "a1", "a2", "a3", "w0") LWK_SHA_PAIR_RND("a3", "a0", "a1", "a2", "w1") \
-                         LWK_SHA_PAIR_RND("a2", "a3", "a0", "a1", "w2") LWK_SHA_PAIR_RND("a1", "a2", "a3", "a0", "w3") \
-                     : [a0] "+v"(r0), [a1] "+v"(r1), [a2] "+v"(r2), [a3] "+v"(r3), [ta] "+v"(ta), [t1] "=&v"(t1),  \
+        asm volatile(LWK_SHA_PAIR_RND("a0", "a1", "a2", "a3", "w1") LWK_SHA_PAIR_RND("a3", "a0", "a1", "a2", "w2") \
+                         LWK_SHA_PAIR_RND("a2", "a3", "a0", "a1", "w3") LWK_SHA_PAIR_RND("a1", "a2", "a3", "a0", "w4") \
+                     : [a0] "+v"(r0), [a1] "+v"(r1), [a2] "+v"(r2), [a3] "+v"(r3), [u] "+v"(u), [t1] "=&v"(t1),    \
                        [t2] "=&v"(t2), [t3] "=&v"(t3)                                                         \
-                     : [w0] "v"((V).x), [w1] "v"((V).y), [w2] "v"((V).z), [w3] "v"((V).w), [s1] "v"(s1), [s2] "v"(s2), \
+                     : [w1] "v"((V).y), [w2] "v"((V).z), [w3] "v"((V).w), [w4] "v"(N), [s1] "v"(s1), [s2] "v"(s2), \
                        [s3] "v"(s3), [bm] "v"(bm));                                                          \
     }
 
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restri
              hv2 = a_half ? 0x3c6ef372u : 0x1f83d9abu, hv3 = a_half ? 0xa54ff53au : 0x5be0cd19u;
     uint32_t r0 = hv0, r1 = hv1, r2 = hv2, r3 = hv3;
     const uint32_t s1 = a_half ? 2u : 6u, s2 = a_half ? 13u : 11u, s3 = a_half ? 22u : 25u, bm = a_half ? ~0u : 0u;
-    uint32_t ta = r2 & bm;  // the next round's r2 & a_half mask (see LWK_SHA_PAIR_RND)
+    uint32_t u = 0;  // h + (W + K) of the coming round on the e half, 0 on the a half (see LWK_SHA_PAIR_RND)
     // producer state: the rolling 16-word window of its current block and the loads of its next one
     uint32_t w[16];
     uint4 nxt[4];
@@ -324,11 +325,11 @@ __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restri
             uint4 v[16];  // all sixteen LDS reads in flight before the first round (the asm rounds are scheduling barriers)
 #pragma unroll
             for (int q = 0; q < 16; q++) v[q] = *(const uint4 *)(base + q * stride);
+            u = a_half ? 0u : r3 + v[0].x;  // the first round's h + (W + K); every later one is computed a round ahead
 #pragma unroll
-            for (int q = 0; q < 16; q++) LWK_SHA_PAIR_ROUNDS4(v[q])
+            for (int q = 0; q < 16; q++) LWK_SHA_PAIR_ROUNDS4(v[q], v[q < 15 ? q + 1 : 15].x)  // (the last round's look-ahead is unused)
             hv0 += r0; hv1 += r1; hv2 += r2; hv3 += r3;
             r0 = hv0; r1 = hv1; r2 = hv2; r3 = hv3;
-            ta = r2 & bm;
         }
         __syncthreads();
     }
