@@ -1,7 +1,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02q
+O=$R/gpurun_out/r02r
 mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests/test_gpu_proof_parity.py tests/test_gpu_zz_env.py -x -q > $O/pytest.log 2>&1
