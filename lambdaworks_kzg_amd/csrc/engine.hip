@@ -606,15 +606,6 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
     LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
     launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
     LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
-    {   // experiment: LWKZG_KEEPWARM="blocks,iters" spins that many workgroups beside the hash (see fr_ops.hip)
-        static const char *kw = getenv("LWKZG_KEEPWARM");
-        if (kw) {
-            int blocks = 512, iters = 200000;
-            sscanf(kw, "%d,%d", &blocks, &iters);
-            LWK_HIP(hipStreamWaitEvent(c->aux[2], c->ev_fork, 0));
-            launch_keepwarm((uint32_t *)w.status_long ? (uint32_t *)w.status_long : (uint32_t *)w.status, blocks, iters, c->aux[2]);
-        }
-    }
     launch_challenge(blobs, comm48, z, le, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
     launch_challenge(blobs, canon, z, le, n, st, comm48);

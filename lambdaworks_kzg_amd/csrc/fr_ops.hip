@@ -43,22 +43,6 @@ __global__ __launch_bounds__(256) void k_build_twiddles(Fr *__restrict__ tw_fwd,
     tw_inv[k] = b;
 }
 
-// experiment (LWKZG_KEEPWARM): an ALU spin on `blocks` workgroups, to see whether a kernel that follows a latency-shaped
-// phase runs slower because the chip dropped its clock while almost idle
-__global__ __launch_bounds__(256) void k_keepwarm(uint32_t *sink, int iters) {
-    uint32_t a = threadIdx.x * 2654435761u + 1u, b = blockIdx.x | 1u;
-    u64 acc0 = a, acc1 = b, acc2 = a ^ b, acc3 = a + b;
-    for (int i = 0; i < iters; i++) {
-        acc0 += (u64)a * b; acc1 += (u64)(a + 1) * b; acc2 += (u64)a * (b + 2); acc3 += (u64)(a ^ 5) * (b ^ 7);
-        a = (uint32_t)acc0 + (uint32_t)acc2; b = (uint32_t)acc1 ^ (uint32_t)acc3;
-    }
-    if (((uint32_t)acc0 ^ (uint32_t)acc1 ^ (uint32_t)acc2 ^ (uint32_t)acc3) == 0x12345u) sink[0] = a;
-}
-void launch_keepwarm(uint32_t *sink, int blocks, int iters, hipStream_t st) {
-    ProfScope p("k_keepwarm", st);
-    hipLaunchKernelGGL(k_keepwarm, dim3((unsigned)blocks), dim3(256), 0, st, sink, iters);
-}
-
 void launch_build_twiddles(Fr *tw_fwd, Fr *tw_inv, hipStream_t st) {
     ProfScope p("k_build_twiddles", st);
     hipLaunchKernelGGL(k_build_twiddles, dim3(kBlobElems / 2 / 256), dim3(256), 0, st, tw_fwd, tw_inv);

@@ -80,8 +80,6 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
 // z bytes -> Montgomery. le = 0: big-endian, reduced. le = 1: little-endian, must be canonical else BADARGS.
 void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, int le, size_t n, hipStream_t st);
 
-void launch_keepwarm(uint32_t *sink, int blocks, int iters, hipStream_t st);  // experiment, see fr_ops.hip
-
 // ---- Fiat-Shamir (sha256.hip)
 // validate + canonicalise commitments (decompress incl. subgroup check, recompress), then
 // z = sha256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blob | commitment) as Fr
