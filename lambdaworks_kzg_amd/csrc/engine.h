@@ -136,6 +136,23 @@ struct Combiner {
     bool ready = false, failed = false;
 };
 
+// The same front for compute_blob_kzg_proof (engine.hip: combine_blob_proof): one leader at a time runs everything queued
+// as one host-pointer batch.
+struct ProofReq {
+    enum State { QUEUED, TAKEN, DONE };
+    const uint8_t *blob = nullptr, *comm = nullptr;
+    uint8_t *out = nullptr;
+    int mode = 0;
+    C_KZG_RET rc = C_KZG_OK;
+    State state = QUEUED;
+};
+struct ProofCombiner {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<ProofReq *> queue;
+    bool leader_active = false;
+};
+
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {
     FFTSettings fs;
@@ -151,6 +168,7 @@ struct Ctx {
     hipStream_t ws_last;
     hipEvent_t lane_done[kCombineLanes];  // last use of a workspace half by a lane of the coalescing front
     Combiner comb;
+    ProofCombiner proof_comb;
     // A second set of streams + workspace over the SAME tables (engine.hip: pick_ctx): device-resident calls that arrive
     // on another caller stream while this context's workspace is still busy run there, so that the latency-shaped head
     // of one call (Fiat-Shamir hash, commitment validation) overlaps the ALU-bound MSM of the other.

@@ -1720,12 +1720,91 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
 
 }  // namespace
 
+static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n, int mode,
+                                       size_t *first_bad);
+
+// Concurrent callers of compute_blob_kzg_proof (one blob per call, as a block builder issues them): whoever arrives while
+// no batch is being run becomes the leader of everything queued in its mode (<= 64), copies the blobs and commitments
+// into contiguous host arrays and runs them as ONE host-pointer batch (host threads hash, one launch set); the others
+// wait for their 48 bytes. If the batch fails (an invalid commitment somewhere in it), every member is redone on its
+// own, so each caller gets exactly the return code a lone call would have given. Same contract as combine_commit.
+static C_KZG_RET combine_blob_proof(Ctx *c, KZGProof *out, const Blob *blob, const Bytes48 *commitment, int mode) {
+    ProofCombiner &pc = c->proof_comb;
+    ProofReq req;
+    req.blob = (const uint8_t *)blob;
+    req.comm = (const uint8_t *)commitment;
+    req.out = (uint8_t *)out;
+    req.mode = mode;
+    std::unique_lock<std::mutex> lk(pc.m);
+    pc.queue.push_back(&req);
+    for (;;) {
+        if (req.state == ProofReq::DONE) break;
+        if (req.state == ProofReq::QUEUED && !pc.leader_active) {
+            pc.leader_active = true;
+            std::vector<ProofReq *> batch;
+            for (auto it = pc.queue.begin(); it != pc.queue.end() && batch.size() < kCombineMaxBatch;) {
+                if ((*it)->mode == mode) {
+                    (*it)->state = ProofReq::TAKEN;
+                    batch.push_back(*it);
+                    it = pc.queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lk.unlock();
+            const size_t m = batch.size();
+            if (m == 1) {
+                req.rc = blob_proof_batch_host(c, (KZGProof *)req.out, (const Blob *)req.blob, (const Bytes48 *)req.comm, 1, mode, nullptr);
+            } else {
+                std::vector<uint8_t> hb(m * (size_t)kBlobBytes), hc(m * 48), ho(m * 48);
+                for (size_t i = 0; i < m; i++) {
+                    memcpy(&hb[i * (size_t)kBlobBytes], batch[i]->blob, kBlobBytes);
+                    memcpy(&hc[48 * i], batch[i]->comm, 48);
+                }
+                C_KZG_RET rc = blob_proof_batch_host(c, (KZGProof *)ho.data(), (const Blob *)hb.data(), (const Bytes48 *)hc.data(), m, mode, nullptr);
+                for (size_t i = 0; i < m; i++) {
+                    ProofReq *r = batch[i];
+                    if (rc == C_KZG_OK) {
+                        memcpy(r->out, &ho[48 * i], 48);
+                        r->rc = C_KZG_OK;
+                    } else {  // somebody's input was rejected: everyone gets the verdict of a call of their own
+                        r->rc = blob_proof_batch_host(c, (KZGProof *)r->out, (const Blob *)r->blob, (const Bytes48 *)r->comm, 1, mode, nullptr);
+                    }
+                }
+            }
+            lk.lock();
+            for (ProofReq *r : batch) r->state = ProofReq::DONE;
+            pc.leader_active = false;
+            pc.cv.notify_all();
+            continue;
+        }
+        pc.cv.wait(lk);
+    }
+    return req.rc;
+}
+
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
                                              const KZGSettings *s, size_t *first_bad) {
     const int mode = mode_now();
     if (!out || !blobs || !commitments) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    if (n == 1) {  // the reference's symbol: merged with the other callers of the moment
+        static const bool coalesce = !(getenv("LWKZG_COALESCE") && atoi(getenv("LWKZG_COALESCE")) == 0);
+        if (coalesce) {
+            C_KZG_RET rc1 = combine_blob_proof(c, out, blobs, commitments, mode);
+            if (rc1 != C_KZG_OK) {
+                if (first_bad) *first_bad = 0;
+                if (!get_error()[0]) set_error("blob 0 rejected");
+            }
+            return rc1;
+        }
+    }
+    return blob_proof_batch_host(c, out, blobs, commitments, n, mode, first_bad);
+}
+
+static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n, int mode,
+                                       size_t *first_bad) {
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     WsUse wsu(c, c->stream);

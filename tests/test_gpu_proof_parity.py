@@ -221,7 +221,8 @@ def test_everything_at_once_on_one_settings_object(K, gpu_setup, oracle):
     pj = b"".join(want_p)
     d_blobs = _dev(joined)
     d_comm = _dev(cj)
-    stop = time.time() + 4.0
+    import os
+    stop = time.time() + float(os.environ.get("LWKZG_TEST_STRESS_SECONDS", "4"))     # a longer run: tools/r02_longsoak.sh
     errors, counts = [], {}
 
     def run(name, fn):
@@ -237,6 +238,8 @@ def test_everything_at_once_on_one_settings_object(K, gpu_setup, oracle):
     def single(k):
         i = k % 48
         assert K.blob_to_kzg_commitment(blobs[i], ts) == want_c[i]
+        if k % 3 == 0:
+            assert K.compute_blob_kzg_proof(blobs[i], want_c[i], ts) == want_p[i]
 
     def host_batch(k):
         lo = (k * 5) % 32
@@ -269,3 +272,47 @@ def test_everything_at_once_on_one_settings_object(K, gpu_setup, oracle):
     assert errors == [], errors
     assert all(counts.get(n, 0) > 0 for n, _ in jobs), counts
     print("mixed concurrency: " + ", ".join("%s x%d" % kv for kv in sorted(counts.items())))
+
+
+def test_concurrent_single_blob_proofs_are_coalesced(K, gpu_setup, oracle, oracle_setup):
+    """compute_blob_kzg_proof, one blob per call, from twelve threads (a block builder proving its blobs in parallel):
+    merged into shared host-pointer batches by the library. Every proof equals the oracle's; a thread that passes an
+    invalid commitment gets its error while the others -- members of the same merged batch -- get their proofs."""
+    import threading
+    import time
+    ts = gpu_setup
+    blobs = [B.synthetic_blob(98000 + i) for i in range(24)]
+    comms = K.blob_to_kzg_commitment_batch(b"".join(blobs), ts)
+    want = [reference_mode_proof_closed_form(oracle, b, c) for b, c in zip(blobs, comms)]
+    for i in (0, 23):
+        assert oracle.compute_blob_kzg_proof(blobs[i], comms[i], oracle_setup, oracle.MODE_R) == (0, want[i])
+    assert K.compute_blob_kzg_proof(blobs[0], comms[0], ts) == want[0]
+    errors, bad_seen = [], []
+    n_threads, per_thread = 12, 40
+
+    def worker(t):
+        try:
+            for it in range(per_thread):
+                i = (t * 5 + it * 7) % 24
+                if t == 3 and it % 4 == 0:           # an invalid commitment in the middle of everybody else's calls
+                    try:
+                        K.compute_blob_kzg_proof(blobs[i], bytes(48), ts)
+                        errors.append("invalid commitment accepted")
+                    except K.KzgError as e:
+                        bad_seen.append(e.rc)
+                else:
+                    assert K.compute_blob_kzg_proof(blobs[i], comms[i], ts) == want[i], (t, it, i)
+        except Exception as e:      # pragma: no cover - reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    el = time.perf_counter() - t0
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert errors == []
+    assert bad_seen == [K.C_KZG_ERROR] * (per_thread // 4)
+    print("coalesced single-blob proofs: %.0f proofs/s from %d threads" % (n_threads * per_thread / el, n_threads))
