@@ -222,7 +222,7 @@ def test_everything_at_once_on_one_settings_object(K, gpu_setup, oracle):
     d_blobs = _dev(joined)
     d_comm = _dev(cj)
     import os
-    stop = time.time() + float(os.environ.get("LWKZG_TEST_STRESS_SECONDS", "4"))     # a longer run: tools/r02_longsoak.sh
+    stop = time.time() + float(os.environ.get("LWKZG_TEST_STRESS_SECONDS", "4"))     # a longer run: tools/r02_experiments/r02_longsoak.sh
     errors, counts = [], {}
 
     def run(name, fn):
