@@ -4,6 +4,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -136,17 +137,17 @@ struct Combiner {
     bool ready = false, failed = false;
 };
 
-// The same front for compute_blob_kzg_proof (engine.hip: combine_blob_proof): one leader at a time runs everything queued
-// as one host-pointer batch.
+// The same front for compute_blob_kzg_proof and compute_kzg_proof (engine.hip: front_run): one leader at a time runs
+// everything queued in its mode as one host-pointer batch. `second` is the commitment (48 bytes) or z (32 bytes).
 struct ProofReq {
     enum State { QUEUED, TAKEN, DONE };
-    const uint8_t *blob = nullptr, *comm = nullptr;
-    uint8_t *out = nullptr;
+    const uint8_t *blob = nullptr, *second = nullptr;
+    uint8_t *out = nullptr, *y_out = nullptr;
     int mode = 0;
     C_KZG_RET rc = C_KZG_OK;
     State state = QUEUED;
 };
-struct ProofCombiner {
+struct ProofFront {
     std::mutex m;
     std::condition_variable cv;
     std::deque<ProofReq *> queue;
@@ -168,7 +169,7 @@ struct Ctx {
     hipStream_t ws_last;
     hipEvent_t lane_done[kCombineLanes];  // last use of a workspace half by a lane of the coalescing front
     Combiner comb;
-    ProofCombiner proof_comb;
+    ProofFront blob_proof_front, point_proof_front;
     // A second set of streams + workspace over the SAME tables (engine.hip: pick_ctx): device-resident calls that arrive
     // on another caller stream while this context's workspace is still busy run there, so that the latency-shaped head
     // of one call (Fiat-Shamir hash, commitment validation) overlaps the ALU-bound MSM of the other.

@@ -1333,6 +1333,12 @@ static size_t slice_len(size_t k, size_t remaining, size_t n, bool direct) {
 // Coalescing front of blob_to_kzg_commitment (engine.h: Combiner). Contract matched: concurrent callers on one
 // KZGSettings, /root/reference/src/lib.rs:253-283 + SURVEY 8b "Threading".
 
+// LWKZG_COALESCE=0: single-blob calls are not merged with concurrent ones
+static bool coalesce_singles() {
+    static const bool on = !(getenv("LWKZG_COALESCE") && atoi(getenv("LWKZG_COALESCE")) == 0);
+    return on;
+}
+
 static bool combiner_init(Ctx *c) {  // caller holds comb.m
     Combiner &cb = c->comb;
     if (cb.ready || cb.failed) return cb.ready;
@@ -1461,10 +1467,9 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blo
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
     if (n == 1) {  // the reference's symbol: merged with the other callers of the moment
-        static const bool coalesce = !(getenv("LWKZG_COALESCE") && atoi(getenv("LWKZG_COALESCE")) == 0);
         C_KZG_RET rc1;
         uint8_t tmp[48];
-        if (coalesce && combine_commit(c, tmp, (const uint8_t *)blobs, mode, &rc1)) {
+        if (coalesce_singles() && combine_commit(c, tmp, (const uint8_t *)blobs, mode, &rc1)) {
             if (rc1 == C_KZG_OK) memcpy(out, tmp, 48);
             else if (first_bad) *first_bad = 0;
             if (rc1 != C_KZG_OK && !get_error()[0]) set_error("blob 0 rejected");
@@ -1723,64 +1728,106 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
 static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n, int mode,
                                        size_t *first_bad);
 
-// Concurrent callers of compute_blob_kzg_proof (one blob per call, as a block builder issues them): whoever arrives while
-// no batch is being run becomes the leader of everything queued in its mode (<= 64), copies the blobs and commitments
-// into contiguous host arrays and runs them as ONE host-pointer batch (host threads hash, one launch set); the others
-// wait for their 48 bytes. If the batch fails (an invalid commitment somewhere in it), every member is redone on its
-// own, so each caller gets exactly the return code a lone call would have given. Same contract as combine_commit.
-static C_KZG_RET combine_blob_proof(Ctx *c, KZGProof *out, const Blob *blob, const Bytes48 *commitment, int mode) {
-    ProofCombiner &pc = c->proof_comb;
-    ProofReq req;
-    req.blob = (const uint8_t *)blob;
-    req.comm = (const uint8_t *)commitment;
-    req.out = (uint8_t *)out;
-    req.mode = mode;
-    std::unique_lock<std::mutex> lk(pc.m);
-    pc.queue.push_back(&req);
+static C_KZG_RET point_proof_batch_host(Ctx *c, KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs, size_t n,
+                                        int mode, size_t *first_bad);
+
+// Concurrent callers of compute_blob_kzg_proof / compute_kzg_proof (one blob per call, as a block builder issues them):
+// whoever arrives while no batch is being run becomes the leader of everything queued in its mode (<= 64) and hands it to
+// `run`, which answers every member; the others wait for their bytes. Same contract as combine_commit.
+static C_KZG_RET front_run(ProofFront &pf, ProofReq &req, const std::function<void(const std::vector<ProofReq *> &)> &run) {
+    std::unique_lock<std::mutex> lk(pf.m);
+    pf.queue.push_back(&req);
     for (;;) {
         if (req.state == ProofReq::DONE) break;
-        if (req.state == ProofReq::QUEUED && !pc.leader_active) {
-            pc.leader_active = true;
+        if (req.state == ProofReq::QUEUED && !pf.leader_active) {
+            pf.leader_active = true;
             std::vector<ProofReq *> batch;
-            for (auto it = pc.queue.begin(); it != pc.queue.end() && batch.size() < kCombineMaxBatch;) {
-                if ((*it)->mode == mode) {
+            for (auto it = pf.queue.begin(); it != pf.queue.end() && batch.size() < kCombineMaxBatch;) {
+                if ((*it)->mode == req.mode) {
                     (*it)->state = ProofReq::TAKEN;
                     batch.push_back(*it);
-                    it = pc.queue.erase(it);
+                    it = pf.queue.erase(it);
                 } else {
                     ++it;
                 }
             }
             lk.unlock();
-            const size_t m = batch.size();
-            if (m == 1) {
-                req.rc = blob_proof_batch_host(c, (KZGProof *)req.out, (const Blob *)req.blob, (const Bytes48 *)req.comm, 1, mode, nullptr);
-            } else {
-                std::vector<uint8_t> hb(m * (size_t)kBlobBytes), hc(m * 48), ho(m * 48);
-                for (size_t i = 0; i < m; i++) {
-                    memcpy(&hb[i * (size_t)kBlobBytes], batch[i]->blob, kBlobBytes);
-                    memcpy(&hc[48 * i], batch[i]->comm, 48);
-                }
-                C_KZG_RET rc = blob_proof_batch_host(c, (KZGProof *)ho.data(), (const Blob *)hb.data(), (const Bytes48 *)hc.data(), m, mode, nullptr);
-                for (size_t i = 0; i < m; i++) {
-                    ProofReq *r = batch[i];
-                    if (rc == C_KZG_OK) {
-                        memcpy(r->out, &ho[48 * i], 48);
-                        r->rc = C_KZG_OK;
-                    } else {  // somebody's input was rejected: everyone gets the verdict of a call of their own
-                        r->rc = blob_proof_batch_host(c, (KZGProof *)r->out, (const Blob *)r->blob, (const Bytes48 *)r->comm, 1, mode, nullptr);
-                    }
-                }
-            }
+            run(batch);
             lk.lock();
             for (ProofReq *r : batch) r->state = ProofReq::DONE;
-            pc.leader_active = false;
-            pc.cv.notify_all();
+            pf.leader_active = false;
+            pf.cv.notify_all();
             continue;
         }
-        pc.cv.wait(lk);
+        pf.cv.wait(lk);
     }
     return req.rc;
+}
+
+// The leader copies the blobs and commitments into contiguous host arrays and runs them as ONE host-pointer batch (host
+// threads hash, one launch set). If the batch fails (an invalid commitment somewhere in it), every member is redone on
+// its own, so each caller gets exactly the return code a lone call would have given.
+static C_KZG_RET combine_blob_proof(Ctx *c, KZGProof *out, const Blob *blob, const Bytes48 *commitment, int mode) {
+    ProofReq req;
+    req.blob = (const uint8_t *)blob;
+    req.second = (const uint8_t *)commitment;
+    req.out = (uint8_t *)out;
+    req.mode = mode;
+    return front_run(c->blob_proof_front, req, [c, mode](const std::vector<ProofReq *> &batch) {
+        auto alone = [c, mode](ProofReq *r) {
+            r->rc = blob_proof_batch_host(c, (KZGProof *)r->out, (const Blob *)r->blob, (const Bytes48 *)r->second, 1, mode, nullptr);
+        };
+        const size_t m = batch.size();
+        if (m == 1) return alone(batch[0]);
+        std::vector<uint8_t> hb(m * (size_t)kBlobBytes), hc(m * 48), ho(m * 48);
+        for (size_t i = 0; i < m; i++) {
+            memcpy(&hb[i * (size_t)kBlobBytes], batch[i]->blob, kBlobBytes);
+            memcpy(&hc[48 * i], batch[i]->second, 48);
+        }
+        C_KZG_RET rc = blob_proof_batch_host(c, (KZGProof *)ho.data(), (const Blob *)hb.data(), (const Bytes48 *)hc.data(), m, mode, nullptr);
+        for (size_t i = 0; i < m; i++) {
+            if (rc != C_KZG_OK) {  // somebody's input was rejected: everyone gets the verdict of a call of their own
+                alone(batch[i]);
+                continue;
+            }
+            memcpy(batch[i]->out, &ho[48 * i], 48);
+            batch[i]->rc = C_KZG_OK;
+        }
+    });
+}
+
+// compute_kzg_proof the same way: blobs and evaluation points side by side, proofs and y values back.
+static C_KZG_RET combine_point_proof(Ctx *c, KZGProof *proof_out, Bytes32 *y_out, const Blob *blob, const Bytes32 *z, int mode) {
+    ProofReq req;
+    req.blob = (const uint8_t *)blob;
+    req.second = (const uint8_t *)z;
+    req.out = (uint8_t *)proof_out;
+    req.y_out = (uint8_t *)y_out;
+    req.mode = mode;
+    return front_run(c->point_proof_front, req, [c, mode](const std::vector<ProofReq *> &batch) {
+        auto alone = [c, mode](ProofReq *r) {
+            r->rc = point_proof_batch_host(c, (KZGProof *)r->out, (Bytes32 *)r->y_out, (const Blob *)r->blob, (const Bytes32 *)r->second, 1,
+                                           mode, nullptr);
+        };
+        const size_t m = batch.size();
+        if (m == 1) return alone(batch[0]);
+        std::vector<uint8_t> hb(m * (size_t)kBlobBytes), hz(m * 32), ho(m * 48), hy(m * 32);
+        for (size_t i = 0; i < m; i++) {
+            memcpy(&hb[i * (size_t)kBlobBytes], batch[i]->blob, kBlobBytes);
+            memcpy(&hz[32 * i], batch[i]->second, 32);
+        }
+        C_KZG_RET rc = point_proof_batch_host(c, (KZGProof *)ho.data(), (Bytes32 *)hy.data(), (const Blob *)hb.data(),
+                                              (const Bytes32 *)hz.data(), m, mode, nullptr);
+        for (size_t i = 0; i < m; i++) {
+            if (rc != C_KZG_OK) {
+                alone(batch[i]);
+                continue;
+            }
+            memcpy(batch[i]->out, &ho[48 * i], 48);
+            memcpy(batch[i]->y_out, &hy[32 * i], 32);
+            batch[i]->rc = C_KZG_OK;
+        }
+    });
 }
 
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
@@ -1790,8 +1837,7 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, c
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
     if (n == 1) {  // the reference's symbol: merged with the other callers of the moment
-        static const bool coalesce = !(getenv("LWKZG_COALESCE") && atoi(getenv("LWKZG_COALESCE")) == 0);
-        if (coalesce) {
+        if (coalesce_singles()) {
             C_KZG_RET rc1 = combine_blob_proof(c, out, blobs, commitments, mode);
             if (rc1 != C_KZG_OK) {
                 if (first_bad) *first_bad = 0;
@@ -1882,6 +1928,19 @@ C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, c
     if (!proofs_out || !ys_out || !blobs || !zs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    if (n == 1 && coalesce_singles()) {  // the reference's symbol: merged with the other callers of the moment
+        C_KZG_RET rc1 = combine_point_proof(c, proofs_out, ys_out, blobs, zs, mode);
+        if (rc1 != C_KZG_OK) {
+            if (first_bad) *first_bad = 0;
+            if (!get_error()[0]) set_error("blob 0 rejected");
+        }
+        return rc1;
+    }
+    return point_proof_batch_host(c, proofs_out, ys_out, blobs, zs, n, mode, first_bad);
+}
+
+static C_KZG_RET point_proof_batch_host(Ctx *c, KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs, size_t n,
+                                        int mode, size_t *first_bad) {
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     WsUse wsu(c, c->stream);

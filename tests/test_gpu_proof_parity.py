@@ -316,3 +316,56 @@ def test_concurrent_single_blob_proofs_are_coalesced(K, gpu_setup, oracle, oracl
     assert errors == []
     assert bad_seen == [K.C_KZG_ERROR] * (per_thread // 4)
     print("coalesced single-blob proofs: %.0f proofs/s from %d threads" % (n_threads * per_thread / el, n_threads))
+
+
+@pytest.mark.parametrize("mode_name", ["reference", "ckzg"])
+def test_concurrent_single_point_proofs_are_coalesced(K, gpu_setup, oracle, oracle_setup, mode_name):
+    """compute_kzg_proof, one blob per call, from twelve threads: merged the same way (blobs and evaluation points side by
+    side). Every (proof, y) equals the oracle's; in c-kzg mode a thread that passes a non-canonical z gets C_KZG_BADARGS
+    while the members of the same merged batch get their answers."""
+    import threading
+    import time
+    ts = gpu_setup
+    ckzg = mode_name == "ckzg"
+    K.set_mode(K.MODE_CKZG if ckzg else K.MODE_REFERENCE)
+    try:
+        omode = oracle.MODE_C if ckzg else oracle.MODE_R
+        blobs = [B.synthetic_blob(99000 + i, big_endian=not ckzg) for i in range(16)]
+        zs = [B.synthetic_blob(99500 + i, big_endian=not ckzg)[:32] for i in range(16)]
+        want = []
+        for b, z in zip(blobs, zs):
+            rc, pr, y = oracle.compute_kzg_proof(b, z, oracle_setup, omode)
+            assert rc == 0
+            want.append((pr, y))
+        assert K.compute_kzg_proof(blobs[0], zs[0], ts) == want[0]
+        errors, bad_seen = [], []
+        n_threads, per_thread = 12, 40
+
+        def worker(t):
+            try:
+                for it in range(per_thread):
+                    i = (t * 5 + it * 7) % 16
+                    if ckzg and t == 3 and it % 4 == 0:
+                        try:
+                            K.compute_kzg_proof(blobs[i], b"\xff" * 32, ts)
+                            errors.append("non-canonical z accepted")
+                        except K.KzgError as e:
+                            bad_seen.append(e.rc)
+                    else:
+                        assert K.compute_kzg_proof(blobs[i], zs[i], ts) == want[i], (t, it, i)
+            except Exception as e:      # pragma: no cover - reported below
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        el = time.perf_counter() - t0
+        assert not any(t.is_alive() for t in threads), "deadlock"
+        assert errors == []
+        assert bad_seen == ([K.C_KZG_BADARGS] * (per_thread // 4) if ckzg else [])
+        print("coalesced single point proofs (%s): %.0f proofs/s from %d threads" % (mode_name, n_threads * per_thread / el, n_threads))
+    finally:
+        K.set_mode(K.MODE_REFERENCE)
