@@ -125,7 +125,12 @@ def cpu_baseline(gpu_outputs, g2_blst):
 
 
 MADS_PER_MIXED_ADD = 6 * 392 + 2 * 301 + 588    # 6 Montgomery products (392 v_mad_u64_u32 each on 14 x 28-bit limbs), 2 squares (301), one fused pair (588)
-INT_MAD_PEAK_MEASURED = 2.93e13                  # tools/ubench.hip on MI355X: v_mad_u64_u32 lane-ops/s at 8 waves/SIMD (profiles/r01_ubench_instruction_rates.jsonl)
+# tools/ubench_mad.hip on MI355X (profiles/r02_ubench_mad.txt): v_mad_u64_u32 issues every 4.17 cycles per SIMD with 8 waves per
+# SIMD at the 2.40 GHz the chip holds in that short loop (3.77e13 lane-ops/s), every 4.63 cycles with the 2 waves per SIMD this
+# kernel's 204 registers allow. (Round 1 quoted 2.93e13 from a loop of 8 instructions per taken branch, which measured the branch.)
+INT_MAD_PEAK_MEASURED = 256 * 4 * 64 / 4.17 * 2.4e9
+INT_MAD_CYCLES_2_WAVES = 4.63
+KERNEL_CLOCK_HZ = 2.05e9                         # GRBM_GUI_ACTIVE under this kernel: 1.99-2.08 GHz (profiles/r02_issue_summary.json)
 INT_MAD_PEAK_THEORETICAL = 256 * 4 * 64 / 4 * 2.4e9   # 256 CUs x 4 SIMDs x 64 lanes / 4 cycles per wave-instruction x 2.4 GHz = 3.93e13
 GATHER_PEAK_ROWS = 1.31e10                       # tools/gather_bench.hip on MI355X: random 112-byte rows/s out of a 128-200 GiB table
 
@@ -170,11 +175,16 @@ def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launc
         "int_mad": {"mad_u64_u32_per_launch": mads_per_launch,
                     "achieved_Gmad_per_s": mad_rate / 1e9,
                     "peak_Gmad_per_s": INT_MAD_PEAK_MEASURED / 1e9,
-                    "peak_note": "measured v_mad_u64_u32 issue rate (tools/ubench.hip, 8 waves per SIMD, the clock the chip holds under that load)",
+                    "peak_note": "measured v_mad_u64_u32 issue rate (tools/ubench_mad.hip: 4.17 cycles per wave-instruction per SIMD with 8 waves per "
+                                 "SIMD, at the 2.40 GHz the chip holds in that short loop; profiles/r02_ubench_mad.txt)",
                     "frac": mad_rate / INT_MAD_PEAK_MEASURED,
+                    "peak_at_kernel_occupancy_and_clock_Gmad_per_s": 256 * 4 * 64 / INT_MAD_CYCLES_2_WAVES * KERNEL_CLOCK_HZ / 1e9,
+                    "frac_at_kernel_occupancy_and_clock": mad_rate / (256 * 4 * 64 / INT_MAD_CYCLES_2_WAVES * KERNEL_CLOCK_HZ),
+                    "peak_at_kernel_occupancy_and_clock_note": "the same micro-benchmark with 2 waves per SIMD (all that 204 VGPRs allow: 4.63 cycles) "
+                                                               "at the ~2.05 GHz the board holds under this kernel (GRBM_GUI_ACTIVE)",
                     "peak_theoretical_Gmad_per_s": INT_MAD_PEAK_THEORETICAL / 1e9,
                     "peak_theoretical_note": "256 CUs x 4 SIMDs x 64 lanes / 4 cycles per wave-instruction at the 2.4 GHz maximum clock; "
-                                             "the kernel holds ~2.08 GHz (GRBM_GUI_ACTIVE, profiles/r02_pmc_*)",
+                                             "the kernel holds 1.99-2.08 GHz (GRBM_GUI_ACTIVE, profiles/r02_pmc_*)",
                     "frac_of_theoretical": mad_rate / INT_MAD_PEAK_THEORETICAL,
                     # all multiply-adds of a step over the step's wall time (every kernel, all streams):
                     "frac_whole_step": mads_per_launch * launches_per_step / (elapsed / steps) / INT_MAD_PEAK_MEASURED},
