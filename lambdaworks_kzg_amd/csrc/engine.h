@@ -186,6 +186,7 @@ struct Ctx {
     G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled
     int direct_bits;           // 14 / 15 / 16 when direct_table is live, else 0
     Fr *tw_fwd, *tw_inv;
+    Fr28 *tw28_fwd, *tw28_inv;  // the same twiddles in the transform's own arithmetic (fr28.cuh)
     Workspace ws;
     VerifyBuffers vs;   // verify-side scratch, sized for vs_cap blobs
     size_t vs_cap;

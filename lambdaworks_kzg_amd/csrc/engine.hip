@@ -223,12 +223,16 @@ static void ctx_destroy(Ctx *c) {
         c->table = nullptr;
         c->direct_table = nullptr;
         c->tw_fwd = c->tw_inv = nullptr;
+    c->tw28_fwd = c->tw28_inv = nullptr;
+        c->tw28_fwd = c->tw28_inv = nullptr;
     }
     dev_free(c->points);
     dev_free(c->table);
     dev_free(c->direct_table);
     dev_free(c->tw_fwd);
     dev_free(c->tw_inv);
+    dev_free(c->tw28_fwd);
+    dev_free(c->tw28_inv);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->vstream) hipStreamDestroy(c->vstream);
     for (int k = 0; k < kMaxSplit; k++) {
@@ -315,11 +319,15 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
         c->direct_bits = twin_of->direct_bits;
         c->tw_fwd = twin_of->tw_fwd;
         c->tw_inv = twin_of->tw_inv;
+        c->tw28_fwd = twin_of->tw28_fwd;
+        c->tw28_inv = twin_of->tw28_inv;
     } else {
         if (e == hipSuccess) e = hipMalloc((void **)&c->points, (size_t)kBlobElems * sizeof(G1Affine));
         if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine29));
         if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
         if (e == hipSuccess) e = hipMalloc((void **)&c->tw_inv, (size_t)(kBlobElems / 2) * sizeof(Fr));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->tw28_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr28));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->tw28_inv, (size_t)(kBlobElems / 2) * sizeof(Fr28));
     }
     if (e != hipSuccess) {
         set_error("device context allocation failed: %s", hipGetErrorString(e));
@@ -357,6 +365,8 @@ static Ctx *pick_ctx(Ctx *c, hipStream_t st) {
 // twiddles on device + the genuine FFTSettings tables on the host
 static C_KZG_RET ctx_finish_fft(Ctx *c) {
     launch_build_twiddles(c->tw_fwd, c->tw_inv, c->stream);
+    launch_twiddles_to28(c->tw_fwd, c->tw28_fwd, c->stream);
+    launch_twiddles_to28(c->tw_inv, c->tw28_inv, c->stream);
     const int n = kBlobElems;
     std::vector<Fr> h_f(n / 2), h_i(n / 2);
     LWK_HIP(hipMemcpyAsync(h_f.data(), c->tw_fwd, (n / 2) * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
@@ -505,9 +515,7 @@ static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode,
     if (mode == LWKZG_MODE_REFERENCE) {
         launch_parse_be_reduce(blobs, scalars, n * kBlobElems, st);
     } else {
-        Fr *fr = w.fr + base * (size_t)kBlobElems;
-        launch_parse_le_canonical(blobs, fr, status, n, st);
-        launch_ntt4096(fr, (Fr *)scalars, c->tw_inv, 1, n, st);
+        launch_blob_evaluations_to_coefficients(blobs, scalars, c->tw28_inv, status, n, st);
     }
 }
 
@@ -2160,10 +2168,10 @@ C_KZG_RET lwkzg_fr_ntt4096_device(void *out_dev, const void *in_dev, size_t n, i
         launch_fr_be_to_mont(src, (Fr *)w.scalars2, m * kBlobElems, st);
         launch_bitrev_permute((const Fr *)w.scalars2, w.fr, m, st);  // natural order in -> DIT wants bit-reversed
         if (inverse) {
-            launch_ntt4096(w.fr, (Fr *)w.scalars, c->tw_inv, 1, m, st);  // scaled by 4096^-1, canonical limbs out
+            launch_ntt4096(w.fr, (Fr *)w.scalars, c->tw28_inv, 1, m, st);  // scaled by 4096^-1, canonical limbs out
             launch_raw_to_be(w.scalars, dst, m * kBlobElems, st);
         } else {
-            launch_ntt4096(w.fr, (Fr *)w.scalars2, c->tw_fwd, 0, m, st);
+            launch_ntt4096(w.fr, (Fr *)w.scalars2, c->tw28_fwd, 0, m, st);
             launch_fr_mont_to_be((const Fr *)w.scalars2, dst, m * kBlobElems, st);
         }
     }

@@ -52,18 +52,78 @@ void launch_build_twiddles(Fr *tw_fwd, Fr *tw_inv, hipStream_t st) {
 // 4096-point DIT transform in LDS.  The input is consumed in the order given: feeding evaluations in
 // bit-reversed order (exactly how a c-kzg-4844 blob stores them) yields natural-order output, so the
 // usual bit-reversal pass disappears.
+//
+// Arithmetic: fr28.cuh (10 lazy limbs of 28 bits, Montgomery radix 2^280). An element enters through one product
+// (x 2^256 -> x 2^280) and leaves through one (-> x 2^256, or -> x / 4096 in canonical words); in between a butterfly
+// is ONE product, ten additions and ten offset subtractions, nothing is reduced or carried, except that the u inputs of
+// stage 6 get one carry ripple: a subtraction adds two units of 2^28 to a limb, twelve stages of them would pass the
+// fifteen a 32-bit limb holds (bounds: max 13 units per limb, value < 50 r, a product's column < 2^64; the same
+// walk-through as a Python loop is in tests/test_capi_cpu.py).
+// LDS: limbs 0..8 as nine arrays of 4096 words, limb 9 (< 2^9: the value's top) as 4096 halfwords: 152 KiB of the 160.
 
 constexpr int kNttThreads = 1024;
+constexpr int kNttLdsBytes = 9 * kBlobElems * 4 + kBlobElems * 2;
 
-__global__ __launch_bounds__(kNttThreads) void k_ntt4096(const Fr *__restrict__ in, Fr *__restrict__ out,
-                                                         const Fr *__restrict__ tw, int scale_to_raw) {
+// tw28[k] = the Fr twiddle tw[k] in fr28 form (canonical limbs); one lane per entry
+__global__ __launch_bounds__(256) void k_twiddles_to28(const Fr *__restrict__ tw, Fr28 *__restrict__ tw28, int n) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    tw28[k] = fr28_canonical(fr28_from_mont256(tw[k]));
+}
+
+void launch_twiddles_to28(const Fr *tw, Fr28 *tw28, hipStream_t st) {
+    ProfScope p("k_twiddles_to28", st);
+    hipLaunchKernelGGL(k_twiddles_to28, dim3(kBlobElems / 2 / 256), dim3(256), 0, st, tw, tw28, kBlobElems / 2);
+}
+
+struct NttLds {
+    uint32_t *lo;   // [9][4096]
+    uint16_t *top;  // [4096]
+    __device__ Fr28 get(int i) const {
+        Fr28 r;
+#pragma unroll
+        for (int j = 0; j < 9; j++) r.l[j] = lo[j * kBlobElems + i];
+        r.l[9] = top[i];
+        return r;
+    }
+    __device__ void put(int i, const Fr28 &v) const {
+#pragma unroll
+        for (int j = 0; j < 9; j++) lo[j * kBlobElems + i] = v.l[j];
+        top[i] = (uint16_t)v.l[9];
+    }
+};
+
+// FROM_BLOB = false: `in` holds Fr values in field.cuh's Montgomery form (the transform API); true: `in` is blob bytes,
+// canonical little-endian evaluations in the order a c-kzg-4844 blob stores them (mode C): the parse, the range check
+// (an element >= r marks its blob in `status`: c-kzg's C_KZG_BADARGS) and the entry into Montgomery form happen on load.
+template <bool FROM_BLOB>
+__global__ __launch_bounds__(kNttThreads) void k_ntt4096(const void *__restrict__ in, Fr *__restrict__ out,
+                                                         const Fr28 *__restrict__ tw, int scale_to_raw,
+                                                         int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    Fr *a = (Fr *)lds_raw;  // 4096 x 32 B = 128 KiB
+    NttLds a{(uint32_t *)lds_raw, (uint16_t *)(lds_raw + 9 * kBlobElems * 4)};
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * kBlobElems;
-    for (int i = tid; i < kBlobElems; i += kNttThreads) a[i] = in[base + i];
+    auto load = [&](int i) {
+        if constexpr (FROM_BLOB) {
+            const uint4 *src = (const uint4 *)in + 2 * (base + i);
+            uint4 lo = src[0], hi = src[1];
+            uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (raw_geq<8>(w, FrParams::MOD)) status[blockIdx.x] = kStatusBadArgs;  // benign race: same value
+            return LWK_FR28_MUL_CONST(fr28_pack(w), RR);
+        } else {
+            return fr28_from_mont256(((const Fr *)in)[base + i]);
+        }
+    };
+    auto store = [&](int i, const Fr28 &v) {
+        if (scale_to_raw) fr28_to_raw_scaled(out[base + i].l, v);  // canonical words
+        else out[base + i] = fr28_to_mont256(v);
+    };
+    for (int i = tid; i < kBlobElems; i += kNttThreads) a.put(i, load(i));
     __syncthreads();
-    // stage s: butterflies of span half = 2^s; twiddle index = (k mod half) * (2048 / half)
+    // stage s: butterflies of span half = 2^s; twiddle index = (k mod half) * (2048 / half). (Two stages per LDS round
+    // trip -- radix-4 passes in registers, first and last pass straight from / to global memory -- measured the same
+    // 0.38 ms per 1024 blobs: the kernel's time is its products.)
     for (int s = 0; s < 12; s++) {
         const int half = 1 << s;
         const int tshift = 11 - s;
@@ -71,30 +131,37 @@ __global__ __launch_bounds__(kNttThreads) void k_ntt4096(const Fr *__restrict__ 
             int k = bfly & (half - 1);
             int i0 = ((bfly >> s) << (s + 1)) + k;
             int i1 = i0 + half;
-            Fr u = a[i0];
-            Fr v = a[i1] * tw[k << tshift];
-            a[i0] = u + v;
-            a[i1] = u - v;
+            Fr28 u = a.get(i0);
+            if (s == 6) u = fr28_norm(u);  // the one carry ripple of the transform (see above)
+            Fr28 v = a.get(i1);
+            if (s != 0) v = fr28_mul(v, tw[k << tshift]);  // stage 0: every twiddle is 1, and v is a product's result already
+            a.put(i0, fr28_add(u, v));
+            a.put(i1, fr28_sub(u, v));
         }
         __syncthreads();
     }
-    if (scale_to_raw) {
-        Fr ninv;
-#pragma unroll
-        for (int i = 0; i < 8; i++) ninv.l[i] = kNInvRaw[i];
-        for (int i = tid; i < kBlobElems; i += kNttThreads) out[base + i] = a[i] * ninv;  // Montgomery x raw -> raw
-    } else {
-        for (int i = tid; i < kBlobElems; i += kNttThreads) out[base + i] = a[i];
-    }
+    for (int i = tid; i < kBlobElems; i += kNttThreads) store(i, a.get(i));
 }
 
-void launch_ntt4096(const Fr *in, Fr *out, const Fr *tw, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st) {
+template <bool FROM_BLOB>
+static void launch_ntt_t(const void *in, Fr *out, const Fr28 *tw, int scale_to_raw, int32_t *status, size_t n_blobs, hipStream_t st) {
     ProfScope p("k_ntt4096", st);
     static const hipError_t attr_set =
-        hipFuncSetAttribute((const void *)k_ntt4096, hipFuncAttributeMaxDynamicSharedMemorySize, kBlobElems * 32);
+        hipFuncSetAttribute((const void *)k_ntt4096<FROM_BLOB>, hipFuncAttributeMaxDynamicSharedMemorySize, kNttLdsBytes);
     (void)attr_set;
-    hipLaunchKernelGGL(k_ntt4096, dim3((unsigned)n_blobs), dim3(kNttThreads), kBlobElems * 32, st, in, out, tw,
-                       inverse_scale_to_raw);
+    hipLaunchKernelGGL(k_ntt4096<FROM_BLOB>, dim3((unsigned)n_blobs), dim3(kNttThreads), kNttLdsBytes, st, in, out, tw, scale_to_raw,
+                       status);
+}
+
+void launch_ntt4096(const Fr *in, Fr *out, const Fr28 *tw, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st) {
+    launch_ntt_t<false>(in, out, tw, inverse_scale_to_raw, nullptr, n_blobs, st);
+}
+
+// mode C front end in one launch: blob bytes (canonical little-endian evaluations, bit-reversed domain order) ->
+// canonical monomial coefficients; status[b] = kStatusBadArgs for a blob with an element >= r
+void launch_blob_evaluations_to_coefficients(const uint8_t *blobs, uint32_t *coeffs_raw, const Fr28 *tw_inv, int32_t *status,
+                                             size_t n_blobs, hipStream_t st) {
+    launch_ntt_t<true>(blobs, (Fr *)coeffs_raw, tw_inv, 1, status, n_blobs, st);
 }
 
 __global__ __launch_bounds__(256) void k_bitrev_permute(const Fr *__restrict__ in, Fr *__restrict__ out, size_t n) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "g1.cuh"
+#include "fr28.cuh"
 #include "plan.h"
 
 namespace lwk {
@@ -23,7 +24,6 @@ struct ProfScope {
 // (blob_to_polynomial, /root/reference/src/utils.rs:27-41).
 void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st);
 // Mode C: 32-byte little-endian elements, must be canonical (else status[blob] = BADARGS) -> Montgomery Fr
-void launch_parse_le_canonical(const uint8_t *blobs, Fr *out_mont, int32_t *status, size_t n_blobs, hipStream_t st);
 
 // ---- MSM (msm.hip)
 void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *bucket_start, uint32_t *perm,
@@ -66,7 +66,10 @@ void launch_build_twiddles(Fr *tw_fwd, Fr *tw_inv, hipStream_t st);
 // in-place-in-LDS 4096-point radix-2 DIT over Fr. Input is consumed in the order given
 // (bit-reversed-order input -> natural-order output). `scale_raw_out`: if set, output is multiplied by
 // 4096^-1 and written as canonical raw limbs; otherwise Montgomery.
-void launch_ntt4096(const Fr *in, Fr *out, const Fr *tw, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st);
+void launch_twiddles_to28(const Fr *tw, Fr28 *tw28, hipStream_t st);
+void launch_ntt4096(const Fr *in, Fr *out, const Fr28 *tw28, int inverse_scale_to_raw, size_t n_blobs, hipStream_t st);
+void launch_blob_evaluations_to_coefficients(const uint8_t *blobs, uint32_t *coeffs_raw, const Fr28 *tw28_inv, int32_t *status,
+                                             size_t n_blobs, hipStream_t st);
 void launch_bitrev_permute(const Fr *in, Fr *out, size_t n_blobs, hipStream_t st);
 void launch_fr_be_to_mont(const uint8_t *in_be, Fr *out, size_t n_elems, hipStream_t st);
 void launch_fr_mont_to_be(const Fr *in, uint8_t *out_be, size_t n_elems, hipStream_t st);

@@ -54,28 +54,10 @@ __global__ __launch_bounds__(256) void k_parse_be_reduce(const uint4 *__restrict
     out[2 * i + 1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-__global__ __launch_bounds__(256) void k_parse_le_canonical(const uint4 *__restrict__ in, Fr *__restrict__ out,
-                                                            int32_t *__restrict__ status, size_t n_elems) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_elems) return;
-    uint4 lo = in[2 * i], hi = in[2 * i + 1];
-    uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    if (raw_geq<8>(s, FrParams::MOD)) status[i / kBlobElems] = kStatusBadArgs;  // benign race: same value
-    out[i] = fe_from_raw<FrParams>(s);
-}
-
 void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st) {
     ProfScope p("k_parse_be_reduce", st);
     unsigned grid = (unsigned)((n_elems + 255) / 256);
     hipLaunchKernelGGL(k_parse_be_reduce, dim3(grid), dim3(256), 0, st, (const uint4 *)blobs, (uint4 *)scalars_raw,
-                       n_elems);
-}
-
-void launch_parse_le_canonical(const uint8_t *blobs, Fr *out_mont, int32_t *status, size_t n_blobs, hipStream_t st) {
-    ProfScope p("k_parse_le_canonical", st);
-    size_t n_elems = n_blobs * kBlobElems;
-    unsigned grid = (unsigned)((n_elems + 255) / 256);
-    hipLaunchKernelGGL(k_parse_le_canonical, dim3(grid), dim3(256), 0, st, (const uint4 *)blobs, out_mont, status,
                        n_elems);
 }
 

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -192,3 +193,49 @@ def test_c_consumers_compile_and_link_against_the_header_and_library(tmp_path):
                                os.path.join(ROOT, "tests", src), "-o", exe, "-L", lib_dir, "-llambdaworks_kzg",
                                "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
         assert os.path.exists(exe)
+
+
+def test_generated_constant_tables_are_current():
+    """field29_consts.inc / fr28_consts.inc are what tools/gen_field_consts.py prints (p, r, their Montgomery constants and
+    the borrowed multiples the lazy subtractions add)."""
+    gen = os.path.join(ROOT, "tools", "gen_field_consts.py")
+    csrc = os.path.join(ROOT, "lambdaworks_kzg_amd", "csrc")
+    assert subprocess.check_output([sys.executable, gen]).decode() == open(os.path.join(csrc, "field29_consts.inc")).read()
+    assert subprocess.check_output([sys.executable, gen, "--fr28"]).decode() == open(os.path.join(csrc, "fr28_consts.inc")).read()
+
+
+def test_transform_lazy_bounds_walkthrough():
+    """The 4096-point transform (fr_ops.hip: k_ntt4096) never reduces and ripples carries once: walk its twelve stages
+    with the bounds fr28.cuh states -- a sum adds the limb bounds, a difference adds two units of 2^28 per limb and 4r to
+    the value, a product's result is one unit per limb and < 2r -- and check what the kernel relies on: no limb passes
+    the 15 units a 32-bit word holds, every product's column fits 64 bits, values stay under 2^25 r (the Montgomery
+    radix 2^280 over r), and the top limb fits the 16 bits it gets in LDS."""
+    n, norm_stage = 4096, 6
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    limb = [1] * n        # units of 2^28
+    val = [2] * n         # units of r: elements enter through a product
+    worst_limb = worst_val = 0
+    for s in range(12):
+        half = 1 << s
+        nl, nv = limb[:], val[:]
+        for b in range(n // 2):
+            k = b & (half - 1)
+            i0 = ((b >> s) << (s + 1)) + k
+            i1 = i0 + half
+            lu, vu = (1, val[i0]) if s == norm_stage else (limb[i0], val[i0])
+            if s != 0:      # v goes through a product with a canonical twiddle
+                assert 10 * (limb[i1] * 1 + 1) * (1 << 56) + (1 << 36) < 1 << 64      # column of a*b + m*r plus the carry
+                assert val[i1] * 1 <= 1 << 25
+                lv, vv = 1, 2
+            else:
+                lv, vv = limb[i1], val[i1]
+                assert lv == 1 and vv == 2      # the subtraction below wants a product's result
+            nl[i0], nv[i0] = lu + lv, vu + vv
+            nl[i1], nv[i1] = lu + 2, vu + 4
+        limb, val = nl, nv
+        worst_limb, worst_val = max(worst_limb, max(limb)), max(worst_val, max(val))
+    assert worst_limb == 13 and worst_limb <= 15
+    assert worst_val <= 50 and worst_val * r < 1 << 280
+    assert (worst_val * r) >> 252 < 1 << 16      # limb 9 as a halfword
+    # the exit product takes the laziest element
+    assert 10 * (worst_limb + 1) * (1 << 56) + (1 << 36) < 1 << 64

@@ -6,11 +6,15 @@
 //      CIOS field on the same values
 //   3. hot-loop group law: [k]G by double-and-add over F29 (XYZZ, mixed additions) == [k]G over the CIOS field, on
 //      compressed bytes; [r]G = O; [r-1]G = -G; P + P through the addition formula's doubling branch; P + (-P) = O
+//   4. the transform's scalar field (fr28.cuh: 10 lazy limbs of 28 bits): products, butterflies and a whole 4096-point
+//      transform in the kernel's stage order (one carry ripple at stage 6, nothing else reduced) == the 8 x 32-bit CIOS field
 //   hipcc -O2 -std=c++17 --offload-arch=gfx950 -I lambdaworks_kzg_amd/csrc tools/host_check.hip -o /tmp/host_check
 #include <stdio.h>
 #include <stdint.h>
 #include <string.h>
 #include "g1.cuh"
+#include "fr28.cuh"
+#include <vector>
 using namespace lwk;
 
 static uint64_t sm(uint64_t &s) {
@@ -118,6 +122,74 @@ int main() {
         ok &= memcmp(o3, o4, 48) == 0;
         if (!ok && bad++ < 5) printf("addition branches mismatch\n");
     }
-    printf(bad ? "FAIL %d\n" : "ok: inversion, field and group-law cross-checks agree\n", bad);
+    // ---- 4. fr28: the NTT's arithmetic against the CIOS scalar field
+    {
+        auto same_fr = [](const Fr &a, const Fr &b) {
+            for (int i = 0; i < 8; i++)
+                if (a.l[i] != b.l[i]) return false;
+            return true;
+        };
+        auto rand_fr = [&]() {
+            uint32_t raw[8];
+            for (int i = 0; i < 8; i++) raw[i] = (uint32_t)sm(seed);
+            raw[7] &= 0x3fffffffu;  // < 2^254 < r
+            return fe_from_raw<FrParams>(raw);
+        };
+        for (int k = 0; k < 2000; k++) {
+            Fr x = rand_fr(), y = rand_fr(), z = rand_fr();
+            if (k == 0) x = Fr::zero();
+            if (k == 1) { uint32_t raw[8]; for (int i = 0; i < 8; i++) raw[i] = FrParams::MOD[i]; raw[0] -= 1; x = y = fe_from_raw<FrParams>(raw); }
+            Fr28 X = fr28_from_mont256(x), Y = fr28_canonical(fr28_from_mont256(y)), Z = fr28_from_mont256(z);
+            uint32_t w1[8], w2[8];
+            fr28_to_raw_scaled(w1, fr28_mul(X, Y));
+            uint32_t ninv_raw[8] = {0x00100001u, 0x400fffffu, 0xbfce5c19u, 0xd3686828u, 0x89213de7u, 0x5eb6a46au, 0xb46ae370u, 0x73e66878u};
+            fe_to_raw<FrParams>(w2, x * y * fe_from_raw<FrParams>(ninv_raw));
+            bool ok = same_fr(fr28_to_mont256(fr28_mul(X, Y)), x * y) && memcmp(w1, w2, 32) == 0 &&
+                      same_fr(fr28_to_mont256(fr28_add(Z, fr28_mul(X, Y))), z + x * y) &&
+                      same_fr(fr28_to_mont256(fr28_sub(Z, fr28_mul(X, Y))), z - x * y) &&
+                      same_fr(fr28_to_mont256(fr28_norm(fr28_sub(fr28_add(Z, Z), fr28_mul(X, Y)))), z + z - x * y);
+            if (!ok && bad++ < 5) printf("fr28 mismatch at case %d\n", k);
+        }
+        // a whole transform, the kernel's loop (fr_ops.hip: k_ntt4096) on both fields; twiddles w^k from the CIOS side
+        const uint32_t omega_raw[8] = {0xa5d36306u, 0xe206da11u, 0x378fbf96u, 0x0ad1347bu, 0xe0f8245fu, 0xfc3e8acfu, 0xa0f704f4u, 0x564c0a11u};
+        const Fr w = fe_from_raw<FrParams>(omega_raw);
+        std::vector<Fr> tw(2048), a(4096);
+        std::vector<Fr28> tw28(2048), a28(4096);
+        tw[0] = Fr::one();
+        for (int k = 1; k < 2048; k++) tw[k] = tw[k - 1] * w;
+        for (int k = 0; k < 2048; k++) tw28[k] = fr28_canonical(fr28_from_mont256(tw[k]));
+        for (int i = 0; i < 4096; i++) {
+            a[i] = rand_fr();
+            if (i % 7 == 0) { uint32_t raw[8]; for (int j = 0; j < 8; j++) raw[j] = FrParams::MOD[j]; raw[0] -= 1 + (i & 3); a[i] = fe_from_raw<FrParams>(raw); }  // large values
+            a28[i] = fr28_from_mont256(a[i]);
+        }
+        uint32_t max_limb = 0;
+        for (int s = 0; s < 12; s++) {
+            const int half = 1 << s, tshift = 11 - s;
+            for (int bfly = 0; bfly < 2048; bfly++) {
+                int k = bfly & (half - 1), i0 = ((bfly >> s) << (s + 1)) + k, i1 = i0 + half;
+                Fr u = a[i0], v = a[i1] * tw[k << tshift];
+                a[i0] = u + v;
+                a[i1] = u - v;
+                Fr28 u28 = a28[i0];
+                if (s == 6) u28 = fr28_norm(u28);
+                Fr28 v28 = a28[i1];
+                if (s != 0) v28 = fr28_mul(v28, tw28[k << tshift]);
+                a28[i0] = fr28_add(u28, v28);
+                a28[i1] = fr28_sub(u28, v28);
+                for (int j = 0; j < 10; j++) {
+                    if (a28[i0].l[j] > max_limb) max_limb = a28[i0].l[j];
+                    if (a28[i1].l[j] > max_limb) max_limb = a28[i1].l[j];
+                }
+            }
+        }
+        int wrong = 0;
+        for (int i = 0; i < 4096; i++) wrong += !same_fr(fr28_to_mont256(a28[i]), a[i]);
+        if (wrong || max_limb >= (14u << 28)) {  // the analysis says 13 units of 2^28 at most
+            printf("fr28 transform: %d of 4096 outputs differ, largest limb %u units\n", wrong, max_limb >> 28);
+            bad++;
+        }
+    }
+    printf(bad ? "FAIL %d\n" : "ok: inversion, field, group-law and transform-field cross-checks agree\n", bad);
     return bad != 0;
 }
