@@ -223,7 +223,6 @@ static void ctx_destroy(Ctx *c) {
         c->table = nullptr;
         c->direct_table = nullptr;
         c->tw_fwd = c->tw_inv = nullptr;
-    c->tw28_fwd = c->tw28_inv = nullptr;
         c->tw28_fwd = c->tw28_inv = nullptr;
     }
     dev_free(c->points);
@@ -297,6 +296,7 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
     c->direct_bits = 0;
     c->vs_cap = 0;
     c->tw_fwd = c->tw_inv = nullptr;
+    c->tw28_fwd = c->tw28_inv = nullptr;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     // validation kernels get a stream of their own. (A CU-masked stream -- hipExtStreamCreateWithCUMask, upper half of
