@@ -333,7 +333,8 @@ def main():
         roof, nwin = engine_picture(K, capi, bits, pr, el, 5, n)
         return {"engine": label, "direct_bits": bits, "value": n * world * 5 / el, "unit": "ops/s", "steps": 5, "warmup": 2,
                 "ms_per_step": el / 5 * 1e3,
-                "table_bytes": capi.direct_table_bytes(bits) if bits else 20 * 4096 * 112,
+                "table_bytes": capi.direct_table_bytes(bits, ts.direct_row_bytes() or 112) if bits else 20 * 4096 * 112,
+                "table_row_bytes": ts.direct_row_bytes() if bits else 112,
                 "kernels": {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in pr.items()},
                 "roofline": roof}
 
@@ -468,8 +469,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "setup_load_s": t_load,
-            "msm_path": ("direct table, %d-bit windows, %d windows, %.0f GB resident" % (
-                direct_bits, nwin, capi.direct_table_bytes(direct_bits) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
+            "msm_path": ("direct table, %d-bit windows, %d windows, %d-byte rows, %.0f GB resident" % (
+                direct_bits, nwin, ts.direct_row_bytes(), capi.direct_table_bytes(direct_bits, ts.direct_row_bytes()) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
             "engine_note": "the timed region runs on the widest direct table that fits (--direct-bits auto, an explicit lwkzg_enable_direct_table "
                            "call); `default_engine` is the same workload on the engine a plain load selects, `bucket_engine` on the low-memory fallback",
             "direct_table_build_s": t_table if direct_bits else None,

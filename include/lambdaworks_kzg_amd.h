@@ -175,7 +175,7 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
 
 /* "Direct" fixed-base MSM for this settings object: trade HBM capacity for arithmetic. With every
  * multiple d * 2^(window_bits * j) * P_i of every setup point resident (window_bits 10 .. 16: 6, 11, 21, 36, 68,
- * 135, 240 GB), the 4096-term MSM behind every entry point above becomes 4096 * ceil(255 / window_bits) gathered
+ * 135, 240 GB with packed rows, 8/7 of that with the rows aligned to 128-byte lines, see lwkzg_direct_row_bytes), the 4096-term MSM behind every entry point above becomes 4096 * ceil(255 / window_bits) gathered
  * mixed additions (26, 24, 22, 20, 19, 17, 16 per scalar): no digit sort, no buckets, no bucket reduction. Results
  * are bit-identical between all widths and the bucket engine. window_bits = 0 frees the table and selects the bucket
  * engine (9 MB table, 20 additions per scalar plus sort and reduction).
@@ -190,6 +190,10 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
 C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits);
 int lwkzg_direct_table_bits(const KZGSettings *s);   /* 0 = bucket engine, 10..16 = direct table live, -1 = bad settings */
 int lwkzg_direct_num_windows(int window_bits);       /* additions per scalar on the direct path (0 for other widths) */
+/* Bytes from one table row to the next: 128 when every row got a 128-byte line of its own (chosen whenever that table
+ * leaves 8 GiB of the device free: one line per gather, +2.5 % / +5 % / +1.4 % at 13 / 15 / 16 bits), 112 when the rows are
+ * packed (the sizes quoted above); 0 = bucket engine, -1 = bad settings. LWKZG_DIRECT_ROW=112|128 forces one. */
+int lwkzg_direct_row_bytes(const KZGSettings *s);
 
 /* The Fiat-Shamir challenges of device-resident blobs: z_i = compute_challenge(blob_i, commitment_i)
  * (src/utils.rs:120-154) as n x 32 bytes in the mode's byte order, canonical. This is the hash kernel of

@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
-    "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows",
+    "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
     "lwkzg_release_context", "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
 ]
@@ -93,6 +93,7 @@ def lib():
     l.lwkzg_enable_direct_table.argtypes = [ps, ci]
     l.lwkzg_direct_table_bits.argtypes = [ps]
     l.lwkzg_direct_num_windows.argtypes = [ci]
+    l.lwkzg_direct_row_bytes.argtypes = [ps]
     l.lwkzg_g1_lincomb_setup_device.argtypes = [vp, vp, sz, ps, vp]
     l.lwkzg_fr_ntt4096_device.argtypes = [vp, vp, sz, ci, ps, vp]
     l.lwkzg_setup_image_bytes.restype = sz
@@ -133,13 +134,13 @@ _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 _libc.fclose.argtypes = [C.c_void_p]
 
 
-def direct_table_bytes(window_bits):
-    """HBM footprint of the direct table of that width (112-byte rows)."""
+def direct_table_bytes(window_bits, row_bytes=112):
+    """HBM footprint of the direct table of that width with packed (112-byte) or line-aligned (128-byte) rows."""
     nw = lib().lwkzg_direct_num_windows(window_bits)
     if nw == 0:
         return 0
     top = 255 - window_bits * (nw - 1)
-    return ((nw - 1) * 4096 * (1 << (window_bits - 1)) + 4096 * (1 << top)) * 112
+    return ((nw - 1) * 4096 * (1 << (window_bits - 1)) + 4096 * (1 << top)) * row_bytes
 
 
 def set_mode(mode):
@@ -217,6 +218,10 @@ class TrustedSetup:
 
     def direct_table_bits(self):
         return lib().lwkzg_direct_table_bits(self.ref())
+
+    def direct_row_bytes(self):
+        """128 = table rows aligned to 128-byte lines, 112 = packed, 0 = bucket engine."""
+        return lib().lwkzg_direct_row_bytes(self.ref())
 
     def free(self):
         if self._loaded:

@@ -5,10 +5,11 @@
 // sum of one table row per (scalar, window): 4096 * ceil(255 / C) mixed additions -- 65,536 for C = 16,
 // 69,632 for C = 15 -- with no digit sort, no bucket array and no bucket reduction (the bucket path of
 // msm.hip spends 81,920 additions plus ~15 % on sort + reduction). The table is 4096 * 16 * 32768 * 112 B =
-// 240 GB for C = 16, 135 GB for C = 15, 68 GB for C = 14; its rows are gathered at random, 112 contiguous
+// 240 GB for C = 16, 135 GB for C = 15, 68 GB for C = 14 (8/7 of that with every row in a 128-byte line of its own,
+// the layout used whenever it fits: kernels.h); its rows are gathered at random, 112 contiguous
 // bytes per lane, which HBM sustains at 1.3e10 rows/s for tables of this size (tools/gather_bench.hip),
-// twice what the arithmetic can consume. It is opt-in (lwkzg_enable_direct_table): the default engine keeps
-// the 9 MB bucket-path table so that several settings objects can coexist.
+// twice what the arithmetic can consume. A load selects a 13 .. 10-bit table by itself (engine.hip:
+// direct_from_env); the wider ones are opt-in (lwkzg_enable_direct_table).
 //
 // Replaces, like msm.hip, lambdaworks_math::msm::pippenger::msm as reached from KZG::commit / KZG::open
 // (call sites /root/reference/src/lib.rs:242,270,329,394).
@@ -87,7 +88,8 @@ constexpr int kChunk = 64;
 
 // M = rows per (window, point) pair in this launch (a power of two)
 __global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restrict__ qbase_win0, G1Affine29 *__restrict__ out_win0,
-                                                      size_t n_pairs, F29<2> *__restrict__ scratch, size_t n_threads, int M) {
+                                                      size_t n_pairs, F29<2> *__restrict__ scratch, size_t n_threads, int M,
+                                                      size_t row_bytes) {
     const int K = M < kChunk ? M : kChunk;
     const size_t kChunksPerPair = (size_t)(M / K);
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restri
             if (m < K - 1) cur = xyzz_madd(cur, q.x, q.y);
         }
         F29<2> inv = f29_inv(pref);
-        G1Affine29 *rows = out_win0 + pair * (size_t)M + (s0 - 1);
+        char *rows = (char *)out_win0 + (pair * (size_t)M + (s0 - 1)) * row_bytes;
         for (int m = K - 1; m >= 0; m--) {
             F29<2> zz = slot(m, 2), zzz = slot(m, 3);
             F29<2> tinv = (m > 0) ? F29<2>(inv * slot(m - 1, 4)) : inv;  // 1 / (ZZ ZZZ) of row m
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restri
             G1Affine29 r;
             r.x = slot(m, 0) * (tinv * zzz);  // X / ZZ
             r.y = slot(m, 1) * (tinv * zz);   // Y / ZZZ
-            rows[m] = r;
+            *(G1Affine29 *)(rows + (size_t)m * row_bytes) = r;
         }
     }
 }
 
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st) {
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st) {
     const DirectPlanRt P = make_plan(bits);
     if (!P.entries) return hipErrorInvalidValue;
     G1Affine29 *qbase = nullptr;
@@ -148,10 +150,10 @@ hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *tabl
         {
             ProfScope p("k_direct_build", st);
             hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase, table,
-                               (size_t)(P.nw - 1) * kBlobElems, scratch, n_threads, (int)P.h);
+                               (size_t)(P.nw - 1) * kBlobElems, scratch, n_threads, (int)P.h, row_bytes);
             hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st,
-                               qbase + (size_t)(P.nw - 1) * kBlobElems, table + P.top_base, (size_t)kBlobElems, scratch,
-                               n_threads, (int)P.htop);
+                               qbase + (size_t)(P.nw - 1) * kBlobElems, (G1Affine29 *)((char *)table + P.top_base * row_bytes),
+                               (size_t)kBlobElems, scratch, n_threads, (int)P.htop, row_bytes);
         }
         e = hipStreamSynchronize(st);
     }
@@ -193,7 +195,7 @@ template <int CT>
 __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
                                                                    const uint4 *__restrict__ scalars,
                                                                    G1Xyzz29 *__restrict__ partials, int scalars_per_lane,
-                                                                   DirectPlanRt rt) {
+                                                                   DirectPlanRt rt, uint32_t row_bytes) {
     const DirectPlanRt P = CT ? PlanOf<CT ? CT : 16>::get() : rt;  // folds to constants when CT != 0
     const int C = P.c;
     __shared__ uint32_t limbs[8 * kDirThreads];   // the lane's current scalar, for run-time window indexing
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
             if (mag && jw >= w_lo && jw < w_hi) {
                 valid = true;
                 neg = ng;
-                row = tab[idx];
+                row = *(const G1Affine29i *)((const char *)tab + idx * row_bytes);
                 return;
             }
         }
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__
 }
 
 template <int CT>
-static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials,
-                            G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
+static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw,
+                            G1Xyzz29 *partials, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
     // 16 workgroups so the chip fills and the dependent chain per lane stays short. `fill` = the number of workgroups
     // to aim for: 512 (two per compute unit, one round) when the kernel has the chip alone; 2048 when the settings
@@ -304,7 +306,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, c
     {
         ProfScope p("k_direct_accumulate", st);
         hipLaunchKernelGGL(k_direct_accumulate<CT>, dim3(blocks_per_blob, (unsigned)n_blobs, wsplit), dim3(kDirThreads), 0, st,
-                           table, (const uint4 *)scalars_raw, parts == 1 ? sums : partials, scalars_per_lane, plan);
+                           table, (const uint4 *)scalars_raw, parts == 1 ? sums : partials, scalars_per_lane, plan, (uint32_t)row_bytes);
     }
     if (parts > 1) {
         ProfScope p("k_direct_fold", st);
@@ -312,15 +314,15 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, c
     }
 }
 
-void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
-                       size_t n_blobs, hipStream_t st, int fill) {
+void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *partials,
+                       G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
     const DirectPlanRt plan = make_plan(bits);
     if (!plan.entries) return;
     switch (bits) {
-        case 14: launch_direct_t<14>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;
-        case 15: launch_direct_t<15>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;
-        case 16: launch_direct_t<16>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;
-        default: launch_direct_t<0>(plan, table, scalars_raw, partials, sums, n_blobs, st, fill); break;  // 10 .. 13
+        case 14: launch_direct_t<14>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;
+        case 15: launch_direct_t<15>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;
+        case 16: launch_direct_t<16>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;
+        default: launch_direct_t<0>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;  // 10 .. 13
     }
 }
 

@@ -185,6 +185,7 @@ struct Ctx {
     G1Affine29 *table;  // kTablePoints, hot-loop representation
     G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled
     int direct_bits;           // 14 / 15 / 16 when direct_table is live, else 0
+    size_t direct_row_bytes;   // 128 (every row in a line of its own) or 112 (packed), see kernels.h
     Fr *tw_fwd, *tw_inv;
     Fr28 *tw28_fwd, *tw28_inv;  // the same twiddles in the transform's own arithmetic (fr28.cuh)
     Workspace ws;

@@ -294,6 +294,7 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
     c->table = nullptr;
     c->direct_table = nullptr;
     c->direct_bits = 0;
+    c->direct_row_bytes = kDirectRowPacked;
     c->vs_cap = 0;
     c->tw_fwd = c->tw_inv = nullptr;
     c->tw28_fwd = c->tw28_inv = nullptr;
@@ -317,6 +318,7 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
         c->table = twin_of->table;
         c->direct_table = twin_of->direct_table;
         c->direct_bits = twin_of->direct_bits;
+        c->direct_row_bytes = twin_of->direct_row_bytes;
         c->tw_fwd = twin_of->tw_fwd;
         c->tw_inv = twin_of->tw_inv;
         c->tw28_fwd = twin_of->tw28_fwd;
@@ -494,7 +496,7 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
     G1Xyzz29 *sums = w.sums + base;
     if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
-        launch_direct_msm(c->direct_bits, c->direct_table, scalars_raw, buckets, sums, n, st, c->primary->twin ? 2048 : 0);
+        launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, sums, n, st, c->primary->twin ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
@@ -2020,11 +2022,13 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
         c->twin->direct_bits = 0;
     }
     if (window_bits == 0) return C_KZG_OK;
-    auto build = [&](int bits) -> hipError_t {
+    // rows aligned to 128-byte lines when that table leaves kDirectAlignedHeadroom of HBM free (workspaces, the caller's
+    // own buffers), packed otherwise; LWKZG_DIRECT_ROW=112|128 forces one (A/B runs)
+    auto build_rows = [&](int bits, size_t row) -> hipError_t {
         G1Affine29 *t = nullptr;
-        hipError_t e = hipMalloc((void **)&t, direct_table_entries(bits) * sizeof(G1Affine29));
+        hipError_t e = hipMalloc((void **)&t, direct_table_entries(bits) * row);
         if (e == hipSuccess) {
-            e = build_direct_table(bits, c->points, t, c->stream);
+            e = build_direct_table(bits, c->points, t, row, c->stream);
             if (e != hipSuccess) hipFree(t);
         }
         if (e != hipSuccess) {
@@ -2033,16 +2037,27 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
         }
         c->direct_table = t;
         c->direct_bits = bits;
+        c->direct_row_bytes = row;
         if (c->twin) {
             c->twin->direct_table = t;
             c->twin->direct_bits = bits;
+            c->twin->direct_row_bytes = row;
         }
         return hipSuccess;
+    };
+    auto build = [&](int bits) -> hipError_t {
+        static const int forced = getenv("LWKZG_DIRECT_ROW") ? atoi(getenv("LWKZG_DIRECT_ROW")) : 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
+        const bool aligned_fits = direct_table_entries(bits) * kDirectRowAligned + kDirectAlignedHeadroom <= free_b;
+        if (forced == (int)kDirectRowAligned || (forced != (int)kDirectRowPacked && aligned_fits))
+            if (build_rows(bits, kDirectRowAligned) == hipSuccess) return hipSuccess;
+        return build_rows(bits, kDirectRowPacked);
     };
     const hipError_t e = build(window_bits);
     if (e != hipSuccess) {
         if (old_bits) (void)build(old_bits);  // the engine the settings had stays in place
-        set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, direct_table_entries(window_bits) * sizeof(G1Affine29),
+        set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, direct_table_entries(window_bits) * kDirectRowPacked,
                   hipGetErrorString(e));
         return C_KZG_MALLOC;
     }
@@ -2055,6 +2070,11 @@ int lwkzg_direct_table_bits(const KZGSettings *s) {
 }
 
 int lwkzg_direct_num_windows(int window_bits) { return direct_num_windows(window_bits); }
+
+int lwkzg_direct_row_bytes(const KZGSettings *s) {
+    Ctx *c = ctx_of(s);
+    return !c ? -1 : c->direct_table ? (int)c->direct_row_bytes : 0;
+}
 
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void *blobs_dev, size_t n, const KZGSettings *s,
                                                     void *stream, int32_t *status_dev) {
@@ -2251,7 +2271,7 @@ namespace lwk {
 // Which MSM engine a freshly loaded setup gets. A consumer that only knows the reference's nine symbols never calls
 // lwkzg_enable_direct_table, so the choice is made here, at the end of every load:
 //   LWKZG_DIRECT_BITS unset : the DEFAULT engine = the widest direct table of 13 .. 10 bit windows that takes at most a
-//                             quarter of the device memory that is free right now (13 bits = 36 GB on an empty MI355X:
+//                             quarter of the device memory that is free right now (13 bits = 41 GB on an empty MI355X:
 //                             20 additions per scalar, no sort, no buckets, no reduction); the bucket engine when
 //                             even the 10-bit table (6 GB) does not pass that test, e.g. beside another process's table
 //   LWKZG_DIRECT_BITS=0     : the bucket engine (9 MB table), whatever is free
@@ -2274,7 +2294,7 @@ void direct_from_env(const KZGSettings *s) {
         return;
     }
     for (int bits = 13; bits >= kDirectMinBits; bits--)
-        if (direct_table_entries(bits) * sizeof(G1Affine29) <= free_b / 4) {
+        if (direct_table_entries(bits) * kDirectRowAligned <= free_b / 4) {
             if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
         }
 }

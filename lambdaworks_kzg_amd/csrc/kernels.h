@@ -37,16 +37,21 @@ void launch_sum_points(const G1Xyzz29 *in, size_t n, G1Xyzz29 *total, int accumu
 void launch_finalize_compress(const G1Xyzz29 *sums, uint8_t *out48, size_t n, hipStream_t st);
 
 // ---- direct fixed-base MSM (direct.hip): every multiple d * 2^(bits j) * P_i precomputed, no buckets.
-// bits in 10 .. 16; the table has direct_table_entries(bits) rows of 112 bytes
-// (6 / 11 / 21 / 36 / 68 / 135 / 240 GB); 0 rows for any other width.
+// bits in 10 .. 16; the table has direct_table_entries(bits) rows of 112 bytes, kDirectRowAligned or kDirectRowPacked apart
+// (packed: 6 / 11 / 21 / 36 / 68 / 135 / 240 GB); 0 rows for any other width.
 constexpr int kDirectMinBits = 10, kDirectMaxBits = 16;
+// bytes from one row of the direct table to the next: 128 = every row in a 128-byte line of its own (a gather touches one
+// line; +2.5 % at 13 bits, +5 % at 15, +1.4 % at 16, profiles/r02_experiments.md section 9), or 112 = the affine point
+// itself, packed (7 of 8 rows straddle two lines), when the aligned table would not leave headroom in HBM
+constexpr size_t kDirectRowAligned = 128, kDirectRowPacked = 112;
+constexpr size_t kDirectAlignedHeadroom = (size_t)8 << 30;  // what an aligned table must leave free (two workspaces, verification scratch, the caller's buffers)
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, hipStream_t st);
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st);
 // sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused otherwise).
 // fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
-void launch_direct_msm(int bits, const G1Affine29 *table, const uint32_t *scalars_raw, G1Xyzz29 *partials, G1Xyzz29 *sums,
-                       size_t n_blobs, hipStream_t st, int fill = 0);
+void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *partials,
+                       G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0);
 
 // ---- setup (setup.hip)
 // 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check

@@ -178,6 +178,8 @@ def test_direct_table_plan_constants(K):
     assert capi.direct_table_bytes(14) == (18 * 4096 * 8192 + 4096 * 8) * 112
     assert capi.direct_table_bytes(13) == (19 * 4096 * 4096 + 4096 * 256) * 112 == 35_819_356_160   # the default engine on an empty MI355X
     assert capi.direct_table_bytes(10) == (25 * 4096 * 512 + 4096 * 32) * 112
+    # rows aligned to 128-byte lines (chosen when the table leaves 8 GiB of the device free): 8/7 of the packed size
+    assert capi.direct_table_bytes(13, 128) == 40_936_407_040 and capi.direct_table_bytes(16, 128) == 274_877_906_944
     for bits in range(10, 17):   # every scalar bit is covered exactly once: (NW - 1) * bits + top == 255
         nw = l.lwkzg_direct_num_windows(bits)
         assert 0 < 255 - bits * (nw - 1) <= bits

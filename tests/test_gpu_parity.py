@@ -671,6 +671,7 @@ def direct_setup(request, K, gpu_setup, bucket_setup):
         assert free_b < capi.direct_table_bytes(request.param) + (12 << 30), (request.param, free_b)
         pytest.skip("direct table of width %d does not fit on this device (%d GB free)" % (request.param, free_b >> 30))
     assert ts.direct_table_bits() == request.param
+    assert ts.direct_row_bytes() in (112, 128)                   # aligned rows when they leave headroom, packed otherwise
     yield ts, request.param
     ts.enable_direct_table(0)
     assert ts.direct_table_bits() == 0
