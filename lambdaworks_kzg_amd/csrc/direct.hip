@@ -248,6 +248,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
             if (mag && jw >= w_lo && jw < w_hi) {
                 valid = true;
                 neg = ng;
+                // (plain loads: with the nt hint the seven loads of a row no longer meet in the cache, -7 %)
                 row = *(const G1Affine29i *)((const char *)tab + idx * row_bytes);
                 return;
             }
