@@ -436,8 +436,9 @@ def main():
             traffic = None
         roofline["traffic"] = traffic
         roofline["traffic_source"] = traffic_source
-        roofline["traffic_note"] = ("bytes per launch at the L2's memory side from rocprofv3 FETCH_SIZE (raw) + WRITE_SIZE, separate passes; " +
-                                    ("random 112-byte row gathers out of the direct table, see DESIGN.md section 4" if direct_bits else
+        roofline["traffic_note"] = ("bytes per launch at the L2's memory side from rocprofv3 2 x FETCH_SIZE (gfx950: 128-byte requests are tallied at 64 bytes) "
+                                    "+ WRITE_SIZE, separate passes; " +
+                                    ("one 128-byte line per gathered table row (1.75 lines per row with packed 112-byte rows), see DESIGN.md section 4" if direct_bits else
                                      "mostly Infinity-Cache-served re-reads of the 9.2 MB fixed-base table, see DESIGN.md section 4"))
         res = {
             "metric": {"commit": "blob_to_kzg_commitment ops/sec (4096-elem blobs)",

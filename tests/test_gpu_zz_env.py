@@ -55,3 +55,24 @@ def test_plain_hash_kernel_still_agrees(K, gpu_setup):
             % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH, n))
     out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, LWKZG_HASH_PAIRS="0")).decode().split()
     assert out[-1] == want
+
+
+def test_packed_and_aligned_table_rows_agree(K, gpu_setup):
+    """The direct table's rows sit 128 bytes apart (one line per gather) when that table leaves headroom on the device,
+    112 bytes apart (packed) otherwise; LWKZG_DIRECT_ROW forces either. Same commitments and proofs from both layouts
+    (fresh processes: the choice is read once), and the loaded setup of this suite reports the layout it got."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    assert gpu_setup.direct_row_bytes() in (112, 128)
+    blob = B.synthetic_blob(4343)
+    comm = K.blob_to_kzg_commitment(blob, gpu_setup)
+    want = [comm.hex(), K.compute_blob_kzg_proof(blob, comm, gpu_setup).hex()]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import blobs as B; import lambdaworks_kzg_amd as K; "
+            "ts = K.TrustedSetup.from_file(%r); b = B.synthetic_blob(4343); c = K.blob_to_kzg_commitment(b, ts); "
+            "print(ts.direct_row_bytes(), c.hex(), K.compute_blob_kzg_proof(b, c, ts).hex())"
+            % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH))
+    for row in ("112", "128"):
+        out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, LWKZG_DIRECT_ROW=row)).decode().split()
+        assert out[-3:] == [row] + want, (row, out[-3:])

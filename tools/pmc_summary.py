@@ -7,11 +7,13 @@ roofline.traffic.
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     python tools/pmc_summary.py out/fetch_counter_collection.csv out/write_counter_collection.csv rNN [blobs_per_launch [direct_bits]]
 
-Units: the counters are in KiB. gfx950 correction (guide, section HBM): FETCH_SIZE tallies 128-byte
-requests at 64 bytes for wide coalesced streams, i.e. reads exactly half; for this kernel's per-lane
-112-byte gathers the factor is uncalibrated, so both the raw and the doubled read side are recorded and
-`traffic_bytes` uses the raw read side (a lower bound). Infinity-Cache hits appear to be counted: this is
-traffic at the L2's memory side, not necessarily HBM.
+Units: the counters are in KiB. gfx950 correction (guide, section HBM): FETCH_SIZE is the L2's memory-side read REQUEST
+count times 64 bytes, so 128-byte requests read exactly half: double it. Calibrated on this kernel's own pattern in round
+2: with every table row in a 128-byte line of its own a launch shows 1.013 requests per gathered row (the 0.013 are the
+scalars), i.e. doubled = one line per row; with packed 112-byte rows the same counter showed 1.75 requests per row (a row
+straddles a line boundary seven times out of eight) -- whose raw figure happens to equal the payload, 1.75 x 64 = 112,
+which round 1 mistook for a calibration. `traffic_bytes` = 2 x FETCH_SIZE + WRITE_SIZE. Infinity-Cache hits appear to be
+counted: this is traffic at the L2's memory side, not necessarily HBM.
 """
 import collections
 import csv
@@ -40,13 +42,13 @@ def main():
         if not k.startswith("k_"):
             continue
         fr, wr = f.get(k, 0.0), w.get(k, 0.0)
-        out["kernels"][k] = {"fetch_raw": fr, "fetch_doubled": 2 * fr, "write": wr, "traffic_bytes": fr + wr}
+        out["kernels"][k] = {"fetch_raw": fr, "fetch_requests": fr / 64.0, "fetch_doubled": 2 * fr, "write": wr, "traffic_bytes": 2 * fr + wr}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", "pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)
     for k, v in out["kernels"].items():
-        print("  %-26s fetch %.3e  write %.3e" % (k, v["fetch_raw"], v["write"]))
+        print("  %-26s read requests %.3e (x 128 B = %.3e)  write %.3e" % (k, v["fetch_requests"], v["fetch_doubled"], v["write"]))
 
 
 if __name__ == "__main__":
