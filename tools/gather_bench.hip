@@ -1,13 +1,17 @@
 // tools/gather_bench.hip -- can HBM serve the gathers of a giant fixed-base table?
 // Each lane reads 112 contiguous bytes (7 x 16 B) at a pseudo-random row of a table of `gib` GiB, `iters` times,
 // with the next row's loads issued before the current row is consumed. Reports rows/s and GB/s.
+// hipcc --offload-arch=gfx950 -O3 [-DROW_PAD=1] tools/gather_bench.hip -o tools/gather_bench_bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-struct Row { uint4 v[7]; };
+#ifndef ROW_PAD   // -DROW_PAD=1: rows 128 bytes apart (one line each) instead of packed at 112
+#define ROW_PAD 0
+#endif
+struct Row { uint4 v[7 + ROW_PAD]; };
 
 __global__ __launch_bounds__(256) void k_gather(const Row *__restrict__ table, uint64_t nrows, int iters, int alu, uint32_t *out) {
     uint64_t s = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
