@@ -2000,7 +2000,8 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch) {
     return ctx_reserve(c, max_batch);
 }
 
-C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
+// row_pref: 0 = rows aligned to 128-byte lines when that leaves headroom on the device, else packed; or one of the two
+static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size_t row_pref) {
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -2046,7 +2047,8 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
         return hipSuccess;
     };
     auto build = [&](int bits) -> hipError_t {
-        static const int forced = getenv("LWKZG_DIRECT_ROW") ? atoi(getenv("LWKZG_DIRECT_ROW")) : 0;
+        static const int forced_env = getenv("LWKZG_DIRECT_ROW") ? atoi(getenv("LWKZG_DIRECT_ROW")) : 0;
+        const int forced = forced_env ? forced_env : (int)row_pref;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
         const bool aligned_fits = direct_table_entries(bits) * kDirectRowAligned + kDirectAlignedHeadroom <= free_b;
@@ -2063,6 +2065,8 @@ C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) {
     }
     return C_KZG_OK;
 }
+
+C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) { return enable_direct_table(s, window_bits, 0); }
 
 int lwkzg_direct_table_bits(const KZGSettings *s) {
     Ctx *c = ctx_of(s);
@@ -2293,9 +2297,12 @@ void direct_from_env(const KZGSettings *s) {
         (void)hipGetLastError();
         return;
     }
-    for (int bits = 13; bits >= kDirectMinBits; bits--)
-        if (direct_table_entries(bits) * kDirectRowAligned <= free_b / 4) {
-            if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
-        }
+    // the widest of 13 .. 10 bits within a quarter of the free memory: with its rows in 128-byte lines if that fits the
+    // quarter too, packed if only that does
+    for (int bits = 13; bits >= kDirectMinBits; bits--) {
+        const size_t rows = direct_table_entries(bits);
+        const size_t pref = rows * kDirectRowAligned <= free_b / 4 ? kDirectRowAligned : rows * kDirectRowPacked <= free_b / 4 ? kDirectRowPacked : 0;
+        if (pref && enable_direct_table(s, bits, pref) == C_KZG_OK) return;
+    }
 }
 }  // namespace lwk
