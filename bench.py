@@ -200,8 +200,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the short untimed-region legs of the commit bench: default engine, bucket engine, host-pointer ABI")
-    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof", "verify_batch", "tiled_msm"],
-                    help="commit = the headline (BASELINE configs[1]); blob_proof = configs[2]; verify_batch = configs[3], host-pointer ABI; tiled_msm = configs[4], one 2^20-term MSM split over the GPUs (strong scaling)")
+    ap.add_argument("--op", default="commit", choices=["commit", "blob_proof", "commit_prove", "verify_batch", "tiled_msm"],
+                    help="commit = the headline (BASELINE configs[1]); blob_proof = configs[2]; commit_prove = commitment AND blob proof of every blob in one pass (lwkzg_commit_and_prove_batch_device); verify_batch = configs[3], host-pointer ABI; tiled_msm = configs[4], one 2^20-term MSM split over the GPUs (strong scaling)")
     ap.add_argument("--mode", default="reference", choices=["reference", "ckzg"],
                     help="reference = lambdaworks_kzg semantics (default, the headline); ckzg = c-kzg-4844 semantics (adds the inverse NTT)")
     ap.add_argument("--direct-bits", default="auto",
@@ -290,6 +290,8 @@ def main():
                                                       cstreams[k].cuda_stream, cstats[k].data_ptr())
         elif args.op == "commit":
             K.blob_to_kzg_commitment_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
+        elif args.op == "commit_prove":
+            K.commit_and_prove_batch_device(d_comm.data_ptr(), d_out.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
         else:
             K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, stream,
                                                   d_status.data_ptr())
@@ -377,6 +379,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_table_max = float(tt.item())
 
+    if args.op == "commit_prove":
+        d_comm = torch.empty(48 * n, dtype=torch.uint8, device=dev)
     if args.op == "blob_proof":
         d_comm = torch.empty(48 * n, dtype=torch.uint8, device=dev)
         K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), n, ts, stream, d_status.data_ptr())
@@ -443,6 +447,7 @@ def main():
         res = {
             "metric": {"commit": "blob_to_kzg_commitment ops/sec (4096-elem blobs)",
                        "blob_proof": "compute_blob_kzg_proof ops/sec (4096-elem blobs)",
+                       "commit_prove": "blob_to_kzg_commitment + compute_blob_kzg_proof pairs/sec (4096-elem blobs, one pass)",
                        "verify_batch": "verify_blob_kzg_proof_batch blobs/sec (4096-elem blobs, host-pointer ABI, PCIe included)",
                        "tiled_msm": "G1 MSM terms/sec (one 2^20-term MSM over the tiled setup)"}[args.op],
             "value": value,
@@ -460,6 +465,8 @@ def main():
                                              "per GPU per step, device-resident, bit-exact vs CPU",
                                    "blob_proof": "BASELINE configs[2]: compute_blob_kzg_proof (Fiat-Shamir hash, quotient, MSM), batch=%d synthetic "
                                                  "blobs per GPU per step, device-resident, one call per step",
+                                   "commit_prove": "a blob producer's pair of calls (BASELINE configs[1] followed by configs[2] on its output) as ONE pass: "
+                                                   "commitment and blob proof of batch=%d synthetic blobs per GPU per step, device-resident",
                                    "verify_batch": "BASELINE configs[3]: verify_blob_kzg_proof_batch, %d synthetic blobs per GPU per step; all ranks' blobs "
                                                    "form ONE batch (one transcript, one r, one pairing check; records and partial sums all-gathered), "
                                                    "blobs in host memory (H2D inside the timed region)",

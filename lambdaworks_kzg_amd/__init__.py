@@ -7,7 +7,7 @@ hand-written HIP kernels for gfx950. See DESIGN.md; the C header is include/lamb
 from .capi import (  # noqa: F401
     BYTES_PER_BLOB, BYTES_PER_COMMITMENT, BYTES_PER_PROOF, C_KZG_BADARGS, C_KZG_ERROR, C_KZG_MALLOC, C_KZG_OK,
     FIELD_ELEMENTS_PER_BLOB, MODE_CKZG, MODE_REFERENCE, KzgError, KZGSettings, TrustedSetup,
-    blob_to_kzg_commitment, blob_to_kzg_commitment_batch, blob_to_kzg_commitment_batch_device,
+    blob_to_kzg_commitment, blob_to_kzg_commitment_batch, blob_to_kzg_commitment_batch_device, commit_and_prove_batch_device,
     compute_blob_kzg_proof, compute_blob_kzg_proof_batch, compute_blob_kzg_proof_batch_device,
     compute_kzg_proof, compute_kzg_proof_batch, get_mode, lib, set_device, set_mode,
     verify_blob_kzg_proof, verify_blob_kzg_proof_batch, verify_kzg_proof,

@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
-    "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
+    "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
     "lwkzg_release_context", "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
 ]
@@ -83,6 +83,7 @@ def lib():
     l.lwkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_challenges_device.argtypes = [vp, vp, vp, sz, ps, vp]
+    l.lwkzg_commit_and_prove_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_verify_shard_begin.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
     l.lwkzg_verify_shard_partial.argtypes = [C.c_char_p, vp, C.c_char_p, sz, sz]
     l.lwkzg_verify_shard_free.argtypes = [vp]
@@ -362,6 +363,13 @@ def blob_to_kzg_commitment_batch_device(out_ptr, blobs_ptr, n, ts, stream=None, 
 def compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts, stream=None, status_ptr=None):
     _check("lwkzg_compute_blob_kzg_proof_batch_device",
            lib().lwkzg_compute_blob_kzg_proof_batch_device(out_ptr, blobs_ptr, comm_ptr, n, ts.ref(), stream, status_ptr))
+
+
+def commit_and_prove_batch_device(comm_ptr, proof_ptr, blobs_ptr, n, ts, stream=None, status_ptr=None):
+    """Commitments and blob proofs of n device-resident blobs in one pass (the hash's commitment-independent part runs
+    beside the commitment MSM); the same bytes as the two separate calls."""
+    _check("lwkzg_commit_and_prove_batch_device",
+           lib().lwkzg_commit_and_prove_batch_device(comm_ptr, proof_ptr, blobs_ptr, n, ts.ref(), stream, status_ptr))
 
 
 def compute_challenges_device(z_ptr, blobs_ptr, comm_ptr, n, ts, stream=None):

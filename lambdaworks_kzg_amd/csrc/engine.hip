@@ -488,7 +488,9 @@ Ctx *ctx_of(const KZGSettings *s) {
 
 // `base` = first workspace slot (in blobs) this launch set may use: sub-batches running on different streams
 // work in disjoint slices of the same workspace.
-static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0) {
+// `shared_chip`: latency-chain kernels of the same call run beside this MSM (the fused commit-and-prove's hash): finer
+// workgroups, as when a twin context exists, so that the compute units they sit on do not set the launch's end
+static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0, bool shared_chip = false) {
     Workspace &w = c->ws;
     uint32_t *sorted = w.sorted + base * (size_t)kMaxEntries;
     uint32_t *bstart = w.bucket_start + base * (size_t)(kNumBuckets + 1);
@@ -496,7 +498,8 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
     G1Xyzz29 *sums = w.sums + base;
     if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
-        launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, sums, n, st, c->primary->twin ? 2048 : 0);
+        launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, sums, n, st,
+                          (c->primary->twin || shared_chip) ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
@@ -505,8 +508,9 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
     return sums;
 }
 
-static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0) {
-    launch_finalize_compress(msm_sums_stage(c, scalars_raw, n, st, base), out48, n, st);
+static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0,
+                       bool shared_chip = false) {
+    launch_finalize_compress(msm_sums_stage(c, scalars_raw, n, st, base, shared_chip), out48, n, st);
 }
 
 // blob bytes -> canonical monomial coefficients in ws.scalars (slots base .. base + n)
@@ -640,6 +644,44 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
             LWK_HIP(hipEventRecord(pr->heavy_done, st));
         }
         launch_finalize_compress(sums, out48 + 48 * off, m, st);
+    }
+    return C_KZG_OK;
+}
+
+// Commitment AND blob proof of every blob in one pass (what a blob producer needs: lib.rs:253-283 followed by
+// lib.rs:361-404 on its own output). Two things a pair of separate calls cannot do: the 2048 blocks of the Fiat-Shamir
+// hash that do not depend on the commitment (all but the last 32 bytes of the blob) run on the side stream BESIDE the
+// commitment MSMs and only the last two blocks wait for the commitments (k_challenge_finish) -- the 3.3 ms hash phase
+// that stands in front of a proof call's MSM disappears -- and the blob is parsed (mode C: transformed) once. The
+// commitments are the library's own output: nothing to validate. Results are those of the two calls, byte for byte.
+C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *proof_out48, const uint8_t *blobs, size_t n, int mode,
+                                        hipStream_t st, int32_t *status) {
+    C_KZG_RET rc = ctx_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    const bool longcall = n > kMaxChunk;
+    if (longcall) {
+        rc = ws_long_reserve(c, n);
+        if (rc != C_KZG_OK) return rc;
+    }
+    Workspace &w = c->ws;
+    const int le = mode == LWKZG_MODE_CKZG;
+    int32_t *stt = status ? status : longcall ? w.status_long : w.status;
+    Fr *z = longcall ? w.z_long : w.z;
+    uint32_t *mid = (uint32_t *)(longcall ? w.canon_long : w.canon48);  // 32 of the 48 bytes per blob this call has no other use for
+    LWK_HIP(hipMemsetAsync(stt, 0, n * 4, st));
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
+    launch_challenge_midstate(blobs, mid, n, c->vstream);  // ALL blobs of the call: a latency chain, as long for 64 blobs as for 16k
+    LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        const uint8_t *b = blobs + off * (size_t)kBlobBytes;
+        coefficients_stage(c, b, m, mode, stt + off, st);
+        msm_stages(c, w.scalars, comm_out48 + 48 * off, m, st, 0, off == 0);  // the first one has the hash beside it
+        if (off == 0) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        launch_challenge_finish(b, comm_out48 + 48 * off, mid + 8 * off, z + off, le, m, st);
+        launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
+        msm_stages(c, w.scalars2, proof_out48 + 48 * off, m, st);
     }
     return C_KZG_OK;
 }
@@ -2103,6 +2145,21 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void 
     WsUse wsu(c, st);
     return blob_proof_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev,
                                    n, mode_now(), st, status_dev);
+}
+
+C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *proofs48_dev, const void *blobs_dev, size_t n,
+                                              const KZGSettings *s, void *stream, int32_t *status_dev) {
+    if (!commitments48_dev || !proofs48_dev || !blobs_dev) return map_rc(C_KZG_BADARGS, mode_now());
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    if (n == 0) return C_KZG_OK;
+    c = pick_ctx(c, (hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    WsUse wsu(c, st);
+    return commit_and_prove_batch_device(c, (uint8_t *)commitments48_dev, (uint8_t *)proofs48_dev, (const uint8_t *)blobs_dev, n,
+                                         mode_now(), st, status_dev);
 }
 
 // z_i = compute_challenge(blob_i, commitment_i) (src/utils.rs:120-154) for device-resident blobs, as 32 bytes in the

@@ -113,6 +113,9 @@ void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const 
 void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from = nullptr);
+void launch_challenge_midstate(const uint8_t *blobs, uint32_t *midstate, size_t n, hipStream_t st);
+void launch_challenge_finish(const uint8_t *blobs, const uint8_t *canon48, const uint32_t *midstate, Fr *z_mont, int le, size_t n,
+                             hipStream_t st);
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 // sha256_host.hip: digests[i] = SHA-256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blobs[i] | comms[i]) on host threads
 void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n);

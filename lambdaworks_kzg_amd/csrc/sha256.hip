@@ -222,9 +222,15 @@ __global__ __launch_bounds__(128) void k_challenge(const uint8_t *__restrict__ b
                        [s3] "v"(s3), [bm] "v"(bm));                                                          \
     }
 
+// MID = true: only the 2048 blocks that do not depend on the commitment (domain, degree and all but the last 32 bytes of
+// the blob) are absorbed, and the chaining value goes to `midstate` (8 words per blob) instead of a challenge: the fused
+// commit-and-prove entry point runs this beside the commitment MSM and finishes with k_challenge_finish once the
+// commitments exist.
+template <bool MID>
 __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
                                                          Fr *__restrict__ z_mont, int le, size_t n,
-                                                         const uint8_t *__restrict__ only_if_differs_from, int prio) {
+                                                         const uint8_t *__restrict__ only_if_differs_from, int prio,
+                                                         uint32_t *__restrict__ midstate) {
     // waves 0, 1: producers (all 64 blobs each; wave 0 expands the even blocks, wave 1 the odd ones, half a block
     // per barrier interval, so a block has two intervals to get ready); waves 2, 3: consumers (32 blobs each, two
     // lanes per blob). Block b is written in intervals b and b + 1 and read in interval b + 2: three LDS buffers.
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restri
     if (threadIdx.x == 0) zero4 = make_uint4(0u, 0u, 0u, 0u);
     if (!__syncthreads_or(active)) return;
 
-    constexpr int kBlocks = (2 + kBlobBytes / 16 + 3 + 3) / 4;  // 2050
+    constexpr int kBlocks = MID ? 2048 : (2 + kBlobBytes / 16 + 3 + 3) / 4;  // 2050 for the whole message
     // consumer state: (e, f, g, h) on the e half, (a, b, c, d) on the a half; hv = the chaining values of that half
     uint32_t hv0 = a_half ? 0x6a09e667u : 0x510e527fu, hv1 = a_half ? 0xbb67ae85u : 0x9b05688cu,
              hv2 = a_half ? 0x3c6ef372u : 0x1f83d9abu, hv3 = a_half ? 0xa54ff53au : 0x5be0cd19u;
@@ -339,6 +345,11 @@ __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restri
                    p3 = __shfl_xor(hv3, 8, 64);
     if (a_half || !active) return;
     const uint32_t h[8] = {p0, p1, p2, p3, hv0, hv1, hv2, hv3};
+    if constexpr (MID) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) midstate[8 * i + k] = h[k];
+        return;
+    }
     uint32_t sdig[8];
     if (le) {
 #pragma unroll
@@ -357,11 +368,71 @@ void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, 
     static const int prio = getenv("LWKZG_HASH_PRIO") ? atoi(getenv("LWKZG_HASH_PRIO")) : 1;
     ProfScope p(only_if_differs_from ? "k_challenge_fixup" : "k_challenge", st);
     if (pairs)
-        hipLaunchKernelGGL(k_challenge_pairs, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, canon48, z_mont, le, n,
-                           only_if_differs_from, prio);
+        hipLaunchKernelGGL(k_challenge_pairs<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, canon48, z_mont, le, n,
+                           only_if_differs_from, prio, (uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(k_challenge, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, st, blobs, canon48, z_mont, le, n,
                            only_if_differs_from);
+}
+
+// ---- the challenge in two parts (fused commit-and-prove: engine.hip) ------------------------------------------------
+// part 1: everything the commitment does not touch (2048 of the 2050 blocks), beside the commitment MSM
+void launch_challenge_midstate(const uint8_t *blobs, uint32_t *midstate, size_t n, hipStream_t st) {
+    if (n == 0) return;
+    static const int prio = getenv("LWKZG_HASH_PRIO") ? atoi(getenv("LWKZG_HASH_PRIO")) : 1;
+    ProfScope p("k_challenge_midstate", st);
+    hipLaunchKernelGGL(k_challenge_pairs<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, (const uint8_t *)nullptr,
+                       (Fr *)nullptr, 0, n, (const uint8_t *)nullptr, prio, midstate);
+}
+
+// part 2: the last two blocks (32 bytes of blob, the 48 commitment bytes, padding and length), one lane per blob
+__global__ __launch_bounds__(64) void k_challenge_finish(const uint8_t *__restrict__ blobs, const uint8_t *__restrict__ canon48,
+                                                         const uint32_t *__restrict__ midstate, Fr *__restrict__ z_mont, int le,
+                                                         size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    __builtin_amdgcn_s_setprio(2);
+    const uint4 *blob = (const uint4 *)(blobs + (size_t)kBlobBytes * i);
+    const uint4 *comm = (const uint4 *)(canon48 + 48 * i);
+    uint32_t h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = midstate[8 * i + k];
+    for (int blk = 2048; blk < 2050; blk++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 c = challenge_chunk(4 * blk + q, blob, comm);
+            w[4 * q] = c.x; w[4 * q + 1] = c.y; w[4 * q + 2] = c.z; w[4 * q + 3] = c.w;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            if (r >= 16) {
+                const uint32_t w15 = w[(r - 15) & 15], w2 = w[(r - 2) & 15];
+                w[r & 15] += (rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3)) + w[(r - 7) & 15] + (rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10));
+            }
+            const uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + kShaK[r] + w[r & 15];
+            const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    uint32_t sdig[8];
+    if (le) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sdig[k] = __builtin_bswap32(h[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sdig[k] = h[7 - k];
+    }
+    z_mont[i] = fe_from_raw<FrParams>(sdig);  // reduced mod r
+}
+
+void launch_challenge_finish(const uint8_t *blobs, const uint8_t *canon48, const uint32_t *midstate, Fr *z_mont, int le, size_t n,
+                             hipStream_t st) {
+    if (n == 0) return;
+    ProfScope p("k_challenge_finish", st);
+    hipLaunchKernelGGL(k_challenge_finish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, blobs, canon48, midstate, z_mont, le, n);
 }
 
 // host SHA-256 for the one batch-level hash of verify_blob_kzg_proof_batch (compute_r_powers,

@@ -369,3 +369,66 @@ def test_concurrent_single_point_proofs_are_coalesced(K, gpu_setup, oracle, orac
         print("coalesced single point proofs (%s): %.0f proofs/s from %d threads" % (mode_name, n_threads * per_thread / el, n_threads))
     finally:
         K.set_mode(K.MODE_REFERENCE)
+
+
+@pytest.mark.parametrize("mode_name", ["reference", "ckzg"])
+@pytest.mark.parametrize("n", [1, 65, 256, 1024, 2100])
+def test_commit_and_prove_in_one_pass_equals_the_two_calls(K, gpu_setup, bucket_setup, oracle, oracle_setup, n, mode_name):
+    """lwkzg_commit_and_prove_batch_device -- the challenge hash's commitment-independent 2048 blocks beside the
+    commitment MSM, the last two blocks (k_challenge_finish) once the commitments exist -- returns the bytes of
+    blob_to_kzg_commitment followed by compute_blob_kzg_proof: against the two device calls on every blob (default
+    engine, and the bucket engine at 65), against the CPU oracle on a spread, and the challenges against hashlib
+    through the separate hash entry point (n = 2100: a call of three chunks)."""
+    import torch
+    ckzg = mode_name == "ckzg"
+    K.set_mode(K.MODE_CKZG if ckzg else K.MODE_REFERENCE)
+    try:
+        data = B.synthetic_batch(120000 + n, n, big_endian=not ckzg)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        for ts in ([gpu_setup, bucket_setup] if n == 65 else [gpu_setup]):
+            c1 = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+            p1 = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+            c2 = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+            p2 = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+            st = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+            K.blob_to_kzg_commitment_batch_device(c1.data_ptr(), d_in.data_ptr(), n, ts, None, None)
+            K.compute_blob_kzg_proof_batch_device(p1.data_ptr(), d_in.data_ptr(), c1.data_ptr(), n, ts, None, None)
+            K.commit_and_prove_batch_device(c2.data_ptr(), p2.data_ptr(), d_in.data_ptr(), n, ts, None, st.data_ptr())
+            torch.cuda.synchronize()
+            assert int(st.abs().sum().item()) == 0
+            assert torch.equal(c1, c2), "commitments differ"
+            assert torch.equal(p1, p2), "proofs differ"
+        comm = bytes(c2.cpu().numpy().tobytes())
+        proof = bytes(p2.cpu().numpy().tobytes())
+        omode = oracle.MODE_C if ckzg else oracle.MODE_R
+        for i in sorted({0, n // 2, n - 1}):
+            blob = data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
+            assert oracle.blob_to_kzg_commitment(blob, oracle_setup, omode) == (0, comm[48 * i:48 * i + 48])
+            assert oracle.compute_blob_kzg_proof(blob, comm[48 * i:48 * i + 48], oracle_setup, omode) == (0, proof[48 * i:48 * i + 48])
+    finally:
+        K.set_mode(K.MODE_REFERENCE)
+
+
+def test_commit_and_prove_flags_a_non_canonical_blob(K, gpu_setup):
+    """c-kzg mode: a blob with an element >= r is marked in the status array by the fused entry point as well; its
+    neighbours get their results."""
+    import torch
+    K.set_mode(K.MODE_CKZG)
+    try:
+        n = 5
+        blobs = [bytearray(B.synthetic_blob(130000 + i, big_endian=False)) for i in range(n)]
+        blobs[3][32 * 100:32 * 101] = b"\xff" * 32
+        data = b"".join(bytes(b) for b in blobs)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        c = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+        p = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+        st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        K.commit_and_prove_batch_device(c.data_ptr(), p.data_ptr(), d_in.data_ptr(), n, gpu_setup, None, st.data_ptr())
+        torch.cuda.synchronize()
+        assert [int(x != 0) for x in st.cpu().tolist()] == [0, 0, 0, 1, 0]
+        for i in (0, 4):
+            want_c = K.blob_to_kzg_commitment(bytes(blobs[i]), gpu_setup)
+            assert bytes(c[48 * i:48 * i + 48].cpu().numpy().tobytes()) == want_c
+            assert bytes(p[48 * i:48 * i + 48].cpu().numpy().tobytes()) == K.compute_blob_kzg_proof(bytes(blobs[i]), want_c, gpu_setup)
+    finally:
+        K.set_mode(K.MODE_REFERENCE)

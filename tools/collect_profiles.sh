@@ -14,6 +14,8 @@ python bench.py --op blob_proof --batch 1024 --no-cpu-baseline > $O/bench_line_b
 python bench.py --op blob_proof --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_blob_proof_b4096.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 256 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b256_two_streams.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 1024 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b1024_two_streams.json 2>> $O/bench_err.txt
+python bench.py --op commit_prove --batch 256 --no-cpu-baseline > $O/bench_line_commit_prove_b256.json 2>> $O/bench_err.txt
+python bench.py --op commit_prove --batch 1024 --no-cpu-baseline > $O/bench_line_commit_prove_b1024.json 2>> $O/bench_err.txt
 python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_verify_batch_b4096.json 2>> $O/bench_err.txt
 python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
 # per-kernel time of the headline command, of the default engine and of the bucket engine

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/final; P=profiles; TAG=${1:-r02}
 for f in bench_line bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
-         bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_verify_batch_b4096 bench_line_tiled_msm; do
+         bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm; do
   [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${TAG}_$f.json
 done
 for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
