@@ -219,6 +219,8 @@ def main():
                     help="experiment: the host synchronizes and sleeps this long before every step (is a kernel slower after an idle gap?)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     args = ap.parse_args()
+    if args.op == "commit_prove" and args.caller_streams > 1:
+        ap.error("--op commit_prove runs on one caller stream")
 
     import numpy as np
     import torch
