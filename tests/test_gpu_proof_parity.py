@@ -251,8 +251,11 @@ def test_everything_at_once_on_one_settings_object(K, gpu_setup, oracle):
         p = torch.zeros(48 * 48, dtype=torch.uint8, device="cuda")
 
         def fn(k):
-            K.blob_to_kzg_commitment_batch_device(o.data_ptr(), d_blobs.data_ptr(), 48, ts, stream.cuda_stream, None)
-            K.compute_blob_kzg_proof_batch_device(p.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), 48, ts, stream.cuda_stream, None)
+            if k % 3 == 2:      # every third round: both in one pass (the hash's first 2048 blocks beside the commitment MSM)
+                K.commit_and_prove_batch_device(o.data_ptr(), p.data_ptr(), d_blobs.data_ptr(), 48, ts, stream.cuda_stream, None)
+            else:
+                K.blob_to_kzg_commitment_batch_device(o.data_ptr(), d_blobs.data_ptr(), 48, ts, stream.cuda_stream, None)
+                K.compute_blob_kzg_proof_batch_device(p.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), 48, ts, stream.cuda_stream, None)
             stream.synchronize()
             assert _host(o) == cj and _host(p) == pj
         return fn
