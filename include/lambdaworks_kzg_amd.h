@@ -121,7 +121,8 @@ C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Byte
 C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commitment_bytes,
                                 const Bytes48 *proof_bytes, const KZGSettings *s);
 
-/* src/lib.rs:525-614. n == 0 -> C_KZG_OK with *ok = false (reference behaviour, src/lib.rs:538-543). */
+/* src/lib.rs:525-614. n == 0 -> C_KZG_OK with *ok = false in reference mode (src/lib.rs:538-543) and *ok = true in
+ * c-kzg mode (the reference's own vector verify_blob_kzg_proof_batch_case_a271b78b8e869d69). */
 C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
                                       const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s);
 
@@ -134,13 +135,16 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
  *   LWKZG_MODE_CKZG: what the c-kzg-4844 vectors under the reference's tests/ encode -- canonical
  *       little-endian scalars are evaluations on the bit-reversed 4096th roots of unity (inverse NTT
  *       in front of the same MSM), little-endian z/y/digest, invalid input is C_KZG_BADARGS.
- * Process-wide; initial value from the environment variable LWKZG_MODE ("reference"|"ckzg"). Every entry point
- * reads the mode once, when it is entered: do not call lwkzg_set_mode while calls whose results should be in a
- * particular mode are in flight on other threads. */
+ * lwkzg_set_mode sets the process-wide DEFAULT (initial value from the environment variable LWKZG_MODE,
+ * "reference"|"ckzg"); lwkzg_settings_set_mode gives ONE settings object a mode of its own, which wins over the default
+ * (mode -1 hands it back to the default), so two consumers in one process can use different semantics. Every entry
+ * point resolves its mode once, when it is entered: a change does not affect calls already in flight. */
 #define LWKZG_MODE_REFERENCE 0
 #define LWKZG_MODE_CKZG 1
-int lwkzg_set_mode(int mode); /* returns the previous mode, or -1 if `mode` is invalid */
+int lwkzg_set_mode(int mode); /* returns the previous default, or -1 if `mode` is invalid */
 int lwkzg_get_mode(void);
+int lwkzg_settings_set_mode(const KZGSettings *s, int mode); /* returns the mode calls on `s` answered in before, -1 on error */
+int lwkzg_settings_get_mode(const KZGSettings *s);           /* the mode a call on `s` would answer in now */
 
 /* For a KZGSettings filled in by hand (fs == NULL and caller-owned g1_values / g2_values, the reference's own layout,
  * src/lib.rs:754-758): the library builds a device context for it on first use and caches it by the g1_values pointer

@@ -38,7 +38,8 @@ EXPORTED_SYMBOLS = [
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof",
     "verify_blob_kzg_proof_batch",
-    "lwkzg_set_mode", "lwkzg_get_mode", "lwkzg_blob_to_kzg_commitment_batch",
+    "lwkzg_set_mode", "lwkzg_get_mode", "lwkzg_settings_set_mode", "lwkzg_settings_get_mode",
+    "lwkzg_blob_to_kzg_commitment_batch",
     "lwkzg_compute_blob_kzg_proof_batch", "lwkzg_compute_kzg_proof_batch",
     "lwkzg_blob_to_kzg_commitment_batch_device", "lwkzg_compute_blob_kzg_proof_batch_device", "lwkzg_reserve",
     "lwkzg_g1_lincomb_setup_device", "lwkzg_fr_ntt4096_device",
@@ -77,6 +78,8 @@ def lib():
     l.verify_blob_kzg_proof.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, ps]
     l.verify_blob_kzg_proof_batch.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
     l.lwkzg_set_mode.argtypes = [ci]
+    l.lwkzg_settings_set_mode.argtypes = [ps, ci]
+    l.lwkzg_settings_get_mode.argtypes = [ps]
     l.lwkzg_blob_to_kzg_commitment_batch.argtypes = [C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
     l.lwkzg_compute_blob_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
     l.lwkzg_compute_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
@@ -212,6 +215,16 @@ class TrustedSetup:
     def reserve(self, n):
         _check("lwkzg_reserve", lib().lwkzg_reserve(self.ref(), n))
 
+    def set_mode(self, mode):
+        """This settings object's own semantics (MODE_REFERENCE / MODE_CKZG; -1 = follow the process-wide default)."""
+        prev = lib().lwkzg_settings_set_mode(self.ref(), mode)
+        if prev < 0:
+            raise KzgError("lwkzg_settings_set_mode", C_KZG_BADARGS)
+        return prev
+
+    def get_mode(self):
+        return lib().lwkzg_settings_get_mode(self.ref())
+
     def enable_direct_table(self, window_bits):
         """Select the direct-table MSM of that width (10 .. 16) or the bucket engine (0); raises KzgError(C_KZG_MALLOC) if
         the table does not fit."""
@@ -290,6 +303,7 @@ class VerifyShard:
     def __init__(self, blobs, commitments_bytes, proofs_bytes, n_local, ts):
         assert len(blobs) == n_local * BYTES_PER_BLOB and len(commitments_bytes) == len(proofs_bytes) == 48 * n_local
         self.n = n_local
+        self.ts = ts  # the shard's device buffers belong to the setup's context: keep it alive as long as the shard
         self.h = C.c_void_p()
         rec = C.create_string_buffer(VERIFY_RECORD_BYTES * max(n_local, 1))
         _check("lwkzg_verify_shard_begin",

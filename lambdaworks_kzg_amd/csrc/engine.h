@@ -193,9 +193,12 @@ struct Ctx {
     size_t vs_cap;
     std::mutex verify_mu;
     std::mutex mu;
+    std::atomic<int> mode_override{-1};  // lwkzg_settings_set_mode: -1 = follow the process-wide default
 };
 
 Ctx *ctx_of(const KZGSettings *s);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise
+
+int mode_of(const KZGSettings *s);    // the semantics a call on `s` answers in: its own mode if it has one, else the default
 
 C_KZG_RET ctx_reserve(Ctx *c, size_t n);
 

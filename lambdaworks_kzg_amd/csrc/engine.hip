@@ -1109,6 +1109,25 @@ static int mode_now() {
     return m;
 }
 
+namespace lwk {
+int mode_of(const KZGSettings *s) {
+    if (s) {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        Ctx *c = nullptr;
+        if (s->fs && g_live_fs.count((const void *)s->fs)) c = (Ctx *)s->fs;
+        else if (s->g1_values) {
+            auto it = g_registry.find(s->g1_values);
+            if (it != g_registry.end()) c = it->second.ctx;
+        }
+        if (c) {
+            const int m = c->mode_override.load(std::memory_order_relaxed);
+            if (m >= 0) return m;
+        }
+    }
+    return mode_now();
+}
+}  // namespace lwk
+
 extern "C" {
 
 int lwkzg_set_mode(int mode) {
@@ -1118,6 +1137,18 @@ int lwkzg_set_mode(int mode) {
     return prev;
 }
 int lwkzg_get_mode(void) { return mode_now(); }
+
+// Per-settings semantics: a settings object that was given a mode of its own answers in it whatever the process-wide
+// default says (-1 gives it back to the default); every entry point resolves its mode ONCE, when it is entered.
+int lwkzg_settings_set_mode(const KZGSettings *s, int mode) {
+    if (mode != LWKZG_MODE_REFERENCE && mode != LWKZG_MODE_CKZG && mode != -1) return -1;
+    Ctx *c = ctx_of(s);  // hand-built settings get their context here
+    if (!c) return -1;
+    const int prev = lwk::mode_of(s);
+    c->mode_override.store(mode, std::memory_order_relaxed);
+    return prev;
+}
+int lwkzg_settings_get_mode(const KZGSettings *s) { return lwk::mode_of(s); }
 
 int lwkzg_device_count(void) {
     int n = 0;
@@ -1514,7 +1545,7 @@ static bool combine_commit(Ctx *c, uint8_t *out48, const uint8_t *blob, int mode
 
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s,
                                              size_t *first_bad) {
-    const int mode = mode_now();
+    const int mode = mode_of(s);
     if (!out || !blobs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
@@ -1884,7 +1915,7 @@ static C_KZG_RET combine_point_proof(Ctx *c, KZGProof *proof_out, Bytes32 *y_out
 
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
                                              const KZGSettings *s, size_t *first_bad) {
-    const int mode = mode_now();
+    const int mode = mode_of(s);
     if (!out || !blobs || !commitments) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
@@ -1976,7 +2007,7 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
 
 C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs,
                                         size_t n, const KZGSettings *s, size_t *first_bad) {
-    const int mode = mode_now();
+    const int mode = mode_of(s);
     if (!proofs_out || !ys_out || !blobs || !zs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
@@ -2131,7 +2162,7 @@ C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void 
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     WsUse wsu(c, st);
-    return commit_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, n, mode_now(), st, status_dev);
+    return commit_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, n, mode_of(s), st, status_dev);
 }
 
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void *blobs_dev, const void *commitments48_dev,
@@ -2144,12 +2175,12 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void 
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     WsUse wsu(c, st);
     return blob_proof_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev,
-                                   n, mode_now(), st, status_dev);
+                                   n, mode_of(s), st, status_dev);
 }
 
 C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *proofs48_dev, const void *blobs_dev, size_t n,
                                               const KZGSettings *s, void *stream, int32_t *status_dev) {
-    if (!commitments48_dev || !proofs48_dev || !blobs_dev) return map_rc(C_KZG_BADARGS, mode_now());
+    if (!commitments48_dev || !proofs48_dev || !blobs_dev) return map_rc(C_KZG_BADARGS, mode_of(s));
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
     if (n == 0) return C_KZG_OK;
@@ -2159,7 +2190,7 @@ C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *pro
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     WsUse wsu(c, st);
     return commit_and_prove_batch_device(c, (uint8_t *)commitments48_dev, (uint8_t *)proofs48_dev, (const uint8_t *)blobs_dev, n,
-                                         mode_now(), st, status_dev);
+                                         mode_of(s), st, status_dev);
 }
 
 // z_i = compute_challenge(blob_i, commitment_i) (src/utils.rs:120-154) for device-resident blobs, as 32 bytes in the
@@ -2178,7 +2209,7 @@ C_KZG_RET lwkzg_compute_challenges_device(void *z32_dev, const void *blobs_dev, 
     C_KZG_RET rc = ctx_reserve(c, n);
     if (rc != C_KZG_OK) return rc;
     if (n > kMaxChunk && (rc = ws_long_reserve(c, n)) != C_KZG_OK) return rc;
-    const int le = mode_now() == LWKZG_MODE_CKZG;
+    const int le = mode_of(s) == LWKZG_MODE_CKZG;
     Fr *z = n > kMaxChunk ? c->ws.z_long : c->ws.z;
     launch_challenge((const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev, z, le, n, st);
     launch_fr_mont_to_bytes(z, (uint8_t *)z32_dev, le, n, st);

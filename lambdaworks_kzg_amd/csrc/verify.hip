@@ -198,7 +198,6 @@ void host_lincomb3(HXyzz out[3], const G1Affine29 *aff, const int32_t *kind, con
         for (int s = 0; s < 3; s++) out[s] = xyzz_add(out[s], part[3 * t + s]);
 }
 
-int g_mode_now() { return lwkzg_get_mode(); }
 C_KZG_RET bad(int mode) { return mode == LWKZG_MODE_CKZG ? C_KZG_BADARGS : C_KZG_ERROR; }
 
 }  // namespace
@@ -236,7 +235,7 @@ C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Byte
                            const Bytes48 *proof_bytes, const KZGSettings *s) {
     if (!ok) return C_KZG_BADARGS;
     *ok = false;  // lib.rs:415-417
-    const int mode = g_mode_now();
+    const int mode = mode_of(s);
     if (!commitment_bytes || !z_bytes || !y_bytes || !proof_bytes || !s) return bad(mode);
     HostPoint c, pi;
     uint32_t z[8], y[8];
@@ -257,7 +256,7 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
                                 const KZGSettings *s) {
     if (!ok) return C_KZG_BADARGS;
     *ok = false;  // lib.rs:463-465
-    const int mode = g_mode_now();
+    const int mode = mode_of(s);
     if (!blob || !commitment_bytes || !proof_bytes || !s) return bad(mode);
     HostPoint c, pi;
     // lib.rs:473-478: both points are decompressed before the blob is parsed (every failure of this function has the
@@ -522,9 +521,14 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
                                       const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s) {
     if (!ok) return C_KZG_BADARGS;
     *ok = false;  // lib.rs:533-535
-    if (n == 0) return C_KZG_OK;  // lib.rs:538-543: OK with ok = false
+    const int mode = mode_of(s);
+    if (n == 0) {
+        // the reference answers OK with ok = false (lib.rs:538-543); c-kzg-4844 accepts the empty batch
+        // (verify_blob_kzg_proof_batch_case_a271b78b8e869d69: output true) -- SURVEY Appendix B: a reference quirk, never in mode C
+        *ok = mode == LWKZG_MODE_CKZG;
+        return C_KZG_OK;
+    }
     if (n == 1) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);  // lib.rs:544
-    const int mode = g_mode_now();
     if (!blobs || !commitments_bytes || !proofs_bytes || !s) return bad(mode);
 
     static const bool timing = getenv("LWKZG_TIMING") != nullptr;  // phase wall-clock to stderr
@@ -573,7 +577,7 @@ C_KZG_RET lwkzg_verify_shard_begin(LwkzgVerifyShard **shard_out, uint8_t *record
                                    const Bytes48 *proofs, size_t n_local, const KZGSettings *s) {
     if (!shard_out) return C_KZG_BADARGS;
     *shard_out = nullptr;
-    const int mode = g_mode_now();
+    const int mode = mode_of(s);
     if (!s || (n_local && (!records_out || !blobs || !commitments || !proofs))) return bad(mode);
     Shard *sh = new (std::nothrow) Shard();
     if (!sh) return C_KZG_MALLOC;
@@ -606,7 +610,10 @@ void lwkzg_verify_shard_free(LwkzgVerifyShard *shard) { delete (Shard *)shard; }
 C_KZG_RET lwkzg_verify_shards_finish(bool *ok, const uint8_t *partials, size_t n_shards, size_t n_total, const KZGSettings *s) {
     if (!ok) return C_KZG_BADARGS;
     *ok = false;
-    if (n_total == 0) return C_KZG_OK;  // lib.rs:538-543: the empty batch is OK with ok = false
+    if (n_total == 0) {  // lib.rs:538-543: the empty batch is OK with ok = false; c-kzg-4844 (mode C) accepts it
+        *ok = mode_of(s) == LWKZG_MODE_CKZG;
+        return C_KZG_OK;
+    }
     if (!partials || !n_shards || !s) return C_KZG_BADARGS;
     HXyzz sums[3] = {HXyzz::infinity(), HXyzz::infinity(), HXyzz::infinity()};
     HFr ysum = HFr::zero();

@@ -108,6 +108,13 @@ def _all_gather_bytes(local, counts, item_bytes, device, group=None):
     return b"".join(bytes(parts[r][: counts[r] * item_bytes].cpu().numpy().tobytes()) for r in range(world))
 
 
+def _empty_batch_verdict(ts):
+    """n == 0: False in reference mode (/root/reference/src/lib.rs:538-543), True in c-kzg mode (the reference's own
+    vector verify_blob_kzg_proof_batch_case_a271b78b8e869d69)."""
+    mode = ts.get_mode() if ts is not None else capi.get_mode()
+    return mode == capi.MODE_CKZG
+
+
 def verify_blob_kzg_proof_batch_sharded(blobs, commitments, proofs, n_local, ts, group=None, _shard=None, _finish=None):
     """BASELINE config "verify_blob_kzg_proof_batch, 4096 blobs sharded across 8 GPUs" as the reference computes it
     (/root/reference/src/lib.rs:525-692, src/utils.rs:166-206): ONE batch, ONE Fiat-Shamir scalar r over the transcript
@@ -116,34 +123,44 @@ def verify_blob_kzg_proof_batch_sharded(blobs, commitments, proofs, n_local, ts,
     `blobs` / `commitments` / `proofs` are THIS rank's contiguous shard (bytes), `n_local` its length; rank k's shard
     follows rank k - 1's in the batch. Steps: (1) per blob on this rank's GPU: validation of C_i and pi_i, z_i, y_i;
     (2) all_gather of the 160-byte transcript records; (3) this rank's terms of the three linear combinations with the
-    common r; (4) all_gather of the 328-byte partial sums; every rank adds them and does the pairing check, so every
-    rank returns the same verdict. Two collectives, 160 bytes per blob + 328 bytes per rank.
+    common r; (4) all_gather of the 328-byte partial sums (+ one status byte); every rank adds them and does the pairing
+    check, so every rank returns the same verdict. Two data collectives, 160 bytes per blob + 329 bytes per rank.
 
-    Errors: an invalid point or blob on ANY rank makes EVERY rank raise KzgError after the first collective (the
-    verdict of the lowest such rank, as the reference returns at the first offending blob) -- no rank is left waiting
-    in a collective. An empty global batch returns False, as the reference does for n == 0 (lib.rs:538-543)."""
+    Errors: ANY failure of step (1) or (3) on ANY rank -- an invalid point or blob, an allocation or device error, a
+    Python-side exception -- is carried through the next collective as a return code, so every rank reaches every
+    collective and EVERY rank raises afterwards (the failing rank its own exception, the others a KzgError naming the
+    lowest failing rank, as the reference returns at the first offending blob). An empty global batch returns False in
+    reference mode, as the reference does for n == 0 (lib.rs:538-543), and True in c-kzg mode."""
     make_shard = _shard or capi.VerifyShard
     finish = _finish or capi.verify_shards_finish
     distributed = not (group is None and not dist.is_initialized())
     err_rc = 0
+    err_first = None
     shard = None
     if not distributed and _shard is None and _finish is None:   # one process, one shard: the reference's own symbol
-        return bool(capi.verify_blob_kzg_proof_batch(blobs, commitments, proofs, n_local, ts)) if n_local else False
+        return bool(capi.verify_blob_kzg_proof_batch(blobs, commitments, proofs, n_local, ts))
     try:
         shard = make_shard(blobs, commitments, proofs, n_local, ts)
-    except capi.KzgError as e:
-        err_rc = e.rc or capi.C_KZG_ERROR
+    except Exception as e:                                       # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+        err_rc = getattr(e, "rc", 0) or capi.C_KZG_ERROR
         err_first = e
     try:
         if not distributed:
             if err_rc:
                 raise err_first
             if n_local == 0:
-                return False
+                return _empty_batch_verdict(ts)
             return bool(finish(shard.partial(shard.records, n_local, 0), 1, n_local, ts))
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+        def raise_for(rcs, what):
+            bad = next(r for r in range(world) if rcs[r])
+            if err_first is not None and bad == rank:
+                raise err_first
+            raise capi.KzgError("verify_blob_kzg_proof_batch_sharded (rank %d %s)" % (bad, what), rcs[bad])
+
         # shard lengths and error codes of every rank: the one small collective every rank always reaches
         meta = torch.tensor([n_local, err_rc], dtype=torch.int64, device=device)
         metas = [torch.empty_like(meta) for _ in range(world)]
@@ -151,17 +168,27 @@ def verify_blob_kzg_proof_batch_sharded(blobs, commitments, proofs, n_local, ts,
         counts = [int(m[0]) for m in metas]
         rcs = [int(m[1]) for m in metas]
         if any(rcs):
-            bad = next(r for r in range(world) if rcs[r])
-            if err_rc and bad == rank:
-                raise err_first
-            raise capi.KzgError("verify_blob_kzg_proof_batch_sharded (rank %d rejected its shard)" % bad, rcs[bad])
+            raise_for(rcs, "rejected its shard")
         n_total = sum(counts)
         if n_total == 0:
-            return False
+            return _empty_batch_verdict(ts)
         first = sum(counts[:rank])
         records_all = _all_gather_bytes(shard.records, counts, capi.VERIFY_RECORD_BYTES, device, group)
-        partial = shard.partial(records_all, n_total, first)
-        partials = _all_gather_bytes(partial, [1] * world, capi.VERIFY_PARTIAL_BYTES, device, group)
+        # step (3) can fail on one rank only (allocation, device error): its code travels in the payload's last byte
+        try:
+            partial = shard.partial(records_all, n_total, first)
+            if len(partial) != capi.VERIFY_PARTIAL_BYTES:
+                raise ValueError("partial sums of %d bytes" % len(partial))
+            partial += b"\0"
+        except Exception as e:                                   # noqa: BLE001
+            err_first = e
+            partial = bytes(capi.VERIFY_PARTIAL_BYTES) + bytes([getattr(e, "rc", 0) or capi.C_KZG_ERROR])
+        padded = _all_gather_bytes(partial, [1] * world, capi.VERIFY_PARTIAL_BYTES + 1, device, group)
+        step = capi.VERIFY_PARTIAL_BYTES + 1
+        rcs = [padded[step * r + step - 1] for r in range(world)]
+        if any(rcs):
+            raise_for(rcs, "failed in its partial sums")
+        partials = b"".join(padded[step * r: step * r + step - 1] for r in range(world))
         return bool(finish(partials, world, n_total, ts))
     finally:
         if shard is not None:

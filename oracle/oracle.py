@@ -68,6 +68,7 @@ def _bind(l):
     l.orc_compute_blob_kzg_proof.argtypes = [cp, cp, cp, vp, ci, ci]
     l.orc_compute_challenge.argtypes = [cp, cp, cp, ci]
     l.orc_verify_kzg_proof_known_tau.argtypes = [C.POINTER(ci), cp, cp, cp, cp, C.c_uint64, ci]
+    l.orc_verify_kzg_proof_known_tau_be.argtypes = [C.POINTER(ci), cp, cp, cp, cp, cp, ci]
     l.orc_msm_affine.argtypes = [cp, cp, cp, ci, ci]
     l.orc_g1_generator_mul.argtypes = [cp, cp]
     l.orc_g1_generator_mul.restype = None
@@ -169,7 +170,7 @@ def compute_challenge(blob, commitment, mode=MODE_R):
 
 def verify_kzg_proof_known_tau(commitment, z, y, proof, tau=1337, mode=MODE_R):
     ok = C.c_int(0)
-    rc = lib().orc_verify_kzg_proof_known_tau(C.byref(ok), commitment, z, y, proof, tau, mode)
+    rc = lib().orc_verify_kzg_proof_known_tau_be(C.byref(ok), commitment, z, y, proof, int(tau).to_bytes(32, "big"), mode)
     return rc, bool(ok.value)
 
 

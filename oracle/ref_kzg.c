@@ -752,8 +752,8 @@ EXPORT int orc_compute_blob_kzg_proof(uint8_t out[48], const uint8_t *blob, cons
  * (tests/trusted_setup.txt: tau = 1337) and subgroup points, that equation
  * holds iff  C - [y]G == [tau - z] pi  in G1, which is what this function checks.
  * Valid ONLY for such a setup; the caller passes tau. */
-EXPORT int orc_verify_kzg_proof_known_tau(int *ok, const uint8_t comm48[48], const uint8_t z_bytes[32],
-                                          const uint8_t y_bytes[32], const uint8_t proof48[48], uint64_t tau, int mode) {
+static int verify_known_tau(int *ok, const uint8_t comm48[48], const uint8_t z_bytes[32], const uint8_t y_bytes[32],
+                            const uint8_t proof48[48], const fr_t *tau, int mode) {
     *ok = 0;
     g1_t c, pi, g, t, lhs, rhs;
     int bad = mode == 0 ? RET_ERROR : RET_BADARGS;
@@ -774,12 +774,28 @@ EXPORT int orc_verify_kzg_proof_known_tau(int *ok, const uint8_t comm48[48], con
     g1_mul_raw(&t, &g, raw, 4);
     g1_neg(&t, &t);
     g1_add(&lhs, &c, &t);
-    fr_set_u64(&tf, tau);
+    tf = *tau;
     fr_sub(&d, &tf, &z);
     fr_to_raw(raw, &d);
     g1_mul_raw(&rhs, &pi, raw, 4);
     *ok = g1_eq(&lhs, &rhs);
     return RET_OK;
+}
+
+EXPORT int orc_verify_kzg_proof_known_tau(int *ok, const uint8_t comm48[48], const uint8_t z_bytes[32],
+                                          const uint8_t y_bytes[32], const uint8_t proof48[48], uint64_t tau, int mode) {
+    fr_t tf;
+    fr_set_u64(&tf, tau);
+    return verify_known_tau(ok, comm48, z_bytes, y_bytes, proof48, &tf, mode);
+}
+
+/* the same for a setup whose secret does not fit 64 bits (tests/golden/trusted_setup_tau2.txt); tau big-endian, < r */
+EXPORT int orc_verify_kzg_proof_known_tau_be(int *ok, const uint8_t comm48[48], const uint8_t z_bytes[32],
+                                             const uint8_t y_bytes[32], const uint8_t proof48[48], const uint8_t tau_be[32],
+                                             int mode) {
+    fr_t tf;
+    fr_from_be(&tf, tau_be);
+    return verify_known_tau(ok, comm48, z_bytes, y_bytes, proof48, &tf, mode);
 }
 
 /* ------------------------------------------------------------------ primitive hooks for kernel-level parity tests */

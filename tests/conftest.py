@@ -80,10 +80,22 @@ def engine_setup(request, gpu_setup, bucket_setup):
     return gpu_setup if request.param == "default" else bucket_setup
 
 
-def tau_closed_form(oracle, scalars):
-    """[sum s_i tau^i] G compressed: the closed-form commitment for the tau = 1337 setup."""
+def tau_closed_form(oracle, scalars, tau=TAU):
+    """[sum s_i tau^i] G compressed: the closed-form commitment for a powers-of-tau setup (default: the tau = 1337 one)."""
     acc, t = 0, 1
     for s in scalars:
         acc = (acc + s * t) % R
-        t = t * TAU % R
+        t = t * tau % R
     return oracle.g1_generator_mul(acc)
+
+
+SETUP_TAU2_PATH = os.path.join(GOLDEN, "trusted_setup_tau2.txt")                   # tests/golden/make_setups.py
+SETUP_UNSTRUCTURED_PATH = os.path.join(GOLDEN, "trusted_setup_unstructured.txt")
+
+
+def unstructured_closed_form(oracle, scalars):
+    """[sum s_i k_i] G compressed: the closed-form commitment for tests/golden/trusted_setup_unstructured.txt (P_i = [k_i]G)."""
+    import make_setups as M
+    if not hasattr(unstructured_closed_form, "k"):
+        unstructured_closed_form.k = [M.unstructured_scalar(i) for i in range(4096)]
+    return oracle.g1_generator_mul(sum(s * k for s, k in zip(scalars, unstructured_closed_form.k)) % R)

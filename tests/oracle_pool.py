@@ -12,11 +12,11 @@ SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
 _state = {}
 
 
-def _init():
+def _init(setup_path=SETUP):
     sys.path.insert(0, ROOT)
     from oracle import oracle as O
     _state["O"] = O
-    _state["s"] = O.Settings.from_file(SETUP, check_subgroup=False)
+    _state["s"] = O.Settings.from_file(setup_path, check_subgroup=False)
 
 
 def _proof(args):
@@ -45,11 +45,12 @@ def usable_cores():
 class OraclePool:
     """with OraclePool() as p: p.blob_proofs(blobs, comms, mode) -> [(rc, proof48), ...] in input order."""
 
-    def __init__(self, procs=None):
+    def __init__(self, procs=None, setup_path=SETUP):
         self.procs = procs or usable_cores()
+        self.setup_path = setup_path
 
     def __enter__(self):
-        self.pool = mp.get_context("spawn").Pool(self.procs, initializer=_init)
+        self.pool = mp.get_context("spawn").Pool(self.procs, initializer=_init, initargs=(self.setup_path,))
         return self
 
     def __exit__(self, *a):

@@ -9,14 +9,15 @@ from conftest import R, TAU
 _cache = {}
 
 
-def oracle_batch(oracle, first, n, mode_c):
-    """(blobs, commitments, proofs) of synthetic blobs first .. first + n - 1 in the given mode, from the CPU oracle."""
-    key = (first, n, bool(mode_c))
+def oracle_batch(oracle, first, n, mode_c, setup_path=None):
+    """(blobs, commitments, proofs) of synthetic blobs first .. first + n - 1 in the given mode, from the CPU oracle
+    (on the tau = 1337 setup unless another setup file is named)."""
+    key = (first, n, bool(mode_c), setup_path)
     if key not in _cache:
-        from oracle_pool import OraclePool
+        from oracle_pool import SETUP, OraclePool
         omode = oracle.MODE_C if mode_c else oracle.MODE_R
         blobs = [B.synthetic_blob(first + i, big_endian=not mode_c) for i in range(n)]
-        with OraclePool() as p:
+        with OraclePool(setup_path=setup_path or SETUP) as p:
             comms = p.commitments(blobs, omode)
             assert all(rc == 0 for rc, _ in comms)
             comms = [c for _, c in comms]
@@ -33,14 +34,14 @@ def challenge_int(blob, commitment, mode_c):
     return int.from_bytes(hashlib.sha256(msg).digest(), "little" if mode_c else "big") % R
 
 
-def reference_mode_proof_closed_form(oracle, blob, commitment):
-    """Reference mode, tau = 1337 setup: proof = [(p(tau) - p(z)) / (tau - z)] G with z from hashlib -- no MSM, no
-    oracle Pippenger: an independent O(n) check of compute_blob_kzg_proof."""
+def reference_mode_proof_closed_form(oracle, blob, commitment, tau=TAU):
+    """Reference mode, powers-of-tau setup (default tau = 1337): proof = [(p(tau) - p(z)) / (tau - z)] G with z from
+    hashlib -- no MSM, no oracle Pippenger: an independent O(n) check of compute_blob_kzg_proof."""
     coeffs = B.blob_scalars(blob)
     z = challenge_int(blob, commitment, False)
     pt = pz = 0
     for c in reversed(coeffs):
-        pt = (pt * TAU + c) % R
+        pt = (pt * tau + c) % R
         pz = (pz * z + c) % R
-    q = (pt - pz) * pow((TAU - z) % R, R - 2, R) % R
+    q = (pt - pz) * pow((tau - z) % R, R - 2, R) % R
     return oracle.g1_generator_mul(q)

@@ -84,12 +84,18 @@ class _FakeShard:
         from lambdaworks_kzg_amd import capi
         if n_local and blobs[:1] == b"\xff":
             raise capi.KzgError("lwkzg_verify_shard_begin", capi.C_KZG_ERROR)
+        if n_local and blobs[:1] == b"\xfe":
+            raise TypeError("not a KzgError: a ctypes argument of the wrong type, a failed assertion ...")
+        self.fail_partial = n_local and blobs[:1] == b"\xfd"
         self.n = n_local
         self.records = b"".join(hashlib.sha256(blobs[i:i + 1] + commitments[i:i + 1]).digest() * 5 for i in range(n_local))
         self.freed = False
 
     def partial(self, records_all, n_total, first):
         import hashlib
+        from lambdaworks_kzg_amd import capi
+        if self.fail_partial:
+            raise capi.KzgError("lwkzg_verify_shard_partial", capi.C_KZG_MALLOC)
         assert records_all[160 * first:160 * (first + self.n)] == self.records
         return (hashlib.sha256(records_all + bytes([first, self.n, n_total])).digest() * 11)[:328]
 
@@ -105,11 +111,17 @@ def _verify_worker(rank, world, port, case, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # the batch: 5 one-byte "blobs", rank 0 holds 3 of them (shard_range), rank 1 two -- or nothing at all
-        n_total = 0 if case == "empty" else 5
+        n_total = 0 if case.startswith("empty") else 5
+        if case == "empty_ckzg":
+            capi.set_mode(capi.MODE_CKZG)
         start, count = D.shard_range(n_total, world, rank)
         blobs = bytes(range(10 + start, 10 + start + count))
         if case == "bad_rank_1" and rank == 1:
             blobs = b"\xff" + blobs[1:]
+        if case == "type_error_rank_0" and rank == 0:
+            blobs = b"\xfe" + blobs[1:]
+        if case == "partial_fails_rank_1" and rank == 1:
+            blobs = b"\xfd" + blobs[1:]
         comms = bytes(range(50 + start, 50 + start + count))
 
         def finish(partials, n_shards, n_tot, ts):
@@ -122,16 +134,19 @@ def _verify_worker(rank, world, port, case, q):
             verdict = D.verify_blob_kzg_proof_batch_sharded(blobs, comms, comms, count, None, _shard=_FakeShard, _finish=finish)
         except capi.KzgError as e:
             verdict = ("error", e.rc)
+        except TypeError:
+            verdict = ("error", "TypeError")
         q.put((rank, verdict))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["honest", "bad_rank_1", "empty"])
+@pytest.mark.parametrize("case", ["honest", "bad_rank_1", "type_error_rank_0", "partial_fails_rank_1", "empty", "empty_ckzg"])
 def test_sharded_batch_verification_gathers_one_transcript(case):
     """world size 2 over gloo: both ranks see the whole transcript in order, the partial sums arrive in rank order, and
-    both return the same verdict; a shard rejected on one rank makes BOTH ranks raise (nobody hangs in a collective); the
-    empty batch is False as in the reference (lib.rs:538-543)"""
+    both return the same verdict; a shard rejected on one rank -- by the library, by a Python-side exception, or only in
+    its partial sums after the first data collective -- makes BOTH ranks raise (nobody hangs in a collective); the empty
+    batch is False as in the reference (lib.rs:538-543) and True in c-kzg mode (the reference's own vector a271b78b8e869d69)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -142,5 +157,8 @@ def test_sharded_batch_verification_gathers_one_transcript(case):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = {"honest": True, "bad_rank_1": ("error", 2), "empty": False}[case]
-    assert res == [(0, want), (1, want)]
+    want = {"honest": (True, True), "bad_rank_1": (("error", 2), ("error", 2)),
+            "type_error_rank_0": (("error", "TypeError"), ("error", 2)),     # the failing rank raises its own exception
+            "partial_fails_rank_1": (("error", 3), ("error", 3)),
+            "empty": (False, False), "empty_ckzg": (True, True)}[case]
+    assert res == [(0, want[0]), (1, want[1])]

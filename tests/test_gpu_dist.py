@@ -107,7 +107,14 @@ def test_sharded_verification_equals_single_batch(K, gpu_setup, n, world):
         with pytest.raises(capi.KzgError) as e:
             _sharded_verdict(capi, D, data, bytes([comms[0] & 0x7f]) + comms[1:], proofs, n, world, gpu_setup)
         assert e.value.rc == (K.C_KZG_ERROR if be else K.C_KZG_BADARGS)
-    assert capi.verify_shards_finish(b"", 0, 0, gpu_setup) is False      # the empty batch: OK, ok = false (lib.rs:538-543)
+    # the empty batch: OK with ok = false in reference mode (lib.rs:538-543), ok = true in c-kzg mode (vector a271b78b8e869d69)
+    K.set_mode(K.MODE_REFERENCE)
+    assert capi.verify_shards_finish(b"", 0, 0, gpu_setup) is False
+    assert D.verify_blob_kzg_proof_batch_sharded(b"", b"", b"", 0, gpu_setup) is False
+    K.set_mode(K.MODE_CKZG)
+    assert capi.verify_shards_finish(b"", 0, 0, gpu_setup) is True
+    assert D.verify_blob_kzg_proof_batch_sharded(b"", b"", b"", 0, gpu_setup) is True
+    K.set_mode(K.MODE_REFERENCE)
 
 
 def _free_port():

@@ -239,6 +239,37 @@ def test_srs_rebuild_restatement(oracle, oracle_setup):
     assert oracle.srs_rebuild(g1[:144], limbs(g2[0] ^ 1) + p2[48:]) == oracle.ERROR
 
 
+def test_more_setups_fixtures_and_oracle_on_them(oracle):
+    """tests/golden/trusted_setup_tau2.txt and trusted_setup_unstructured.txt (make_setups.py): the committed files are what
+    their generator writes (its G2 arithmetic first reproduces the 65 G2 points of the tau = 1337 setup), every point is a
+    valid subgroup point, and the oracle's commitment / proof on them agree with the closed forms, with the plain MSM over
+    the decompressed points and with the known-tau' verifier -- so the GPU tests on these setups compare against an oracle
+    that is pinned for them too (what /root/reference/tests/lib_test.rs:68 does with a random secret)."""
+    import make_setups as M
+    from conftest import SETUP_TAU2_PATH, SETUP_UNSTRUCTURED_PATH, unstructured_closed_form
+    from proof_cases import reference_mode_proof_closed_form
+    M.self_check_against_tau_1337()
+    g1_tau, g1_un, g2 = M.build_texts()
+    assert open(SETUP_TAU2_PATH).read() == M.setup_text(g1_tau, g2)
+    assert open(SETUP_UNSTRUCTURED_PATH).read() == M.setup_text(g1_un, g2)
+    s_tau = oracle.Settings.from_file(SETUP_TAU2_PATH, check_subgroup=True)
+    s_un = oracle.Settings.from_file(SETUP_UNSTRUCTURED_PATH, check_subgroup=True)
+    blob = B.synthetic_blob(31)
+    sc = B.blob_scalars(blob)
+    rc, cm = oracle.blob_to_kzg_commitment(blob, s_tau, oracle.MODE_R)
+    assert rc == 0 and cm == tau_closed_form(oracle, sc, tau=M.TAU2)
+    rc, pr = oracle.compute_blob_kzg_proof(blob, cm, s_tau, oracle.MODE_R)
+    assert rc == 0 and pr == reference_mode_proof_closed_form(oracle, blob, cm, tau=M.TAU2)
+    z = (12345).to_bytes(32, "big")
+    rc, pr, y = oracle.compute_kzg_proof(blob, z, s_tau, oracle.MODE_R)
+    assert oracle.verify_kzg_proof_known_tau(cm, z, y, pr, M.TAU2, oracle.MODE_R) == (0, True)
+    assert oracle.verify_kzg_proof_known_tau(cm, z, y, pr, TAU, oracle.MODE_R) == (0, False)      # not the 1337 setup
+    rc, cu = oracle.blob_to_kzg_commitment(blob, s_un, oracle.MODE_R)
+    assert rc == 0 and cu == unstructured_closed_form(oracle, sc) and cu != cm
+    pts = b"".join(oracle.g1_decompress(p)[0] for p in g1_un)
+    assert oracle.msm_affine(pts, blob, oracle.ALGO_NAIVE) == cu == oracle.msm_affine(pts, blob, oracle.ALGO_PIPPENGER)
+
+
 def test_oracle_golden_vectors_under_address_sanitizer():
     """SURVEY section 5 (sanitizers): the oracle built with -fsanitize=address,undefined (oracle/Makefile) re-runs its
     golden-vector tests in a child process; any report aborts it. CPU only: GPU sanitizers are not available here."""
