@@ -15,6 +15,11 @@ Rank 0 prints ONE JSON line. Besides the contract's fields it carries
   default_engine  the same workload on the engine a plain load_trusted_setup* selects (what a drop-in consumer gets),
   bucket_engine   and on the low-memory fallback: short regions of their own, timed like the headline's;
   host_abi        the same batch through the host-pointer C ABI, PCIe included (never `value`);
+  configs         BASELINE configs[2]-[4] and the Fr transform as short legs of their own (never folded into `value`):
+                  blob proofs at 256 on one and two caller streams, commit-and-prove at 256, c-kzg-mode commitments with
+                  k_ntt4096's own roofline object, a 4096-blob batch verification, the 2^20-term tiled MSM;
+  dist            the process group this run used (`--force-dist` takes the RCCL branch at --gpus 1 too) and the per-rank
+                  HBM budget the table width was chosen against;
   cpu_baseline    the CPU oracle (a restatement of the reference's algorithm, NOT the reference binary, which cannot be
                   built here) on this box's host cores, with and without the SRS rebuild the reference pays per call.
 """
@@ -191,6 +196,145 @@ def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launc
     }, nwin
 
 
+NTT_ALGO_BYTES = 131072 + 131072               # one 4096-point Fr transform reads and writes 131,072 B
+NTT_PRODUCTS_PER_BLOB = 30720                  # 22,528 butterflies + entry and exit of every element
+NTT_MADS_PER_PRODUCT = 190                     # 10 lazy limbs of 28 bits (fr28.cuh)
+
+
+def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
+    """BASELINE configs[2]-[4] and the Fr transform, each a short region of its own on the engine of
+    the headline, timed like it (untimed warm-up, synchronize on both sides, hipEvent kernel times from the library).
+    One GPU only; never part of `value`. A leg that fails reports its error instead of taking the line down."""
+    out = {"engine_direct_bits": direct_bits}
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def region(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        capi.profile_reset()
+        capi.profile_enable(True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        capi.profile_enable(False)
+        pr = capi.profile_report()
+        return el, {name: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for name, v in pr.items()}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001 -- the headline must survive a leg
+            out[name] = {"error": repr(e)}
+
+    def dev_bytes(b):
+        return torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).to(dev)
+
+    nb = 256
+    d_blobs = dev_bytes(B.synthetic_batch(7000, nb))
+    d_comm = torch.empty(48 * nb, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(nb, dtype=torch.int32, device=dev)
+    K.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), nb, ts, stream, d_st.data_ptr())
+    torch.cuda.synchronize(dev)
+
+    def blob_proof(n_streams):
+        def run():
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else []
+            outs = [torch.empty(48 * nb, dtype=torch.uint8, device=dev) for _ in range(max(1, n_streams))]
+            stats = [torch.zeros(nb, dtype=torch.int32, device=dev) for _ in range(max(1, n_streams))]
+            k = [0]
+
+            def step():
+                i = k[0] % max(1, n_streams)
+                k[0] += 1
+                K.compute_blob_kzg_proof_batch_device(outs[i].data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), nb, ts,
+                                                      streams[i].cuda_stream if streams else stream, stats[i].data_ptr())
+            steps = 20
+            el, kern = region(step, steps, 4)
+            assert all(int(x.abs().sum().item()) == 0 for x in stats) and all(torch.equal(o, outs[0]) for o in outs)
+            return {"workload": "BASELINE configs[2]: compute_blob_kzg_proof, batch=%d device-resident blobs per call, %d caller stream%s"
+                                % (nb, max(1, n_streams), "s (consecutive calls alternate; the library overlaps one call's hash with the other's MSM)" if n_streams > 1 else ""),
+                    "value": nb * steps / el, "unit": "proofs/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
+        return run
+    leg("blob_proof_b256", blob_proof(1))
+    leg("blob_proof_b256_two_streams", blob_proof(2))
+
+    def commit_prove():
+        d_c2 = torch.empty(48 * nb, dtype=torch.uint8, device=dev)
+        d_p2 = torch.empty(48 * nb, dtype=torch.uint8, device=dev)
+        steps = 20
+        el, kern = region(lambda: K.commit_and_prove_batch_device(d_c2.data_ptr(), d_p2.data_ptr(), d_blobs.data_ptr(), nb, ts, stream, d_st.data_ptr()), steps, 4)
+        assert int(d_st.abs().sum().item()) == 0 and torch.equal(d_c2, d_comm)
+        return {"workload": "commitment AND blob proof of batch=%d device-resident blobs in one pass (configs[1] then configs[2] on its output)" % nb,
+                "value": nb * steps / el, "unit": "pairs/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
+    leg("commit_prove_b256", commit_prove)
+
+    def ckzg_commit():
+        n = BLOBS_PER_GPU
+        d_le = dev_bytes(B.synthetic_batch(0, n, big_endian=False))
+        d_o = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+        d_s = torch.zeros(n, dtype=torch.int32, device=dev)
+        ts.set_mode(K.MODE_CKZG)          # this settings object only (lwkzg_settings_set_mode)
+        try:
+            steps = 10
+            el, kern = region(lambda: K.blob_to_kzg_commitment_batch_device(d_o.data_ptr(), d_le.data_ptr(), n, ts, stream, d_s.data_ptr()), steps, 3)
+        finally:
+            ts.set_mode(-1)
+        assert int(d_s.abs().sum().item()) == 0
+        ntt_ms = kern.get("k_ntt4096", {}).get("avg_ms", 0.0)
+        launches_per_step = max(1, round(kern.get("k_ntt4096", {}).get("launches", steps) / steps))
+        per_launch = n / launches_per_step
+        ach = per_launch * NTT_ALGO_BYTES / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+        mads = per_launch * NTT_PRODUCTS_PER_BLOB * NTT_MADS_PER_PRODUCT
+        return {"workload": "c-kzg-4844 semantics: batch=%d little-endian evaluation-form blobs -> commitments (k_ntt4096: parse, range check, "
+                            "inverse 4096-point Fr transform, in front of the same MSM)" % n,
+                "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern,
+                "ntt_roofline": {"kernel": "k_ntt4096", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": per_launch * NTT_ALGO_BYTES, "avg_launch_ms": ntt_ms, "blobs_per_launch": per_launch,
+                                 "traffic": None,
+                                 "int_mad": {"mad_u64_u32_per_launch": mads, "achieved_Gmad_per_s": mads / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0,
+                                             "peak_theoretical_Gmad_per_s": INT_MAD_PEAK_THEORETICAL / 1e9,
+                                             "frac_of_theoretical": mads / (ntt_ms * 1e-3) / INT_MAD_PEAK_THEORETICAL if ntt_ms > 0 else 0.0},
+                                 "note": "SURVEY 8d: 262,144 algorithmic bytes per 4096-point transform; the whole blob stays in LDS for the twelve stages, "
+                                         "so HBM sees each element once in and once out; the kernel is bound by its 30,720 Fr products per blob"}}
+    leg("ckzg_commit_b1024_with_ntt", ckzg_commit)
+
+    def verify_batch():
+        n = 4096
+        h_blobs = B.synthetic_batch(9000, n)
+        h_comms = b"".join(K.blob_to_kzg_commitment_batch(h_blobs, ts))
+        h_proofs = b"".join(K.compute_blob_kzg_proof_batch(h_blobs, h_comms, ts))
+        steps = 3
+
+        def step():
+            assert D.verify_blob_kzg_proof_batch_sharded(h_blobs, h_comms, h_proofs, n, ts)
+        el, kern = region(step, steps, 1)
+        return {"workload": "BASELINE configs[3] on one GPU: verify_blob_kzg_proof_batch of %d blobs (one transcript, one r, one pairing check), "
+                            "host-pointer ABI: 512 MiB of pageable host blobs uploaded inside the clock" % n,
+                "value": n * steps / el, "unit": "blobs/s", "steps": steps, "warmup": 1, "ms_per_step": el / steps * 1e3, "kernels": kern}
+    leg("verify_batch_b4096", verify_batch)
+
+    def tiled_msm():
+        tiles = 256
+        d_t = dev_bytes(B.synthetic_batch(5000, tiles))
+        steps = 10
+        el, kern = region(lambda: D.msm_tiled_sharded(d_t, tiles * 4096, ts, dev), steps, 3)
+        dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
+        ms = kern.get(dom, {}).get("avg_ms", 0.0)
+        lps = max(1, round(kern.get(dom, {}).get("launches", steps) / steps))
+        algo = (tiles * 4096 * 128 + 48) / lps  # SURVEY 8d: 2^20 x (32 B scalar + 96 B affine point) + 48 B, per launch
+        return {"workload": "BASELINE configs[4] on one GPU: one 2^20-term G1 MSM over the setup tiled 256 times",
+                "value": tiles * 4096 * steps / el, "unit": "terms/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern,
+                "roofline": {"kernel": dom, "bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms,
+                             "launches_per_step": lps, "traffic": None}}
+    leg("tiled_msm_2_pow_20", tiled_msm)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +362,14 @@ def main():
     ap.add_argument("--idle-ms", type=float, default=0.0,
                     help="experiment: the host synchronizes and sleeps this long before every step (is a kernel slower after an idle gap?)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and take every collective branch (setup broadcast, barriers, max over ranks) "
+                         "at --gpus 1 too: the RCCL code path on a one-GPU box")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the short legs for BASELINE configs[2]-[4] and the Fr transform (they run at --gpus 1 only)")
+    ap.add_argument("--hbm-headroom-gib", type=float, default=6.0,
+                    help="--direct-bits auto: device memory the chosen table must leave free on this rank (workspaces of the other "
+                         "legs, RCCL's buffers, the caller's own tensors)")
     args = ap.parse_args()
     if args.op == "commit_prove" and args.caller_streams > 1:
         ap.error("--op commit_prove runs on one caller stream")
@@ -243,17 +395,31 @@ def main():
     dev = torch.device("cuda", dev_index)
     K.set_device(dev_index)
     K.set_mode(K.MODE_REFERENCE if args.mode == "reference" else K.MODE_CKZG)
-    if world > 1:
+    distributed = world > 1 or args.force_dist
+    dist_info = {"initialised": False, "backend": None, "ranks": world}
+    if distributed:
+        if world == 1:     # --force-dist without a launcher: a rendezvous with ourselves
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        dist_info = {"initialised": True, "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                     "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
+                     "note": "backend nccl IS RCCL on ROCm; collectives of this run: one broadcast of the setup image, barriers, "
+                             "the max-over-ranks of the timings"}
 
     # trusted setup: rank 0 parses + validates + builds the fixed-base table, one RCCL broadcast delivers it; every rank
     # then holds the engine a plain load selects (the default engine: engine.hip, direct_from_env)
     t_load0 = time.perf_counter()
     ts = K.TrustedSetup.from_file(SETUP) if rank == 0 else None
-    if world > 1:
+    if distributed:
         ts = D.broadcast_trusted_setup(ts, dev, src=0)
     t_load = time.perf_counter() - t_load0
     default_bits = ts.direct_table_bits()
@@ -305,7 +471,7 @@ def main():
         torch.cuda.synchronize(dev)
         capi.profile_reset()
         capi.profile_enable(True)             # hipEvent pairs around every kernel, on the launch stream
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -315,12 +481,12 @@ def main():
                 time.sleep(args.idle_ms * 1e-3)
             step()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         el = time.perf_counter() - t0
         capi.profile_enable(False)
         pr = capi.profile_report()
-        if world > 1:
+        if distributed:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -357,8 +523,23 @@ def main():
     # timed region; the seconds are reported per rank below.
     t_tab0 = time.perf_counter()
     direct_bits = 0
+    hbm_budget = None
     if args.direct_bits == "auto":
-        for bits in (16, 15, 14, 13, 12, 11, 10, 0):
+        # per-rank HBM budget: what is free on THIS device now (the table in place is freed before the new one is built),
+        # shared with every other rank of this node that was mapped to the same device, minus the headroom the rest of the
+        # run needs -- so that 8 ranks on 8 devices (or N ranks on fewer) pick a width that fits instead of finding out
+        # in the middle of a launch
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        in_place = capi.direct_table_bytes(default_bits, ts.direct_row_bytes() or 112) if default_bits else 0
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        sharing = sum(1 for lr in range(local_world) if lr % max(1, torch.cuda.device_count()) == dev_index)
+        headroom = int(args.hbm_headroom_gib * (1 << 30))
+        budget = (free_b + in_place) // max(1, sharing) - headroom
+        fits = [b for b in (16, 15, 14, 13, 12, 11, 10) if capi.direct_table_bytes(b, 112) <= budget]
+        hbm_budget = {"device_total_bytes": total_b, "free_bytes_before": free_b, "table_in_place_bytes": in_place,
+                      "ranks_sharing_device": sharing, "headroom_bytes": headroom, "budget_bytes": budget,
+                      "widths_within_budget": fits}
+        for bits in fits + [0]:
             try:
                 ts.enable_direct_table(bits)
                 direct_bits = bits
@@ -366,6 +547,8 @@ def main():
             except capi.KzgError as e:
                 if e.rc != capi.C_KZG_MALLOC:
                     raise
+        hbm_budget["chosen_bits"] = direct_bits
+        hbm_budget["free_bytes_after"] = torch.cuda.mem_get_info(dev)[0]
     elif args.direct_bits == "default":     # whatever a plain load selected (engine.hip: direct_from_env)
         direct_bits = default_bits
     else:
@@ -373,7 +556,7 @@ def main():
         direct_bits = int(args.direct_bits)
     t_table = time.perf_counter() - t_tab0
     direct_bits_min, t_table_max = direct_bits, t_table
-    if world > 1:   # every rank should have got the same width; report it if one did not
+    if distributed:   # every rank should have got the same width; report it if one did not
         tb = torch.tensor([direct_bits], dtype=torch.int32, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)
         direct_bits_min = int(tb.item())
@@ -416,6 +599,9 @@ def main():
                              "ms_per_call_best": times[0] * 1e3, "calls": len(times),
                              "note": "PCIe-inclusive wall clock on rank 0: pageable host blobs in, 48-byte commitments out, one GPU; "
                                      "results equal to the device-resident path's"}
+
+    if args.op == "commit" and world == 1 and not args.no_config_legs and not args.no_extra_legs and args.mode == "reference":
+        extra["configs"] = config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits)
 
     if rank == 0:
         total_blobs = n * world * args.steps
@@ -487,6 +673,8 @@ def main():
             "direct_table_build_s_max_over_ranks": t_table_max if direct_bits else None,
             "direct_table_build_note": "every rank builds its own table from the broadcast setup points, once, outside the timed region" if direct_bits else None,
         }
+        res["dist"] = dist_info
+        res["hbm_budget"] = hbm_budget
         res.update(extra)
         if world > 1:
             res["scaling_note"] = "per-GPU work is fixed (weak scaling); multi-GPU throughput is unmeasured on hardware by the builder (one-GPU boxes only)"
@@ -494,7 +682,7 @@ def main():
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
             res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)], ts.g2_values_bytes())
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     ts.free() if ts is not None else None

@@ -1,9 +1,10 @@
-"""One rank of the two-process multi-GPU rehearsal that tests/test_gpu_dist.py runs on ONE device (gloo backend: RCCL
-needs a GPU per rank). Fresh process; everything a rank of an 8-GPU job does, in order: rendezvous, setup image
+"""One rank of the multi-GPU rehearsals that tests/test_gpu_dist.py runs on ONE device: two processes over gloo (RCCL
+needs a GPU per rank), and ONE process over "nccl" (= RCCL on ROCm) at world size 1, which is how the RCCL code path
+-- device tensors through dist.broadcast / dist.all_gather -- executes on a one-GPU box. Fresh process; everything a rank of an 8-GPU job does, in order: rendezvous, setup image
 export -> broadcast -> import, its shard of a commitment batch, its tiles of a long MSM, its shard of a sharded batch
 verification (honest and tampered). Results go to a JSON file the test compares with the single-process answers.
 
-    python tests/dist_gpu_worker.py RANK WORLD PORT OUT.json
+    python tests/dist_gpu_worker.py RANK WORLD PORT OUT.json [BACKEND=gloo]
 """
 import json
 import os
@@ -18,6 +19,7 @@ N_COMMIT, N_TILES, N_VERIFY = 96, 16, 160
 
 def main():
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import numpy as np
@@ -27,11 +29,16 @@ def main():
     import lambdaworks_kzg_amd as K
     from lambdaworks_kzg_amd import capi
     from lambdaworks_kzg_amd import dist as D
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = {"rank": rank}
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    res = {"rank": rank, "backend": dist.get_backend()}
     try:
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
+        if backend == "nccl":
+            res["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         K.set_device(0)
         K.set_mode(K.MODE_REFERENCE)
         # rank 0 loads and validates; the others import what the broadcast delivered
@@ -39,6 +46,17 @@ def main():
         ts = D.broadcast_trusted_setup(ts, dev, src=0)
         res["direct_bits"] = ts.direct_table_bits()
         res["g1_values_sha"] = __import__("hashlib").sha256(ts.g1_values_bytes()).hexdigest()
+        if world == 1:
+            # at world size 1 the source rank keeps its own setup: import what went through the broadcast explicitly, and
+            # commit with it, so that the receiving side of broadcast_trusted_setup has run on this backend too
+            image = torch.empty(capi.setup_image_bytes(), dtype=torch.uint8, device=dev)
+            ts.export_device_image(image.data_ptr())
+            D.broadcast_bytes(image, src=0)
+            torch.cuda.synchronize(dev)
+            ts_imp = capi.TrustedSetup.from_device_image(image.data_ptr())
+            res["imported_g1_values_sha"] = __import__("hashlib").sha256(ts_imp.g1_values_bytes()).hexdigest()
+            res["imported_commitment"] = K.blob_to_kzg_commitment(B.synthetic_blob(60000), ts_imp).hex()
+            ts_imp.free()
 
         # commitments: contiguous shard, no data-path collective; gathered here only so that the test can compare
         st, cnt = D.shard_range(N_COMMIT, world, rank)

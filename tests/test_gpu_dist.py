@@ -175,3 +175,37 @@ def test_two_process_rehearsal_of_a_multi_gpu_job(K, gpu_setup, oracle, tmp_path
     assert comms == b"".join(K.blob_to_kzg_commitment_batch(vdata, gpu_setup))
     assert proofs == b"".join(K.compute_blob_kzg_proof_batch(vdata, comms, gpu_setup))
     assert K.verify_blob_kzg_proof_batch(vdata, comms, proofs, W.N_VERIFY, gpu_setup) is True
+
+
+def test_rccl_path_at_world_size_1(K, gpu_setup, tmp_path):
+    """The RCCL transport of the multi-GPU layer, executed on the one GPU there is: a FRESH process initialises the "nccl"
+    backend (= RCCL) at world size 1 and runs broadcast_trusted_setup (+ an explicit export -> broadcast -> import),
+    gather_shards, msm_tiled_sharded and verify_blob_kzg_proof_batch_sharded through it -- device tensors in
+    dist.broadcast / dist.all_gather, which the gloo rehearsal above never touches. Bytes equal to the plain calls.
+    (N > 1 over xGMI is unmeasured on hardware: one-GPU boxes.)"""
+    import torch
+    from lambdaworks_kzg_amd import capi
+    worker = os.path.join(ROOT, "tests", "dist_gpu_worker.py")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_gpu_worker as W
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LWKZG_MODE", None)
+    out = str(tmp_path / "rank0.json")
+    p = subprocess.run([sys.executable, worker, "0", "1", str(_free_port()), out, "nccl"], env=env, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-4000:]
+    res = json.load(open(out))
+    assert res["backend"] == "nccl" and res["nccl_version"]
+    want_sha = hashlib.sha256(gpu_setup.g1_values_bytes()).hexdigest()
+    assert res["g1_values_sha"] == res["imported_g1_values_sha"] == want_sha
+    assert res["imported_commitment"] == K.blob_to_kzg_commitment(B.synthetic_blob(60000), gpu_setup).hex()
+    data = B.synthetic_batch(60000, W.N_COMMIT)
+    assert res["commitments"] == b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup)).hex()
+    tiles = B.synthetic_batch(61000, W.N_TILES)
+    d_sc = torch.frombuffer(bytearray(tiles), dtype=torch.uint8).cuda()
+    d_out = torch.empty(48, dtype=torch.uint8, device="cuda")
+    capi.g1_msm_tiled_device(d_out.data_ptr(), d_sc.data_ptr(), W.N_TILES * 4096, gpu_setup)
+    torch.cuda.synchronize()
+    assert res["tiled_msm"] == bytes(d_out.cpu().numpy().tobytes()).hex()
+    assert res["verify_honest"] is True and res["verify_tampered"] is False and res["verify_invalid"] == K.C_KZG_ERROR
+    vdata = B.synthetic_batch(62000, W.N_VERIFY)
+    assert bytes.fromhex(res["comms"]) == b"".join(K.blob_to_kzg_commitment_batch(vdata, gpu_setup))

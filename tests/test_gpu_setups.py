@@ -184,88 +184,6 @@ def test_tau2_point_proofs_and_verification(K, tau2_setup, oracle, oracle_tau2, 
         ts1337.free()
 
 
-# ---- unstructured points -----------------------------------------------------------------------------------------
-
-@pytest.fixture(scope="module", params=ENGINES, ids=lambda e: "engine_%s" % e)
-def unstructured_setups(request, K, gpu_setup, oracle_unstructured):
-    """(loaded through load_trusted_setup bytes, hand-built KZGSettings over the same points) on one engine"""
-    ts = K.TrustedSetup.from_bytes(oracle_unstructured.g1_compressed(), oracle_unstructured.g2_compressed())
-    undo = _select_engine(K, ts.ref(), request.param, gpu_setup)
-    hand = K.KZGSettings()
-    g1 = C.create_string_buffer(oracle_unstructured.g1_blst())
-    hand.fs, hand.g1_values, hand.g2_values = None, C.cast(g1, C.c_void_p), ts.s.g2_values
-    yield ts, hand, request.param
-    K.lib().lwkzg_release_context(C.byref(hand))
-    undo()
-    ts.free()
-    del g1
-
-
-def test_unstructured_commitments_vs_cpu_msm(K, unstructured_setups, gpu_setup, oracle, oracle_unstructured):
-    ts, hand, engine = unstructured_setups
-    assert ts.g1_values_bytes() == oracle_unstructured.g1_blst()
-    pts = b"".join(oracle.g1_decompress(oracle_unstructured.g1_compressed()[48 * i:48 * i + 48])[0] for i in range(4096))
-    n = 70
-    data = B.synthetic_batch(34000, n)
-    got = K.blob_to_kzg_commitment_batch(data, ts)
-    for i in range(n):
-        blob = data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]
-        assert got[i] == unstructured_closed_form(oracle, B.blob_scalars(blob)), i
-        if i < 2:
-            assert got[i] == oracle.msm_affine(pts, blob)                                  # the CPU MSM over the same points
-            assert (0, got[i]) == oracle.blob_to_kzg_commitment(blob, oracle_unstructured, oracle.MODE_R)
-    sets = _adversarial_sets()
-    blobs = [b"".join(s.to_bytes(32, "big") for s in ss) for ss in sets]
-    adv = K.blob_to_kzg_commitment_batch(b"".join(blobs), ts)
-    for ss, g in zip(sets, adv):
-        assert g == unstructured_closed_form(oracle, ss)
-    # c-kzg mode (inverse transform in front of the same MSM) against the oracle
-    K.set_mode(K.MODE_CKZG)
-    le = [B.synthetic_blob(34500 + i, big_endian=False) for i in range(3)]
-    got_c = K.blob_to_kzg_commitment_batch(b"".join(le), ts)
-    for b, g in zip(le, got_c):
-        assert (0, g) == oracle.blob_to_kzg_commitment(b, oracle_unstructured, oracle.MODE_C)
-    K.set_mode(K.MODE_REFERENCE)
-    # the same points as a hand-built KZGSettings (fs == NULL, the reference's layout lib.rs:754-758), same engine
-    if engine != "default":
-        stepped = engine >= 15
-        if stepped:
-            K.lib().lwkzg_enable_direct_table(ts.ref(), 0)       # one 16-bit table at a time
-        assert K.lib().lwkzg_enable_direct_table(C.byref(hand), engine) == K.C_KZG_OK
-    out = C.create_string_buffer(48 * n)
-    bad = C.c_size_t(0)
-    assert K.lib().lwkzg_blob_to_kzg_commitment_batch(out, data, n, C.byref(hand), C.byref(bad)) == K.C_KZG_OK
-    assert [out.raw[48 * i:48 * i + 48] for i in range(n)] == got
-    one = C.create_string_buffer(48)
-    for blob, want in zip(blobs, adv):
-        assert K.lib().blob_to_kzg_commitment(one, blob, C.byref(hand)) == K.C_KZG_OK and one.raw == want
-    if engine != "default":
-        K.lib().lwkzg_enable_direct_table(C.byref(hand), 0)
-        if engine >= 15:
-            assert K.lib().lwkzg_enable_direct_table(ts.ref(), engine) == K.C_KZG_OK
-
-
-def test_unstructured_tiled_long_msm(K, unstructured_setups, oracle):
-    """configs[4] on points without structure: sum_k s_k P_(k mod 4096) over 2^15 terms = [sum_k s_k k_(k mod 4096)]G"""
-    import numpy as np
-    import torch
-    ts, _, _ = unstructured_setups
-    n_terms = 1 << 15
-    rng = np.random.default_rng(99)
-    raw = rng.integers(0, 256, size=(n_terms, 32), dtype=np.uint8)
-    raw[:, 0] &= 0x3f                                               # < 2^254 < r
-    scalars = [int.from_bytes(raw[k].tobytes(), "big") for k in range(n_terms)]
-    d_s = torch.from_numpy(raw.reshape(-1)).cuda()
-    d_out = torch.empty(48, dtype=torch.uint8, device="cuda")
-    from lambdaworks_kzg_amd import capi
-    capi.g1_msm_tiled_device(d_out.data_ptr(), d_s.data_ptr(), n_terms, ts)
-    torch.cuda.synchronize()
-    folded = [0] * 4096
-    for k, s in enumerate(scalars):
-        folded[k % 4096] = (folded[k % 4096] + s) % R
-    assert bytes(d_out.cpu().numpy().tobytes()) == unstructured_closed_form(oracle, folded)
-
-
 # ---- two consumers, two semantics, one process -------------------------------------------------------------------
 
 def test_two_settings_objects_with_different_modes(K, gpu_setup, tau2_setup, oracle, oracle_setup, oracle_tau2):

@@ -270,6 +270,24 @@ def test_more_setups_fixtures_and_oracle_on_them(oracle):
     assert oracle.msm_affine(pts, blob, oracle.ALGO_NAIVE) == cu == oracle.msm_affine(pts, blob, oracle.ALGO_PIPPENGER)
 
 
+def test_fuzz_seed_fixture_and_oracle_answers(oracle, oracle_setup):
+    """tests/golden/fuzz_seeds.{json,xz} (make_fuzz_seeds.py): 115 seeds of the reference's six fuzz targets, the stored
+    bytes match their digests, and the oracle reproduces every stored answer in both modes (what the GPU replay in
+    tests/test_gpu_fuzz_seeds.py is compared with)"""
+    import fuzz_cases as F
+    index, seeds = F.load_seeds()
+    assert len(seeds) == 115 and sum(1 for e, _ in seeds if e["harness_calls"]) == 65
+    per_target = {t: sum(1 for e, _ in seeds if e["target"] == t) for t in F.TARGETS}
+    assert per_target == {"blob_to_kzg_commitment": 36, "compute_kzg_proof": 19, "compute_blob_kzg_proof": 14, "verify_kzg_proof": 2,
+                          "verify_blob_kzg_proof": 2, "verify_blob_kzg_proof_batch": 42}
+    for e, data in seeds:
+        if not e["harness_calls"]:
+            assert data is None and "expect" not in e
+            continue
+        for name, mode in (("reference", oracle.MODE_R), ("ckzg", oracle.MODE_C)):
+            assert F.oracle_answer(oracle, oracle_setup, e["target"], data or b"", mode) == e["expect"][name], (e["target"], e["name"], name)
+
+
 def test_oracle_golden_vectors_under_address_sanitizer():
     """SURVEY section 5 (sanitizers): the oracle built with -fsanitize=address,undefined (oracle/Makefile) re-runs its
     golden-vector tests in a child process; any report aborts it. CPU only: GPU sanitizers are not available here."""
