@@ -374,6 +374,12 @@ def main():
     if args.op == "commit_prove" and args.caller_streams > 1:
         ap.error("--op commit_prove runs on one caller stream")
 
+    # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 meanwhile (RCCL
+    # prints a version banner there when its first communicator comes up) goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -681,7 +687,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mode == "reference" and args.scalars == "31byte":
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
             res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)], ts.g2_values_bytes())
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
