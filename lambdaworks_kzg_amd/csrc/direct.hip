@@ -195,7 +195,10 @@ template <int CT>
 __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
                                                                    const uint4 *__restrict__ scalars,
                                                                    G1Xyzz29 *__restrict__ partials, int scalars_per_lane,
-                                                                   DirectPlanRt rt, uint32_t row_bytes) {
+                                                                   DirectPlanRt rt, uint32_t row_bytes,
+                                                                   const uint32_t *__restrict__ redo) {
+    // second pass behind the hand-scheduled kernel (k_direct_accumulate_asm): only the blobs it flagged are recomputed
+    if (redo && !redo[blockIdx.y]) return;
     const DirectPlanRt P = CT ? PlanOf<CT ? CT : 16>::get() : rt;  // folds to constants when CT != 0
     const int C = P.c;
     __shared__ uint32_t limbs[8 * kDirThreads];   // the lane's current scalar, for run-time window indexing
@@ -277,6 +280,75 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same accumulation as a hand-scheduled instruction stream (tools/gen_direct_asm.py writes direct_asm.inc and
+// explains what it does differently). The statement is the whole kernel: it reads its operands,
+// runs the loop over (scalar, window) with every register placed by the generator, and stores each LANE's partial sum
+// (-X, -Y, ZZ, ZZZ: 56 words, literal zeros for a lane that added nothing) to lane_out[blob][block][lane];
+// k_direct_fold_lanes adds the 256 lanes of a workgroup. A lane that meets P = +-Q (or would have to double) sets
+// redo[blob]; k_direct_accumulate<CT> then recomputes exactly those blobs with its complete branches.
+constexpr int kLaneWords = 56;
+
+__global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1Affine29 *__restrict__ table,
+                                                                       const uint4 *__restrict__ scalars,
+                                                                       uint32_t *__restrict__ lane_out, uint32_t *__restrict__ redo,
+                                                                       int scalars_per_lane, DirectPlanRt rt, uint32_t row_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t first = blockIdx.x * kDirThreads + tid;
+    const uint4 *sc = scalars + (size_t)blockIdx.y * kBlobElems * 2;
+    uint32_t *out = lane_out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(kDirThreads * kLaneWords);
+    uint32_t *flag = redo + blockIdx.y;
+    const uint32_t lanes_per_blob = gridDim.x * kDirThreads;
+    const uint32_t top_lo = (uint32_t)rt.top_base, top_hi = (uint32_t)(rt.top_base >> 32);
+    asm volatile(
+#include "direct_asm.inc"
+        :
+        : "s"(table), "s"(sc), "s"(out), "s"(flag), "s"(scalars_per_lane), "s"(lanes_per_blob), "s"(rt.c), "s"(rt.nw), "s"(rt.wtop),
+          "s"(rt.h), "s"(rt.htop), "s"(top_lo), "s"(top_hi), "s"(row_bytes), "v"(first), "v"(tid)
+        :
+#include "direct_asm_clobbers.inc"
+    );
+#endif
+}
+
+// the 256 lane sums of one workgroup of k_direct_accumulate_asm -> one partial sum (same shuffle tree as the C++ kernel's tail)
+__global__ __launch_bounds__(kDirThreads) void k_direct_fold_lanes(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
+                                                                   const uint32_t *__restrict__ redo) {
+    if (redo[blockIdx.y]) return;  // recomputed by the second pass
+    __shared__ G1Xyzz29 wave_sum[kDirThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *src = lane_out + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kDirThreads + tid) * (size_t)kLaneWords;
+    F29<10, true, 2> nx;
+    F29<4, true, 2> ny;
+    G1Xyzz29i acc;
+    const uint4 *s4 = (const uint4 *)src;
+    uint32_t wds[kLaneWords];
+#pragma unroll
+    for (int k = 0; k < kLaneWords / 4; k++) {
+        uint4 t = s4[k];
+        wds[4 * k] = t.x; wds[4 * k + 1] = t.y; wds[4 * k + 2] = t.z; wds[4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        nx.l[i] = wds[i];
+        ny.l[i] = wds[14 + i];
+        acc.zz.l[i] = wds[28 + i];
+        acc.zzz.l[i] = wds[42 + i];
+    }
+    const F29<1, true> one = F29<1, true>::one();
+    acc.x = neg(nx) * one;  // the stream keeps -X and -Y
+    acc.y = neg(ny) * one;
+    G1Xyzz29 s = wave_fold(*(G1Xyzz29 *)&acc, lane);
+    if (lane == 0) wave_sum[wave] = s;
+    __syncthreads();
+    if (wave == 0) {
+        G1Xyzz29 t = lane < kDirThreads / 64 ? wave_sum[lane] : G1Xyzz29::infinity();
+        t = wave_fold(t, lane, kDirThreads / 64);
+        if (lane == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // sums[blob] = sum of its per-block partial sums (only when a blob was spread over several workgroups):
 // one wave per blob, a shuffle tree over the <= 64 partials
 __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__ partials, G1Xyzz29 *__restrict__ sums,
@@ -289,9 +361,19 @@ __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__
     if (lane == 0) sums[b] = s;
 }
 
+// LWKZG_DIRECT_ASM=0 keeps every launch on the compiler-scheduled kernel (the A/B arm)
+static bool direct_asm_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("LWKZG_DIRECT_ASM");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 template <int CT>
 static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw,
-                            G1Xyzz29 *partials, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
+                            G1Xyzz29 *lane_scratch, G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st,
+                            int fill) {
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
     // 16 workgroups so the chip fills and the dependent chain per lane stays short. `fill` = the number of workgroups
     // to aim for: 512 (two per compute unit, one round) when the kernel has the chip alone; 2048 when the settings
@@ -304,10 +386,30 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, s
     while (wsplit < 4 && n_blobs * blocks_per_blob * wsplit * 8 <= (size_t)kFill) wsplit <<= 1;  // only for a handful of blobs
     const int scalars_per_lane = kBlobElems / (kDirThreads * blocks_per_blob);
     const int parts = blocks_per_blob * wsplit;
-    {
+    G1Xyzz29 *dest = parts == 1 ? sums : partials;
+    if (direct_asm_enabled() && wsplit == 1) {
+        // the hand-scheduled stream, its lane fold, and a second pass of the C++ kernel over the blobs it flagged (none on
+        // honest data: the launch exits at its first instruction)
+        hipMemsetAsync(redo, 0, n_blobs * sizeof(uint32_t), st);
+        {
+            ProfScope p("k_direct_accumulate_asm", st);
+            hipLaunchKernelGGL(k_direct_accumulate_asm, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(kDirThreads), 0, st, table,
+                               (const uint4 *)scalars_raw, (uint32_t *)lane_scratch, redo, scalars_per_lane, plan, (uint32_t)row_bytes);
+        }
+        {
+            ProfScope p("k_direct_fold_lanes", st);
+            hipLaunchKernelGGL(k_direct_fold_lanes, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(kDirThreads), 0, st,
+                               (const uint32_t *)lane_scratch, dest, (const uint32_t *)redo);
+        }
+        {
+            ProfScope p("k_direct_redo", st);
+            hipLaunchKernelGGL(k_direct_accumulate<CT>, dim3(blocks_per_blob, (unsigned)n_blobs, 1), dim3(kDirThreads), 0, st, table,
+                               (const uint4 *)scalars_raw, dest, scalars_per_lane, plan, (uint32_t)row_bytes, (const uint32_t *)redo);
+        }
+    } else {
         ProfScope p("k_direct_accumulate", st);
         hipLaunchKernelGGL(k_direct_accumulate<CT>, dim3(blocks_per_blob, (unsigned)n_blobs, wsplit), dim3(kDirThreads), 0, st,
-                           table, (const uint4 *)scalars_raw, parts == 1 ? sums : partials, scalars_per_lane, plan, (uint32_t)row_bytes);
+                           table, (const uint4 *)scalars_raw, dest, scalars_per_lane, plan, (uint32_t)row_bytes, (const uint32_t *)nullptr);
     }
     if (parts > 1) {
         ProfScope p("k_direct_fold", st);
@@ -315,15 +417,15 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, s
     }
 }
 
-void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *partials,
-                       G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
+void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
+                       G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
     const DirectPlanRt plan = make_plan(bits);
     if (!plan.entries) return;
     switch (bits) {
-        case 14: launch_direct_t<14>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;
-        case 15: launch_direct_t<15>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;
-        case 16: launch_direct_t<16>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;
-        default: launch_direct_t<0>(plan, table, row_bytes, scalars_raw, partials, sums, n_blobs, st, fill); break;  // 10 .. 13
+        case 14: launch_direct_t<14>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;
+        case 15: launch_direct_t<15>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;
+        case 16: launch_direct_t<16>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;
+        default: launch_direct_t<0>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;  // 10 .. 13
     }
 }
 

@@ -498,8 +498,10 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
     G1Xyzz29 *sums = w.sums + base;
     if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
-        launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, sums, n, st,
-                          (c->primary->twin || shared_chip) ? 2048 : 0);
+        // (scratch of the bucket engine, idle on this path: `buckets` holds the per-lane sums of the hand-scheduled kernel,
+        // `sorted` the per-workgroup partial sums, `bstart` the redo flags)
+        launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
+                          st, (c->primary->twin || shared_chip) ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);

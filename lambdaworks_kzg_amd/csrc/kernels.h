@@ -48,10 +48,11 @@ constexpr size_t kDirectAlignedHeadroom = (size_t)8 << 30;  // what an aligned t
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
 hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st);
-// sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused otherwise).
+// sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused
+// otherwise); `lane_scratch` 4096 * n_blobs entries (the per-lane sums of the hand-scheduled kernel) and `redo` n_blobs words (its flags).
 // fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
-void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *partials,
-                       G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0);
+void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
+                       G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0);
 
 // ---- setup (setup.hip)
 // 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check

@@ -111,21 +111,21 @@ VTID = vregs("VTID", 1)[0]
 NUM_VGPRS = _next[0]
 assert NUM_VGPRS <= 232, NUM_VGPRS
 
-SBASE = 30                   # s0 .. s29 stay with the compiler (the statement's operands live there)
+SBASE = 28                   # s0 .. s27 stay with the compiler (the 18 scalar registers of the statement's operands live there)
 S_ = {}
 _snext = [SBASE]
 
 
 def sregs(name, n=1, align=1):
-    while _snext[0] % align:
+    while _snext[0] % align or any(r in (32, 33, 34) for r in range(_snext[0], _snext[0] + n)):   # s32..s34: SP / FP / BP of the ABI
         _snext[0] += 1
     S_[name] = _snext[0] if n == 1 else list(range(_snext[0], _snext[0] + n))
     _snext[0] += n
     return S_[name]
 
 
+sINV, sMASK, sINVP, sMORE = sregs("INV"), sregs("MASK"), sregs("INVP"), sregs("MORE")     # (these four fill s28..s31)
 sMOD = sregs("MOD", 14)
-sINV, sMASK, sINVP = sregs("INV"), sregs("MASK"), sregs("INVP")
 sTABLE = sregs("TABLE", 2, 2)
 sSC = sregs("SCPTR", 2, 2)
 sOUT = sregs("OUT", 2, 2)
@@ -146,9 +146,9 @@ sTROUBLE = sregs("TROUBLE", 2, 2)
 sACT = sregs("ACT", 2, 2)
 sTMP = sregs("TMP", 2, 2)
 sTMPB = sregs("TMPB", 2, 2)
-sHCMP, sHJ, sMASKJ, sMORE, sSTMP = sregs("HCMP"), sregs("HJ"), sregs("MASKJ"), sregs("MORE"), sregs("STMP")
+sHCMP, sHJ, sMASKJ, sSTMP = sregs("HCMP"), sregs("HJ"), sregs("MASKJ"), sregs("STMP")
 NUM_SGPRS = _snext[0]
-assert NUM_SGPRS <= 100, NUM_SGPRS
+assert NUM_SGPRS <= 102, NUM_SGPRS
 
 # operands of the asm statement, in this order (direct.hip): all "s" except the last two ("v")
 OPERANDS = ["table", "scalars", "out", "redo", "spl", "lpb", "c", "nw", "wtop", "h", "htop", "top_base_lo", "top_base_hi", "row_bytes",
@@ -325,7 +325,7 @@ def interleave(prog, *chains):
 # ---- the kernel ----------------------------------------------------------------------------------------------------
 KP4_1 = borrowed(4, 1)
 KP8_4 = borrowed(8, 4)
-KP16_2 = borrowed(16, 2)
+KP16_1 = borrowed(16, 1)
 
 
 def build():
@@ -390,7 +390,9 @@ def build():
     scalar_load(p, SCN, T3)
     p.label("L_no_second%=")
     digit_and_address(p)
+    e("s_mov_b64", EXEC, sp(sVALIDN))       # (a zero digit has no row: its address would be the row in front of the window's)
     row_loads(p)
+    e("s_mov_b64", EXEC, lit(-1))
     # ---------------- the loop
     e(".p2align", ("raw", "3"))
     p.label("L_loop%=")
@@ -511,10 +513,10 @@ def build():
     nx3 = Val(NX, 2 + 8, 1)
     # t1 = (-Q) - (-X3) + 16p  [= -(Q - X3)],  t2 = 4p - PPP
     for i in range(14):
+        e("v_add_u32", v(D2[i]), lit(KP16_1[i]), v(D2[i]))
         e("v_sub_u32", v(D2[i]), v(D2[i]), v(NX[i]))
-        e("v_add_u32", v(D2[i]), lit(KP16_2[i]), v(D2[i]))
         e("v_sub_u32", v(U[i]), lit(KP4_1[i]), v(D1[i]))
-    t1 = Val(D2, 2 + 16, 1 + 3)
+    t1 = Val(D2, 2 + 16, 1 + 2)
     t2 = Val(U, 4, 2)
     # ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP, -Y3 = R t1 + (-Y1) t2   (three chains; each output overwrites an input limb by limb:
     # output limb k - 14 is written at column k, the input limb k - 14 was last read at column k - 1)
@@ -620,7 +622,8 @@ def fmt(o):  # noqa: F811  (raw operands: s_waitcnt / s_nop / .p2align arguments
 
 
 def clobbers():
-    return ", ".join(['"v%d"' % i for i in range(NUM_VGPRS)] + ['"s%d"' % i for i in range(SBASE, NUM_SGPRS)] + ['"vcc"', '"memory"'])
+    return ", ".join(['"v%d"' % i for i in range(NUM_VGPRS)] + ['"s%d"' % i for i in range(SBASE, NUM_SGPRS) if i not in (32, 33, 34)] +
+                     ['"vcc"', '"memory"'])
 
 
 # ---- simulator: one lane ---------------------------------------------------------------------------------------------
