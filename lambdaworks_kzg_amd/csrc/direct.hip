@@ -312,16 +312,25 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1A
 #endif
 }
 
-// the 256 lane sums of one workgroup of k_direct_accumulate_asm -> one partial sum (same shuffle tree as the C++ kernel's tail)
-__global__ __launch_bounds__(kDirThreads) void k_direct_fold_lanes(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
-                                                                   const uint32_t *__restrict__ redo) {
-    if (redo[blockIdx.y]) return;  // recomputed by the second pass
-    __shared__ G1Xyzz29 wave_sum[kDirThreads / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t *src = lane_out + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kDirThreads + tid) * (size_t)kLaneWords;
-    F29<10, true, 2> nx;
-    F29<4, true, 2> ny;
-    G1Xyzz29i acc;
+// the 256 lane sums of one workgroup of k_direct_accumulate_asm -> one partial sum. ONE wave per workgroup's worth of lanes:
+// every thread first adds four lane sums in sequence (all 64 lanes busy), then six shuffle levels -- nine additions deep
+// on a quarter of the waves, where a 256-thread tree is eight deep with most lanes idle on four times as many
+// (0.48 ms -> 0.13 ms at 1024 blobs).
+constexpr int kFoldPerThread = kDirThreads / 64;
+
+// LWK_FOLD_CALL: field products of the lane fold as calls of the shared product function (small code) instead of inlined
+#ifdef LWK_FOLD_CALL
+constexpr bool kFoldInl = false;
+typedef G1Xyzz29 FoldPoint;
+#else
+constexpr bool kFoldInl = true;
+typedef G1Xyzz29i FoldPoint;
+#endif
+
+__device__ __forceinline__ FoldPoint load_lane_sum(const uint32_t *src) {
+    F29<25, kFoldInl, 1> nx;  // (tools/gen_direct_asm.py: NX_B)
+    F29<4, kFoldInl, 2> ny;
+    FoldPoint acc;
     const uint4 *s4 = (const uint4 *)src;
     uint32_t wds[kLaneWords];
 #pragma unroll
@@ -336,17 +345,41 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_fold_lanes(const uint32_
         acc.zz.l[i] = wds[28 + i];
         acc.zzz.l[i] = wds[42 + i];
     }
-    const F29<1, true> one = F29<1, true>::one();
+    const F29<1, kFoldInl> one = F29<1, kFoldInl>::one();
     acc.x = neg(nx) * one;  // the stream keeps -X and -Y
     acc.y = neg(ny) * one;
-    G1Xyzz29 s = wave_fold(*(G1Xyzz29 *)&acc, lane);
-    if (lane == 0) wave_sum[wave] = s;
-    __syncthreads();
-    if (wave == 0) {
-        G1Xyzz29 t = lane < kDirThreads / 64 ? wave_sum[lane] : G1Xyzz29::infinity();
-        t = wave_fold(t, lane, kDirThreads / 64);
-        if (lane == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    return acc;
+}
+
+__global__ __launch_bounds__(64) void k_direct_fold_lanes(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
+                                                          const uint32_t *__restrict__ redo) {
+    if (redo[blockIdx.y]) return;  // recomputed by the second pass
+    __builtin_amdgcn_s_setprio(2);
+    const int lane = threadIdx.x;
+    const uint32_t *src = lane_out + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kDirThreads + lane) * (size_t)kLaneWords;
+    FoldPoint acc = load_lane_sum(src);
+    // ONE call site of the (inlined, 48 KB) addition for all nine steps, so that the kernel stays inside the instruction cache:
+    // steps 0 .. 2 add this thread's other three lane sums, steps 3 .. 8 are the shuffle tree
+#pragma unroll 1
+    for (int step = 1; step < kFoldPerThread + 6; step++) {
+        FoldPoint other;
+        bool take = true;
+        if (step < kFoldPerThread) {
+            other = load_lane_sum(src + (size_t)step * 64 * kLaneWords);
+        } else {
+            const int d = 32 >> (step - kFoldPerThread);
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                other.x.l[k] = __shfl_down(acc.x.l[k], d, 64);
+                other.y.l[k] = __shfl_down(acc.y.l[k], d, 64);
+                other.zz.l[k] = __shfl_down(acc.zz.l[k], d, 64);
+                other.zzz.l[k] = __shfl_down(acc.zzz.l[k], d, 64);
+            }
+            take = lane < d;
+        }
+        if (take) acc = xyzz_add(acc, other);
     }
+    if (lane == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = *(G1Xyzz29 *)&acc;
 }
 
 // sums[blob] = sum of its per-block partial sums (only when a blob was spread over several workgroups):
@@ -398,7 +431,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, s
         }
         {
             ProfScope p("k_direct_fold_lanes", st);
-            hipLaunchKernelGGL(k_direct_fold_lanes, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(kDirThreads), 0, st,
+            hipLaunchKernelGGL(k_direct_fold_lanes, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(64), 0, st,
                                (const uint32_t *)lane_scratch, dest, (const uint32_t *)redo);
         }
         {

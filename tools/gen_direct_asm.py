@@ -66,6 +66,10 @@ def borrowed(k, br):
 MOD = limbs(P)
 R1 = limbs(RMONT % P)
 
+# experiment knobs (A/B builds only; the committed .inc is generated with none of them set)
+KNOB_SDST = int(os.environ.get("LWK_ASM_SDST", "0"))      # 1: every chain writes its multiply-add carry-out to a scalar pair of its own
+KNOB_BLOCK = int(os.environ.get("LWK_ASM_BLOCK", "1"))    # instructions a chain issues before the next chain takes its turn
+
 # ---- register map ------------------------------------------------------------------------------------------------
 V = {}
 _next = [0]
@@ -79,7 +83,7 @@ def vregs(name, n, align=1):
     return V[name]
 
 
-NX = vregs("NX", 14)        # -X of the accumulator   (B <= 10, L <= 2)
+NX = vregs("NX", 14)        # -X of the accumulator   (B <= 25, L = 1)
 NY = vregs("NY", 14)        # -Y                      (B <= 4,  L <= 2)
 ZZ = vregs("ZZ", 14)
 ZZZ = vregs("ZZZ", 14)
@@ -147,6 +151,7 @@ sACT = sregs("ACT", 2, 2)
 sTMP = sregs("TMP", 2, 2)
 sTMPB = sregs("TMPB", 2, 2)
 sHCMP, sHJ, sMASKJ, sSTMP = sregs("HCMP"), sregs("HJ"), sregs("MASKJ"), sregs("STMP")
+sCARRY2 = sregs("CARRY2", 2, 2) if KNOB_SDST else None
 NUM_SGPRS = _snext[0]
 assert NUM_SGPRS <= 102, NUM_SGPRS
 
@@ -250,30 +255,57 @@ class Val:
         self.r, self.B, self.L = regs, B, L
 
 
-def chain_mul(a, b, out, m, acc, tmp):
+# A product whose reduction digits m_k are NOT masked to 28 bits ("wide"): m_k = (column * -p^-1) mod 2^32 clears the
+# column's low 28 bits just the same, and its upper four bits add a multiple of p one column up -- one instruction less
+# per column, a result < 17p instead of < 2p (the callers' bounds say where that is affordable).
+WIDE_B, NARROW_B = 17, 2
+
+
+def check_columns(terms_ll, wide):
+    """exact bound of every 64-bit column: terms_ll = [La Lb per product pair], all limbs at their bound"""
+    mmax = (1 << 32) - 1 if wide else MASK
+    carry = 0
+    for k in range(27):
+        lo, hi = max(0, k - 13), min(k, 13)
+        n = hi - lo + 1
+        tot = carry + sum(n * ll * (1 << W) * (1 << W) for ll in terms_ll)
+        tot += sum(mmax * MOD[k - i] for i in range(lo, hi + 1) if i <= 13 and (k < 14 or i >= k - 13))
+        assert tot < (1 << 64), ("64-bit column", k, terms_ll, wide)
+        carry = tot >> W
+
+
+def chain_mul(a, b, out, m, acc, tmp, wide=False):
     """instruction list of one Montgomery product out = a b / R (product scanning, one dependent chain)."""
-    assert a.B * b.B <= 2520 and a.L * b.L <= 17, (a.B, b.B, a.L, b.L)
-    return _chain([(a.r, b.r)], None, out, m, acc, tmp)
+    assert a.B * b.B <= 2520, (a.B, b.B)
+    check_columns([a.L * b.L], wide)
+    return _chain([(a.r, b.r)], None, out, m, acc, tmp, wide)
 
 
-def chain_sqr(a, dbl, out, m, acc, tmp):
+def chain_sqr(a, dbl, out, m, acc, tmp, wide=False):
     """out = a^2 / R with the cross products taken once against dbl = 2a (dbl registers must already hold 2a)."""
-    assert a.B * a.B <= 2520 and a.L * a.L <= 17 and a.L <= 7
-    return _chain([], (a.r, dbl), out, m, acc, tmp)
+    assert a.B * a.B <= 2520 and 2 * a.L <= 15, (a.B, a.L)     # (the doubled limbs must fit 32 bits)
+    check_columns([a.L * a.L], wide)
+    return _chain([], (a.r, dbl), out, m, acc, tmp, wide)
 
 
-def chain_mul_add(a, b, c, d, out, m, acc, tmp):
-    assert a.B * b.B + c.B * d.B <= 2520 and a.L * b.L + c.L * d.L <= 17, (a.B * b.B + c.B * d.B, a.L * b.L + c.L * d.L)
-    return _chain([(a.r, b.r), (c.r, d.r)], None, out, m, acc, tmp)
+def chain_mul_add(a, b, c, d, out, m, acc, tmp, wide=False):
+    assert a.B * b.B + c.B * d.B <= 2520, (a.B * b.B + c.B * d.B)
+    check_columns([a.L * b.L, c.L * d.L], wide)
+    return _chain([(a.r, b.r), (c.r, d.r)], None, out, m, acc, tmp, wide)
 
 
-def _chain(pairs, square, out, m, acc, tmp):
+def _chain(pairs, square, out, m, acc, tmp, wide=False):
     ins = []
     A = vp(acc[0])
     first = [True]
+    sink = VCC
+    if KNOB_SDST and acc[0] == ACC2[0]:
+        sink = sp(sCARRY2)
+    if KNOB_SDST and acc[0] == ACC3[0]:
+        sink = sp(sTMP)
 
     def mad(x, y):
-        ins.append(("v_mad_u64_u32", (A, VCC, x, y, lit(0) if first[0] else A), {}))
+        ins.append(("v_mad_u64_u32", (A, sink, x, y, lit(0) if first[0] else A), {}))
         first[0] = False
 
     def column(k):
@@ -293,8 +325,11 @@ def _chain(pairs, square, out, m, acc, tmp):
         column(k)
         for i in range(k):
             mad(v(m[i]), s(sMOD[k - i]))
-        ins.append(("v_mul_lo_u32", (v(tmp), v(acc[0]), s(sINV)), {}))
-        ins.append(("v_and_b32", (v(m[k]), s(sMASK), v(tmp)), {}))
+        if wide:
+            ins.append(("v_mul_lo_u32", (v(m[k]), v(acc[0]), s(sINV)), {}))
+        else:
+            ins.append(("v_mul_lo_u32", (v(tmp), v(acc[0]), s(sINV)), {}))
+            ins.append(("v_and_b32", (v(m[k]), s(sMASK), v(tmp)), {}))
         mad(v(m[k]), s(sMOD[0]))
         ins.append(("v_lshrrev_b64", (A, lit(W), A), {}))
     for k in range(14, 27):
@@ -314,18 +349,24 @@ def interleave(prog, *chains):
     n = [len(c) for c in chains]
     pos = [0] * len(chains)
     total = sum(n)
-    for _ in range(total):
+    done = 0
+    while done < total:
         # the chain that is furthest behind its share goes next
         k = min((j for j in range(len(chains)) if pos[j] < n[j]), key=lambda j: (pos[j] + 0.5) / n[j])
-        op, args, kw = chains[k][pos[k]]
-        prog.emit(op, *args, **kw)
-        pos[k] += 1
+        for _ in range(KNOB_BLOCK):
+            if pos[k] >= n[k]:
+                break
+            op, args, kw = chains[k][pos[k]]
+            prog.emit(op, *args, **kw)
+            pos[k] += 1
+            done += 1
 
 
 # ---- the kernel ----------------------------------------------------------------------------------------------------
 KP4_1 = borrowed(4, 1)
 KP8_4 = borrowed(8, 4)
-KP16_1 = borrowed(16, 1)
+KP32_1 = borrowed(32, 1)
+NX_B = WIDE_B + 8            # -X3 = PPP (wide) - R^2 - 2(-Q) + 8p
 
 
 def build():
@@ -417,6 +458,11 @@ def build():
     e("s_cbranch_execz", ("label", "L_no_init%="))
     for i in range(14):
         e("v_sub_u32", v(NX[i]), lit(KP4_1[i]), v(QX[i]))
+        if i > 0:
+            e("v_add_u32", v(NX[i]), v(NX[i]), v(T1))
+        if i < 13:                                         # carried: -X keeps its limbs under 2^28
+            e("v_lshrrev_b32", v(T1), lit(W), v(NX[i]))
+            e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
     for i in range(14):
         e("v_sub_u32", v(NY[i]), lit(KP4_1[i]), v(QY[i]))
     for i in range(14):
@@ -454,20 +500,21 @@ def build():
     p.label("L_no_next%=")
     # ---- the mixed addition, first part: U2 = QX ZZ1, S2 = QY ZZZ1; P = U2 + (-X1), R = S2 + (-Y1)
     qx, qy = Val(QX, 2, 1), Val(QY, 4, 2)
-    nx, ny = Val(NX, 10, 2), Val(NY, 4, 2)
+    nx, ny = Val(NX, NX_B, 1), Val(NY, 4, 2)
     zz, zzz = Val(ZZ, 2, 1), Val(ZZZ, 2, 1)
     e("s_mov_b64", EXEC, sp(sACT))
     e("s_cbranch_execz", ("label", "L_skip_a%="))
-    interleave(p, chain_mul(qx, zz, U, M1, ACC1, T1), chain_mul(qy, zzz, S, M2, ACC2, T2r))
+    interleave(p, chain_mul(qx, zz, U, M1, ACC1, T1, wide=True), chain_mul(qy, zzz, S, M2, ACC2, T2r, wide=True))
     for i in range(14):
         e("v_add_u32", v(U[i]), v(U[i]), v(NX[i]))
         e("v_add_u32", v(S[i]), v(S[i]), v(NY[i]))
-    pp_ = Val(U, 2 + nx.B, 1 + nx.L)
-    rr = Val(S, 2 + ny.B, 1 + ny.L)
-    # P == 0 mod p? value = k p with k < 16 <=> (low 56 bits) p^-1 < 16 mod 2^56, tested 28 bits at a time
+    pp_ = Val(U, WIDE_B + nx.B, 1 + nx.L)
+    rr = Val(S, WIDE_B + ny.B, 1 + ny.L)
+    # P == 0 mod p? value = k p with k < 64 <=> (low 56 bits) p^-1 < 64 mod 2^56, tested 28 bits at a time
+    assert pp_.B <= 64
     e("v_mul_lo_u32", v(T1), v(U[0]), s(sINVP))
     e("v_and_b32", v(T1), s(sMASK), v(T1))
-    e("v_cmp_gt_u32", VCC, lit(16), v(T1))
+    e("v_cmp_gt_u32", VCC, lit(64), v(T1))
     e("s_cbranch_vccz", ("label", "L_no_cand%="))
     # second limb of k p: ((k MOD0) >> 28) + k MOD1, against limb 1 of P plus limb 0's carry
     e("s_mov_b64", sp(sTMP), VCC)
@@ -495,10 +542,11 @@ def build():
     for i in range(14):
         e("v_lshlrev_b32", v(D1[i]), lit(1), v(U[i]))
         e("v_lshlrev_b32", v(D2[i]), lit(1), v(S[i]))
-    interleave(p, chain_sqr(pp_, D1, PP, M1, ACC1, T1), chain_sqr(rr, D2, RR2, M2, ACC2, T2r))
-    pp, rr2 = Val(PP, 2, 1), Val(RR2, 2, 1)
-    interleave(p, chain_mul(pp_, pp, D1, M1, ACC1, T1), chain_mul(nx, pp, D2, M2, ACC2, T2r))
-    ppp, nq = Val(D1, 2, 1), Val(D2, 2, 1)          # nq = (-X1) PP = -Q
+    interleave(p, chain_sqr(pp_, D1, PP, M1, ACC1, T1, wide=True), chain_sqr(rr, D2, RR2, M2, ACC2, T2r))
+    pp, rr2 = Val(PP, WIDE_B, 1), Val(RR2, NARROW_B, 1)
+    interleave(p, chain_mul(pp_, pp, D1, M1, ACC1, T1, wide=True), chain_mul(nx, pp, D2, M2, ACC2, T2r))
+    ppp, nq = Val(D1, WIDE_B, 1), Val(D2, NARROW_B, 1)          # nq = (-X1) PP = -Q
+    assert rr2.B + 2 * nq.B <= 8
     # X3 = R^2 - PPP - 2Q  ->  -X3 = PPP - R^2 - 2(-Q) + 8p, carried: limbs < 2^28
     for i in range(14):
         e("v_lshl_add_u32", v(T1), v(D2[i]), lit(1), v(RR2[i]))          # 2(-Q) + R^2        < 3 2^28
@@ -510,14 +558,15 @@ def build():
         if i < 13:
             e("v_lshrrev_b32", v(T2r), lit(W), v(NX[i]))
             e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
-    nx3 = Val(NX, 2 + 8, 1)
-    # t1 = (-Q) - (-X3) + 16p  [= -(Q - X3)],  t2 = 4p - PPP
+    nx3 = Val(NX, ppp.B + 8, 1)
+    # t1 = (-Q) - (-X3) + 32p  [= -(Q - X3)],  t2 = 32p - PPP
+    assert nx3.B <= 32 and ppp.B <= 32
     for i in range(14):
-        e("v_add_u32", v(D2[i]), lit(KP16_1[i]), v(D2[i]))
+        e("v_add_u32", v(D2[i]), lit(KP32_1[i]), v(D2[i]))
         e("v_sub_u32", v(D2[i]), v(D2[i]), v(NX[i]))
-        e("v_sub_u32", v(U[i]), lit(KP4_1[i]), v(D1[i]))
-    t1 = Val(D2, 2 + 16, 1 + 2)
-    t2 = Val(U, 4, 2)
+        e("v_sub_u32", v(U[i]), lit(KP32_1[i]), v(D1[i]))
+    t1 = Val(D2, nq.B + 32, 1 + 2)
+    t2 = Val(U, 32, 2)
     # ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP, -Y3 = R t1 + (-Y1) t2   (three chains; each output overwrites an input limb by limb:
     # output limb k - 14 is written at column k, the input limb k - 14 was last read at column k - 1)
     interleave(p, chain_mul(zz, pp, ZZ, M1, ACC1, T1), chain_mul(zzz, ppp, ZZZ, M2, ACC2, T2r),
