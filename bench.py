@@ -143,7 +143,9 @@ GATHER_PEAK_ROWS = 1.31e10                       # tools/gather_bench.hip on MI3
 def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launch_override=None):
     """Roofline object of the dominant MSM kernel of one engine, from the library's hipEvent timings of a timed region:
     `achieved` = algorithmic bytes per launch / average launch duration (524,336 B per 4096-term MSM)."""
-    dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
+    # the direct engine's accumulation runs as the hand-scheduled kernel (k_direct_accumulate_asm, tools/gen_direct_asm.py) unless
+    # LWKZG_DIRECT_ASM=0 or a handful of blobs put it on the compiler-scheduled one
+    dom = ("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in prof else "k_direct_accumulate") if direct_bits else "k_bucket_accumulate"
     k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
     avg_ms = k["total_ms"] / max(1, k["launches"])
     # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
@@ -322,7 +324,7 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         d_t = dev_bytes(B.synthetic_batch(5000, tiles))
         steps = 10
         el, kern = region(lambda: D.msm_tiled_sharded(d_t, tiles * 4096, ts, dev), steps, 3)
-        dom = "k_direct_accumulate" if direct_bits else "k_bucket_accumulate"
+        dom = ("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in kern else "k_direct_accumulate") if direct_bits else "k_bucket_accumulate"
         ms = kern.get(dom, {}).get("avg_ms", 0.0)
         lps = max(1, round(kern.get(dom, {}).get("launches", steps) / steps))
         algo = (tiles * 4096 * 128 + 48) / lps  # 2^20 x (32 B scalar + 96 B affine point) + 48 B, per launch
@@ -616,7 +618,7 @@ def main():
             value = tiles_total * 4096 * args.steps / elapsed      # terms per second, whole job
         override = None
         if args.op == "tiled_msm":    # a tile is one 4096-term MSM; rank 0's share of the tiles per launch
-            k0 = prof.get("k_direct_accumulate" if direct_bits else "k_bucket_accumulate", {"launches": 0})
+            k0 = prof.get(("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in prof else "k_direct_accumulate") if direct_bits else "k_bucket_accumulate", {"launches": 0})
             override = D.shard_range(tiles_total, world, 0)[1] / max(1, round(k0["launches"] / max(1, args.steps)))
         roofline, nwin = engine_picture(K, capi, direct_bits, prof, elapsed, args.steps, n, override)
         dom = roofline["kernel"]

@@ -328,8 +328,10 @@ typedef G1Xyzz29i FoldPoint;
 #endif
 
 __device__ __forceinline__ FoldPoint load_lane_sum(const uint32_t *src) {
-    F29<25, kFoldInl, 1> nx;  // (tools/gen_direct_asm.py: NX_B)
-    F29<4, kFoldInl, 2> ny;
+    // bounds as tools/gen_direct_asm.py leaves them: -X < 25p, and -Y, ZZ, ZZZ < 17p (products whose reduction digits are
+    // not masked); one product by 1 each brings them to the < 2p the point type holds
+    F29<25, kFoldInl, 1> nx;
+    F29<17, kFoldInl, 1> ny, zz, zzz;
     FoldPoint acc;
     const uint4 *s4 = (const uint4 *)src;
     uint32_t wds[kLaneWords];
@@ -342,12 +344,16 @@ __device__ __forceinline__ FoldPoint load_lane_sum(const uint32_t *src) {
     for (int i = 0; i < 14; i++) {
         nx.l[i] = wds[i];
         ny.l[i] = wds[14 + i];
-        acc.zz.l[i] = wds[28 + i];
-        acc.zzz.l[i] = wds[42 + i];
+        zz.l[i] = wds[28 + i];
+        zzz.l[i] = wds[42 + i];
     }
     const F29<1, kFoldInl> one = F29<1, kFoldInl>::one();
+    const bool inf = zz.is_literal_zero();
     acc.x = neg(nx) * one;  // the stream keeps -X and -Y
     acc.y = neg(ny) * one;
+    acc.zz = zz * one;
+    acc.zzz = zzz * one;
+    if (inf) acc = FoldPoint::infinity();
     return acc;
 }
 

@@ -84,7 +84,7 @@ def vregs(name, n, align=1):
 
 
 NX = vregs("NX", 14)        # -X of the accumulator   (B <= 25, L = 1)
-NY = vregs("NY", 14)        # -Y                      (B <= 4,  L <= 2)
+NY = vregs("NY", 14)        # -Y                      (B <= 17, L = 1)
 ZZ = vregs("ZZ", 14)
 ZZZ = vregs("ZZZ", 14)
 ROW = vregs("ROW", 28, 2)   # the gathered table row: QX = ROW[0:14], QY = ROW[14:28]
@@ -465,6 +465,11 @@ def build():
             e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
     for i in range(14):
         e("v_sub_u32", v(NY[i]), lit(KP4_1[i]), v(QY[i]))
+        if i > 0:
+            e("v_add_u32", v(NY[i]), v(NY[i]), v(T1))
+        if i < 13:
+            e("v_lshrrev_b32", v(T1), lit(W), v(NY[i]))
+            e("v_and_b32", v(NY[i]), s(sMASK), v(NY[i]))
     for i in range(14):
         e("v_mov_b32", v(ZZ[i]), lit(R1[i]))
     for i in range(14):
@@ -500,8 +505,8 @@ def build():
     p.label("L_no_next%=")
     # ---- the mixed addition, first part: U2 = QX ZZ1, S2 = QY ZZZ1; P = U2 + (-X1), R = S2 + (-Y1)
     qx, qy = Val(QX, 2, 1), Val(QY, 4, 2)
-    nx, ny = Val(NX, NX_B, 1), Val(NY, 4, 2)
-    zz, zzz = Val(ZZ, 2, 1), Val(ZZZ, 2, 1)
+    nx, ny = Val(NX, NX_B, 1), Val(NY, WIDE_B, 1)
+    zz, zzz = Val(ZZ, WIDE_B, 1), Val(ZZZ, WIDE_B, 1)
     e("s_mov_b64", EXEC, sp(sACT))
     e("s_cbranch_execz", ("label", "L_skip_a%="))
     interleave(p, chain_mul(qx, zz, U, M1, ACC1, T1, wide=True), chain_mul(qy, zzz, S, M2, ACC2, T2r, wide=True))
@@ -569,8 +574,8 @@ def build():
     t2 = Val(U, 32, 2)
     # ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP, -Y3 = R t1 + (-Y1) t2   (three chains; each output overwrites an input limb by limb:
     # output limb k - 14 is written at column k, the input limb k - 14 was last read at column k - 1)
-    interleave(p, chain_mul(zz, pp, ZZ, M1, ACC1, T1), chain_mul(zzz, ppp, ZZZ, M2, ACC2, T2r),
-               chain_mul_add(rr, t1, ny, t2, NY, RR2, ACC3, T3))
+    interleave(p, chain_mul(zz, pp, ZZ, M1, ACC1, T1, wide=True), chain_mul(zzz, ppp, ZZZ, M2, ACC2, T2r, wide=True),
+               chain_mul_add(rr, t1, ny, t2, NY, RR2, ACC3, T3, wide=True))
     assert nx3.B <= nx.B and nx3.L <= nx.L
     p.label("L_skip_b%=")
     e("s_mov_b64", EXEC, lit(-1))
@@ -871,8 +876,10 @@ class Sim:
                 for r, val in self.pending:
                     self.vr[r] = val
                 self.pending = []
-            elif op == "s_nop":
+            elif op in ("s_nop", "s_sleep"):
                 pass
+            elif op == "s_branch":
+                pc = self.labels[a[0][1]]
             elif op == "global_load_dwordx4":
                 if self.exec & 1:
                     addr = self.g64(a[1]) + kw.get("offset", 0)
