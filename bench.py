@@ -423,6 +423,12 @@ def main():
                      "note": "backend nccl IS RCCL on ROCm; collectives of this run: one broadcast of the setup image, barriers, "
                              "the max-over-ranks of the timings"}
 
+    # first use of the HIP runtime by this process, timed apart from the load (a fresh process on a fresh box pays about a
+    # second here, whichever call comes first)
+    t_init0 = time.perf_counter()
+    capi.runtime_init()
+    t_hip_init = time.perf_counter() - t_init0
+
     # trusted setup: rank 0 parses + validates + builds the fixed-base table, one RCCL broadcast delivers it; every rank
     # then holds the engine a plain load selects (the default engine: engine.hip, direct_from_env)
     t_load0 = time.perf_counter()
@@ -431,6 +437,7 @@ def main():
         ts = D.broadcast_trusted_setup(ts, dev, src=0)
     t_load = time.perf_counter() - t_load0
     default_bits = ts.direct_table_bits()
+    load_breakdown = ts.timing_report()
 
     n = args.batch
     first = rank * n                       # shard: blob k of the job lives on GPU floor(k / n)
@@ -563,6 +570,7 @@ def main():
         ts.enable_direct_table(int(args.direct_bits))
         direct_bits = int(args.direct_bits)
     t_table = time.perf_counter() - t_tab0
+    table_breakdown = ts.timing_report().get("last_table_build") if direct_bits else None
     direct_bits_min, t_table_max = direct_bits, t_table
     if distributed:   # every rank should have got the same width; report it if one did not
         tb = torch.tensor([direct_bits], dtype=torch.int32, device=dev)
@@ -672,13 +680,20 @@ def main():
                        "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
             "roofline": roofline,
             "kernels": kernels,
+            "hip_first_use_init_s": t_hip_init,
             "setup_load_s": t_load,
+            "setup_load_breakdown_ms": load_breakdown.get("load"),
+            "default_table_build_breakdown_ms": load_breakdown.get("last_table_build"),
             "msm_path": ("direct table, %d-bit windows, %d windows, %d-byte rows, %.0f GB resident" % (
                 direct_bits, nwin, ts.direct_row_bytes(), capi.direct_table_bytes(direct_bits, ts.direct_row_bytes()) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
             "engine_note": "the timed region runs on the widest direct table that fits (--direct-bits auto, an explicit lwkzg_enable_direct_table "
                            "call); `default_engine` is the same workload on the engine a plain load selects, `bucket_engine` on the low-memory fallback",
             "direct_table_build_s": t_table if direct_bits else None,
             "direct_table_build_s_max_over_ranks": t_table_max if direct_bits else None,
+            "direct_table_build_breakdown_ms": table_breakdown,
+            "direct_table_build_breakdown_note": "free_old = hipFree of the table in place, table_malloc = ONE hipMalloc of the new table: the driver "
+                                                 "provisions device memory at 15-26 ms per GB on the boxes measured, serially, whatever the API or the "
+                                                 "number of calls (tools/alloc_bench.hip, profiles/r03_alloc_bench.txt); kernels = k_direct_qbase + k_direct_build" if direct_bits else None,
             "direct_table_build_note": "every rank builds its own table from the broadcast setup points, once, outside the timed region" if direct_bits else None,
         }
         res["dist"] = dist_info

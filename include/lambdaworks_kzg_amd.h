@@ -279,6 +279,14 @@ void lwkzg_profile_enable(int on);
 void lwkzg_profile_reset(void);
 /* JSON: {"kernel": {"launches": n, "total_ms": t}, ...}; returns bytes needed (incl. NUL) */
 size_t lwkzg_profile_report(char *buf, size_t cap);
+/* JSON: the wall-clock milliseconds of this settings object's load (context, points + tables, G2 + FFT settings, the
+ * default engine's table) and of its last lwkzg_enable_direct_table (freeing the old table, hipMalloc of the new one,
+ * scratch, build kernels); returns bytes needed (incl. NUL). The table's hipMalloc dominates: the driver provisions
+ * device memory at 15-26 ms per GB on the boxes measured (tools/alloc_bench.hip). */
+size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap);
+/* First use of the HIP runtime by this process (device context + this library's code object), so that a caller can pay
+ * and time it apart from its first real call. 0, or -1 without a GPU. */
+int lwkzg_runtime_init(void);
 /* MSM plan constants, for roofline arithmetic in bench.py */
 int lwkzg_msm_window_bits(void);
 int lwkzg_msm_num_windows(void);

@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
+    "lwkzg_timing_report", "lwkzg_runtime_init",
     "lwkzg_release_context", "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
 ]
 
@@ -78,6 +79,8 @@ def lib():
     l.verify_blob_kzg_proof.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, ps]
     l.verify_blob_kzg_proof_batch.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
     l.lwkzg_set_mode.argtypes = [ci]
+    l.lwkzg_timing_report.argtypes = [ps, C.c_char_p, sz]
+    l.lwkzg_timing_report.restype = sz
     l.lwkzg_settings_set_mode.argtypes = [ps, ci]
     l.lwkzg_settings_get_mode.argtypes = [ps]
     l.lwkzg_blob_to_kzg_commitment_batch.argtypes = [C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
@@ -153,6 +156,12 @@ def set_mode(mode):
 
 def get_mode():
     return lib().lwkzg_get_mode()
+
+
+def runtime_init():
+    """first use of the HIP runtime by this process (device context, code object load): timed apart from the first real call"""
+    if lib().lwkzg_runtime_init() != 0:
+        raise KzgError("lwkzg_runtime_init", C_KZG_ERROR)
 
 
 def set_device(ordinal):
@@ -236,6 +245,13 @@ class TrustedSetup:
     def direct_row_bytes(self):
         """128 = table rows aligned to 128-byte lines, 112 = packed, 0 = bucket engine."""
         return lib().lwkzg_direct_row_bytes(self.ref())
+
+    def timing_report(self):
+        """where the milliseconds of the load and of the last table build went (lwkzg_timing_report)"""
+        n = lib().lwkzg_timing_report(self.ref(), None, 0)
+        buf = C.create_string_buffer(n)
+        lib().lwkzg_timing_report(self.ref(), buf, n)
+        return json.loads(buf.value.decode())
 
     def free(self):
         if self._loaded:

@@ -14,6 +14,7 @@
 // Replaces, like msm.hip, lambdaworks_math::msm::pippenger::msm as reached from KZG::commit / KZG::open
 // (call sites /root/reference/src/lib.rs:242,270,329,394).
 #include <stdlib.h>
+#include <chrono>
 #include "kernels.h"
 
 namespace lwk {
@@ -132,16 +133,22 @@ __global__ __launch_bounds__(256) void k_direct_build(const G1Affine29 *__restri
     }
 }
 
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st) {
+static double wall_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st, double *ms) {
     const DirectPlanRt P = make_plan(bits);
     if (!P.entries) return hipErrorInvalidValue;
     G1Affine29 *qbase = nullptr;
     F29<2> *scratch = nullptr;
+    const double t0 = wall_ms();
     // lanes in flight during the build: 4.7 GB of scratch for the wide tables, a quarter of that (one wave per SIMD) for
     // the narrow ones (the default engine's table should not need gigabytes of headroom to be built)
     const size_t n_threads = bits >= 14 ? 256 * 1024 : 64 * 1024;
     hipError_t e = hipMalloc((void **)&qbase, (size_t)P.nw * kBlobElems * sizeof(G1Affine29));
     if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)kChunk * 5 * n_threads * sizeof(F29<2>));
+    const double t1 = wall_ms();
     if (e == hipSuccess) {
         {
             ProfScope p("k_direct_qbase", st);
@@ -157,8 +164,14 @@ hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *tabl
         }
         e = hipStreamSynchronize(st);
     }
+    const double t2 = wall_ms();
     if (qbase) hipFree(qbase);
     if (scratch) hipFree(scratch);
+    if (ms) {
+        ms[0] = t1 - t0;
+        ms[1] = t2 - t1;
+        ms[2] = wall_ms() - t2;
+    }
     return e;
 }
 

@@ -154,6 +154,20 @@ struct ProofFront {
     bool leader_active = false;
 };
 
+// Where the seconds of a load and of a table build went (lwkzg_timing_report): wall-clock milliseconds of the host thread.
+struct BuildTiming {
+    int bits = 0;
+    size_t row_bytes = 0, table_bytes = 0;
+    double free_old_ms = 0, table_malloc_ms = 0, scratch_malloc_ms = 0, kernels_ms = 0, scratch_free_ms = 0, total_ms = 0;
+};
+struct LoadTiming {
+    double context_ms = 0;           // streams, events, the small device buffers
+    double points_and_tables_ms = 0; // upload, decompression + subgroup checks, blst layout, 9 MB fixed-base table, D2H
+    double g2_and_fft_ms = 0;        // G2 points on the host, twiddles and FFTSettings
+    double default_table_ms = 0;     // the engine the load selects (BuildTiming of it is kept as the last build)
+    double total_ms = 0;
+};
+
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {
     FFTSettings fs;
@@ -194,6 +208,8 @@ struct Ctx {
     std::mutex verify_mu;
     std::mutex mu;
     std::atomic<int> mode_override{-1};  // lwkzg_settings_set_mode: -1 = follow the process-wide default
+    BuildTiming last_build;              // written under mu (enable_direct_table)
+    LoadTiming load_timing;
 };
 
 Ctx *ctx_of(const KZGSettings *s);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise

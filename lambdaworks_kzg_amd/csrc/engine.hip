@@ -1203,13 +1203,57 @@ size_t lwkzg_profile_report(char *buf, size_t cap) {
     return s.size() + 1;
 }
 
+// first use of the HIP runtime by this process (device context, this library's code object): what a fresh process pays
+// once, whichever call comes first. Returns 0, or -1 without a GPU.
+__global__ void k_runtime_init(int *p) {
+    if (p) *p = 1;
+}
+
+extern "C" int lwkzg_runtime_init(void) {
+    if (!gpu_available()) return -1;
+    if (hipSetDevice(g_default_device.load()) != hipSuccess || hipFree(nullptr) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_runtime_init, dim3(1), dim3(1), 0, nullptr, (int *)nullptr);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+
+// JSON: where the milliseconds of this settings object's load and of its last table build went
+extern "C" size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap) {
+    Ctx *c = ctx_of(s);
+    char tmp[1024];
+    int k = 0;
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        const LoadTiming &l = c->load_timing;
+        const BuildTiming &b = c->last_build;
+        k = snprintf(tmp, sizeof tmp,
+                     "{\"load\": {\"context_ms\": %.3f, \"points_and_tables_ms\": %.3f, \"g2_and_fft_ms\": %.3f, \"default_table_ms\": %.3f, "
+                     "\"total_ms\": %.3f}, \"last_table_build\": {\"bits\": %d, \"row_bytes\": %zu, \"table_bytes\": %zu, \"free_old_ms\": %.3f, "
+                     "\"table_malloc_ms\": %.3f, \"scratch_malloc_ms\": %.3f, \"kernels_ms\": %.3f, \"scratch_free_ms\": %.3f, \"total_ms\": %.3f}}",
+                     l.context_ms, l.points_and_tables_ms, l.g2_and_fft_ms, l.default_table_ms, l.total_ms, b.bits, b.row_bytes, b.table_bytes,
+                     b.free_old_ms, b.table_malloc_ms, b.scratch_malloc_ms, b.kernels_ms, b.scratch_free_ms, b.total_ms);
+    } else {
+        k = snprintf(tmp, sizeof tmp, "{}");
+    }
+    if (buf && cap) {
+        size_t n = (size_t)k < cap - 1 ? (size_t)k : cap - 1;
+        memcpy(buf, tmp, n);
+        buf[n] = 0;
+    }
+    return (size_t)k + 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // trusted setup
 
 static C_KZG_RET setup_from_bytes(KZGSettings *out, const uint8_t *g1_bytes, const uint8_t *g2_bytes) {
     Ctx *c = nullptr;
+    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = wall();
     C_KZG_RET rc = ctx_new(&c);
     if (rc != C_KZG_OK) return rc;
+    LoadTiming lt;
+    lt.context_ms = wall() - t_start;
+    double t_mark = wall();
     const size_t n1 = kBlobElems, n2 = TRUSTED_SETUP_NUM_G2_POINTS;
     uint8_t *d_in = nullptr;
     int32_t *d_status = nullptr;
@@ -1236,8 +1280,11 @@ static C_KZG_RET setup_from_bytes(KZGSettings *out, const uint8_t *g1_bytes, con
             if (h_status[i] == 1) { set_error("g1 point %zu is the point at infinity: the reference cannot read such a setup back (srs.rs:155-172)", i); good = false; break; }
         }
         if (!good) break;
+        lt.points_and_tables_ms = wall() - t_mark;
+        t_mark = wall();
         if (!g2_fill_values(g2v, g2_bytes, n2)) { if (!get_error()[0]) set_error("invalid g2 point in trusted setup"); break; }
         rc = ctx_finish_fft(c);
+        lt.g2_and_fft_ms = wall() - t_mark;
     } while (0);
     if (d_in) hipFree(d_in);
     if (d_status) hipFree(d_status);
@@ -1251,7 +1298,11 @@ static C_KZG_RET setup_from_bytes(KZGSettings *out, const uint8_t *g1_bytes, con
     out->fs = &c->fs;
     out->g1_values = g1v;
     out->g2_values = g2v;
+    t_mark = wall();
     direct_from_env(out);
+    lt.default_table_ms = wall() - t_mark;
+    lt.total_ms = wall() - t_start;
+    c->load_timing = lt;
     return C_KZG_OK;
 }
 
@@ -2091,7 +2142,11 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
         return C_KZG_BADARGS;
     }
     const int old_bits = c->direct_bits;
+    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = wall();
     dev_free(c->direct_table);  // (the old and the new table need not fit side by side)
+    BuildTiming bt;
+    bt.free_old_ms = wall() - t_start;
     c->direct_bits = 0;
     if (c->twin) {
         c->twin->direct_table = nullptr;
@@ -2102,9 +2157,15 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
     // own buffers), packed otherwise; LWKZG_DIRECT_ROW=112|128 forces one (A/B runs)
     auto build_rows = [&](int bits, size_t row) -> hipError_t {
         G1Affine29 *t = nullptr;
+        const double t0 = wall();
         hipError_t e = hipMalloc((void **)&t, direct_table_entries(bits) * row);
+        bt.table_malloc_ms += wall() - t0;
         if (e == hipSuccess) {
-            e = build_direct_table(bits, c->points, t, row, c->stream);
+            double ms[3] = {0, 0, 0};
+            e = build_direct_table(bits, c->points, t, row, c->stream, ms);
+            bt.scratch_malloc_ms += ms[0];
+            bt.kernels_ms += ms[1];
+            bt.scratch_free_ms += ms[2];
             if (e != hipSuccess) hipFree(t);
         }
         if (e != hipSuccess) {
@@ -2114,6 +2175,9 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
         c->direct_table = t;
         c->direct_bits = bits;
         c->direct_row_bytes = row;
+        bt.bits = bits;
+        bt.row_bytes = row;
+        bt.table_bytes = direct_table_entries(bits) * row;
         if (c->twin) {
             c->twin->direct_table = t;
             c->twin->direct_bits = bits;
@@ -2132,6 +2196,8 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
         return build_rows(bits, kDirectRowPacked);
     };
     const hipError_t e = build(window_bits);
+    bt.total_ms = wall() - t_start;
+    c->last_build = bt;
     if (e != hipSuccess) {
         if (old_bits) (void)build(old_bits);  // the engine the settings had stays in place
         set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, direct_table_entries(window_bits) * kDirectRowPacked,

@@ -47,7 +47,8 @@ constexpr size_t kDirectRowAligned = 128, kDirectRowPacked = 112;
 constexpr size_t kDirectAlignedHeadroom = (size_t)8 << 30;  // what an aligned table must leave free (two workspaces, verification scratch, the caller's buffers)
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st);
+// ms[0] = the scratch allocations, ms[1] = the build kernels (to completion), ms[2] = freeing the scratch (host wall clock; may be null)
+hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st, double *ms = nullptr);
 // sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused
 // otherwise); `lane_scratch` 4096 * n_blobs entries (the per-lane sums of the hand-scheduled kernel) and `redo` n_blobs words (its flags).
 // fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
