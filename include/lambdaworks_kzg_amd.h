@@ -183,6 +183,12 @@ C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void 
 C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *proofs48_dev, const void *blobs_dev, size_t n,
                                               const KZGSettings *s, void *stream, int32_t *status_dev);
 C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch);
+/* lwkzg_reserve covers calls on ONE caller stream. A device-resident call that arrives on a second stream while the
+ * workspace is busy runs on a second context of the settings object (own streams and workspace, about 1.8 MB per blob of
+ * max_batch, over the same tables); unless reserved here it is created inside that first overlapped call, which then
+ * allocates and synchronises the device once. caller_streams >= 2 creates and reserves it now. Footprint of a load beside
+ * this: the default engine's table (41 GB when the device is empty, see lwkzg_enable_direct_table below). */
+C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int caller_streams);
 
 /* "Direct" fixed-base MSM for this settings object: trade HBM capacity for arithmetic. With every
  * multiple d * 2^(window_bits * j) * P_i of every setup point resident (window_bits 10 .. 16: 6, 11, 21, 36, 68,

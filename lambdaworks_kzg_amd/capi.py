@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_set_mode", "lwkzg_get_mode", "lwkzg_settings_set_mode", "lwkzg_settings_get_mode",
     "lwkzg_blob_to_kzg_commitment_batch",
     "lwkzg_compute_blob_kzg_proof_batch", "lwkzg_compute_kzg_proof_batch",
-    "lwkzg_blob_to_kzg_commitment_batch_device", "lwkzg_compute_blob_kzg_proof_batch_device", "lwkzg_reserve",
+    "lwkzg_blob_to_kzg_commitment_batch_device", "lwkzg_compute_blob_kzg_proof_batch_device", "lwkzg_reserve", "lwkzg_reserve_streams",
     "lwkzg_g1_lincomb_setup_device", "lwkzg_fr_ntt4096_device",
     "lwkzg_setup_image_bytes", "lwkzg_setup_export_device", "lwkzg_setup_import_device",
     "lwkzg_device_count", "lwkzg_set_device", "lwkzg_version", "lwkzg_last_error",
@@ -97,6 +97,7 @@ def lib():
     l.lwkzg_verify_shards_finish.argtypes = [C.POINTER(C.c_bool), C.c_char_p, sz, sz, ps]
     l.lwkzg_release_context.argtypes = [ps]
     l.lwkzg_reserve.argtypes = [ps, sz]
+    l.lwkzg_reserve_streams.argtypes = [ps, sz, ci]
     l.lwkzg_enable_direct_table.argtypes = [ps, ci]
     l.lwkzg_direct_table_bits.argtypes = [ps]
     l.lwkzg_direct_num_windows.argtypes = [ci]
@@ -221,8 +222,8 @@ class TrustedSetup:
     def ref(self):
         return C.byref(self.s)
 
-    def reserve(self, n):
-        _check("lwkzg_reserve", lib().lwkzg_reserve(self.ref(), n))
+    def reserve(self, n, caller_streams=1):
+        _check("lwkzg_reserve_streams", lib().lwkzg_reserve_streams(self.ref(), n, caller_streams))
 
     def set_mode(self, mode):
         """This settings object's own semantics (MODE_REFERENCE / MODE_CKZG; -1 = follow the process-wide default)."""

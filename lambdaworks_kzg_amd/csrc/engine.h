@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../include/lambdaworks_kzg_amd.h"
 #include "kernels.h"
+#include "front.h"
 
 namespace lwk {
 
@@ -120,20 +121,17 @@ struct CombineReq {
     int slot = -1;          // pinned staging slot holding the blob
     int mode = 0;
     uint8_t *out48 = nullptr;
-    C_KZG_RET rc = C_KZG_OK;
+    int rc = C_KZG_OK;      // a C_KZG_RET
     State state = QUEUED;
 };
 
+// the threading (queue, leaders, lanes, slots) is front.h's LaneFront; this adds the pinned host memory of the lanes
 struct Combiner {
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<CombineReq *> queue;
-    int leaders = 0;
-    bool lane_busy[kCombineLanes] = {false, false};
+    LaneFront<CombineReq, kCombineLanes> front;
+    std::mutex init_m;
     uint8_t *pinned_blobs = nullptr;                  // kCombineSlots x 131072, hipHostMalloc
     uint8_t *pinned_out[kCombineLanes] = {nullptr, nullptr};     // kCombineMaxBatch x 48
     int32_t *pinned_status[kCombineLanes] = {nullptr, nullptr};  // kCombineMaxBatch
-    std::vector<int> free_slots;
     bool ready = false, failed = false;
 };
 
@@ -144,15 +142,10 @@ struct ProofReq {
     const uint8_t *blob = nullptr, *second = nullptr;
     uint8_t *out = nullptr, *y_out = nullptr;
     int mode = 0;
-    C_KZG_RET rc = C_KZG_OK;
+    int rc = C_KZG_OK;      // a C_KZG_RET
     State state = QUEUED;
 };
-struct ProofFront {
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<ProofReq *> queue;
-    bool leader_active = false;
-};
+typedef LeaderFront<ProofReq> ProofFront;   // front.h
 
 // Where the seconds of a load and of a table build went (lwkzg_timing_report): wall-clock milliseconds of the host thread.
 struct BuildTiming {
@@ -187,7 +180,7 @@ struct Ctx {
     // A second set of streams + workspace over the SAME tables (engine.hip: pick_ctx): device-resident calls that arrive
     // on another caller stream while this context's workspace is still busy run there, so that the latency-shaped head
     // of one call (Fiat-Shamir hash, commitment validation) overlaps the ALU-bound MSM of the other.
-    Ctx *twin = nullptr;
+    std::atomic<Ctx *> twin{nullptr};   // written under mu (pick_ctx), read without it by calls that run on the twin: release / acquire
     bool is_twin = false;
     // Left alone, two proof pipelines that share the GPU fall into step (both hash, then both MSMs fight for the chip).
     // The ALU-bound phase of a proof call therefore takes turns across the two contexts: it waits for this event (the

@@ -211,9 +211,9 @@ static void ctx_destroy(Ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();  // every stream of the context, and the callers' streams that ran its work
-    if (c->twin) {
-        ctx_destroy(c->twin);
-        c->twin = nullptr;
+    if (Ctx *t = c->twin.load(std::memory_order_acquire)) {
+        ctx_destroy(t);
+        c->twin.store(nullptr, std::memory_order_release);
     }
     ws_free(c->ws);
     ws_long_free(c->ws);
@@ -356,12 +356,12 @@ static Ctx *pick_ctx(Ctx *c, hipStream_t st) {
         return c;
     }
     (void)hipGetLastError();  // hipErrorNotReady is an answer
-    if (!c->twin) {
+    if (!c->twin.load(std::memory_order_acquire)) {
         Ctx *t = nullptr;
         if (ctx_new(&t, c) != C_KZG_OK) return c;
-        c->twin = t;
+        c->twin.store(t, std::memory_order_release);
     }
-    return c->twin;
+    return c->twin.load(std::memory_order_acquire);
 }
 
 // twiddles on device + the genuine FFTSettings tables on the host
@@ -501,7 +501,7 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
         // (scratch of the bucket engine, idle on this path: `buckets` holds the per-lane sums of the hand-scheduled kernel,
         // `sorted` the per-workgroup partial sums, `bstart` the redo flags)
         launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
-                          st, (c->primary->twin || shared_chip) ? 2048 : 0);
+                          st, (c->primary->twin.load(std::memory_order_acquire) || shared_chip) ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
@@ -1475,8 +1475,9 @@ static bool coalesce_singles() {
     return on;
 }
 
-static bool combiner_init(Ctx *c) {  // caller holds comb.m
+static bool combiner_init(Ctx *c) {
     Combiner &cb = c->comb;
+    std::lock_guard<std::mutex> lk(cb.init_m);
     if (cb.ready || cb.failed) return cb.ready;
     hipSetDevice(c->device);
     bool ok = hipHostMalloc((void **)&cb.pinned_blobs, kCombineSlots * (size_t)kBlobBytes, hipHostMallocDefault) == hipSuccess;
@@ -1488,7 +1489,10 @@ static bool combiner_init(Ctx *c) {  // caller holds comb.m
         cb.failed = true;  // callers fall back to one launch set each
         return false;
     }
-    for (int k = (int)kCombineSlots - 1; k >= 0; k--) cb.free_slots.push_back(k);
+    {
+        std::lock_guard<std::mutex> fl(cb.front.m);
+        cb.front.add_slots((int)kCombineSlots);
+    }
     cb.ready = true;
     return true;
 }
@@ -1537,7 +1541,7 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
         if (rc != C_KZG_OK) {
             r->rc = rc;
         } else if (cb.pinned_status[lane][i] != 0) {
-            r->rc = map_rc((C_KZG_RET)cb.pinned_status[lane][i], mode);
+            r->rc = (int)map_rc((C_KZG_RET)cb.pinned_status[lane][i], mode);
         } else {
             memcpy(r->out48, cb.pinned_out[lane] + 48 * i, 48);
             r->rc = C_KZG_OK;
@@ -1549,50 +1553,16 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
 // unavailable (no pinned memory): the caller then takes the plain path.
 static bool combine_commit(Ctx *c, uint8_t *out48, const uint8_t *blob, int mode, C_KZG_RET *rc_out) {
     Combiner &cb = c->comb;
+    if (!combiner_init(c)) return false;
     CombineReq req;
     req.mode = mode;
     req.out48 = out48;
-    std::unique_lock<std::mutex> lk(cb.m);
-    if (!combiner_init(c)) return false;
-    cb.cv.wait(lk, [&] { return !cb.free_slots.empty(); });
-    req.slot = cb.free_slots.back();
-    cb.free_slots.pop_back();
-    lk.unlock();
-    memcpy(cb.pinned_blobs + (size_t)req.slot * kBlobBytes, blob, kBlobBytes);  // every caller stages its own blob, in parallel
-    lk.lock();
-    cb.queue.push_back(&req);
-    for (;;) {
-        if (req.state == CombineReq::DONE) break;
-        if (req.state == CombineReq::QUEUED && cb.leaders < kCombineLanes) {
-            // lead: take every waiting request of this mode (this one included), up to one launch set
-            int lane = cb.lane_busy[0] ? 1 : 0;
-            cb.lane_busy[lane] = true;
-            cb.leaders++;
-            std::vector<CombineReq *> batch;
-            for (auto it = cb.queue.begin(); it != cb.queue.end() && batch.size() < kCombineMaxBatch;) {
-                if ((*it)->mode == mode) {
-                    (*it)->state = CombineReq::TAKEN;
-                    batch.push_back(*it);
-                    it = cb.queue.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-            lk.unlock();
-            combine_run(c, lane, batch);
-            lk.lock();
-            for (CombineReq *r : batch) {
-                r->state = CombineReq::DONE;
-                cb.free_slots.push_back(r->slot);
-            }
-            cb.lane_busy[lane] = false;
-            cb.leaders--;
-            cb.cv.notify_all();
-            continue;  // req is DONE now: it was part of its own batch
-        }
-        cb.cv.wait(lk);
-    }
-    *rc_out = req.rc;
+    // front.h: every caller stages its own blob (in parallel), the first to find a free lane leads everything queued
+    const int rc = cb.front.submit(
+        req, kCombineMaxBatch, (int)C_KZG_MALLOC,
+        [&](int slot) { memcpy(cb.pinned_blobs + (size_t)slot * kBlobBytes, blob, kBlobBytes); },
+        [&](int lane, const std::vector<CombineReq *> &batch) { combine_run(c, lane, batch); });
+    *rc_out = (C_KZG_RET)rc;
     return true;
 }
 
@@ -1869,35 +1839,10 @@ static C_KZG_RET point_proof_batch_host(Ctx *c, KZGProof *proofs_out, Bytes32 *y
 
 // Concurrent callers of compute_blob_kzg_proof / compute_kzg_proof (one blob per call, as a block builder issues them):
 // whoever arrives while no batch is being run becomes the leader of everything queued in its mode (<= 64) and hands it to
-// `run`, which answers every member; the others wait for their bytes. Same contract as combine_commit.
+// `run`, which answers every member; the others wait for their bytes (front.h: LeaderFront). A `run` that throws (the
+// leader's host vectors: std::bad_alloc) answers every member with C_KZG_MALLOC instead of unwinding across the C ABI.
 static C_KZG_RET front_run(ProofFront &pf, ProofReq &req, const std::function<void(const std::vector<ProofReq *> &)> &run) {
-    std::unique_lock<std::mutex> lk(pf.m);
-    pf.queue.push_back(&req);
-    for (;;) {
-        if (req.state == ProofReq::DONE) break;
-        if (req.state == ProofReq::QUEUED && !pf.leader_active) {
-            pf.leader_active = true;
-            std::vector<ProofReq *> batch;
-            for (auto it = pf.queue.begin(); it != pf.queue.end() && batch.size() < kCombineMaxBatch;) {
-                if ((*it)->mode == req.mode) {
-                    (*it)->state = ProofReq::TAKEN;
-                    batch.push_back(*it);
-                    it = pf.queue.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-            lk.unlock();
-            run(batch);
-            lk.lock();
-            for (ProofReq *r : batch) r->state = ProofReq::DONE;
-            pf.leader_active = false;
-            pf.cv.notify_all();
-            continue;
-        }
-        pf.cv.wait(lk);
-    }
-    return req.rc;
+    return (C_KZG_RET)pf.submit(req, kCombineMaxBatch, (int)C_KZG_MALLOC, run);
 }
 
 // The leader copies the blobs and commitments into contiguous host arrays and runs them as ONE host-pointer batch (host
@@ -2126,6 +2071,26 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch) {
     return ctx_reserve(c, max_batch);
 }
 
+// the same for a caller that will issue device-resident calls on `caller_streams` streams at once: with two or more the
+// settings' second context (own streams and workspace over the same tables, pick_ctx) is created and reserved HERE, so that
+// the first overlapped call neither allocates nor synchronises the device
+C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int caller_streams) {
+    C_KZG_RET rc = lwkzg_reserve(s, max_batch);
+    if (rc != C_KZG_OK || caller_streams < 2) return rc;
+    Ctx *c = ctx_of(s);
+    Ctx *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        t = c->twin.load(std::memory_order_acquire);
+        if (!t) {
+            if (ctx_new(&t, c) != C_KZG_OK) return C_KZG_MALLOC;
+            c->twin.store(t, std::memory_order_release);
+        }
+    }
+    std::lock_guard<std::mutex> lk(t->mu);
+    return ctx_reserve(t, max_batch);
+}
+
 // row_pref: 0 = rows aligned to 128-byte lines when that leaves headroom on the device, else packed; or one of the two
 static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size_t row_pref) {
     Ctx *c = ctx_of(s);
@@ -2133,7 +2098,8 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
     std::lock_guard<std::mutex> lk(c->mu);
     // the twin context launches against the same table under its own lock: keep it out as well (lock order: main, twin)
     std::unique_lock<std::mutex> lk_twin;
-    if (c->twin) lk_twin = std::unique_lock<std::mutex>(c->twin->mu);
+    Ctx *const twin = c->twin.load(std::memory_order_acquire);
+    if (twin) lk_twin = std::unique_lock<std::mutex>(twin->mu);
     LWK_HIP(hipSetDevice(c->device));
     LWK_HIP(hipDeviceSynchronize());  // the table may be in use on any stream, the callers' included
     if (window_bits == c->direct_bits) return C_KZG_OK;
@@ -2148,9 +2114,9 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
     BuildTiming bt;
     bt.free_old_ms = wall() - t_start;
     c->direct_bits = 0;
-    if (c->twin) {
-        c->twin->direct_table = nullptr;
-        c->twin->direct_bits = 0;
+    if (twin) {
+        twin->direct_table = nullptr;
+        twin->direct_bits = 0;
     }
     if (window_bits == 0) return C_KZG_OK;
     // rows aligned to 128-byte lines when that table leaves kDirectAlignedHeadroom of HBM free (workspaces, the caller's
@@ -2178,10 +2144,10 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
         bt.bits = bits;
         bt.row_bytes = row;
         bt.table_bytes = direct_table_entries(bits) * row;
-        if (c->twin) {
-            c->twin->direct_table = t;
-            c->twin->direct_bits = bits;
-            c->twin->direct_row_bytes = row;
+        if (twin) {
+            twin->direct_table = t;
+            twin->direct_bits = bits;
+            twin->direct_row_bytes = row;
         }
         return hipSuccess;
     };

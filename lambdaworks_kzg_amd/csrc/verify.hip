@@ -320,13 +320,14 @@ constexpr size_t kPartial = LWKZG_VERIFY_PARTIAL_BYTES;  // 3 x (flag 1 | x 48 |
 struct Shard {
     Ctx *ctx = nullptr;
     const KZGSettings *s = nullptr;
+    int device = 0;   // kept here: the shard may outlive its settings' context (a caller that frees the setup first)
     size_t n = 0;
     int mode = 0;
     VerifyBuffers vb;
     std::vector<uint8_t> zs, ys, canon_c, canon_p;
     ~Shard() {
-        if (vb.owned) {
-            if (ctx) hipSetDevice(ctx->device);
+        if (vb.owned) {  // device memory of the shard's own: freed on its device whether or not the context still exists
+            hipSetDevice(device);
             hipDeviceSynchronize();
             verify_buffers_free(vb);
         }
@@ -337,6 +338,7 @@ C_KZG_RET shard_begin(Shard &sh, const uint8_t *blobs, const uint8_t *comms, con
                       int mode, bool own_buffers) {
     sh.ctx = ctx_of(s);
     if (!sh.ctx) return C_KZG_ERROR;
+    sh.device = sh.ctx->device;
     sh.s = s;
     sh.n = n;
     sh.mode = mode;
@@ -595,6 +597,10 @@ C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out, LwkzgVerifyShard *sha
                                      size_t first_index) {
     if (!partial_out || !shard || (!records_all && n_total)) return C_KZG_BADARGS;
     Shard &sh = *(Shard *)shard;
+    if (ctx_of(sh.s) != sh.ctx) {  // the setup was freed (or rebuilt) under the shard: its context is gone
+        set_error("lwkzg_verify_shard_partial: the shard's trusted setup is no longer loaded");
+        return C_KZG_BADARGS;
+    }
     HXyzz sums[3];
     HFr ysum;
     C_KZG_RET rc = shard_partial(sh, records_all, n_total, first_index, sums, ysum, nullptr);
