@@ -287,6 +287,13 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
             ts.set_mode(-1)
         assert int(d_s.abs().sum().item()) == 0
         ntt_ms = kern.get("k_ntt4096", {}).get("avg_ms", 0.0)
+        ntt_traffic = ntt_traffic_source = None
+        try:   # committed PMC passes over the all-legs run (tools/pmc_traffic_all.py): every k_ntt4096 launch there is this one
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_all_legs.json")))
+            ntt_traffic = pmc["kernels"]["k_ntt4096"]["largest_launch_traffic_bytes"]
+            ntt_traffic_source = "profiles/r03_pmc_traffic_all_legs.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in this run"
+        except Exception:
+            pass
         launches_per_step = max(1, round(kern.get("k_ntt4096", {}).get("launches", steps) / steps))
         per_launch = n / launches_per_step
         ach = per_launch * NTT_ALGO_BYTES / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
@@ -296,7 +303,7 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                 "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern,
                 "ntt_roofline": {"kernel": "k_ntt4096", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": per_launch * NTT_ALGO_BYTES, "avg_launch_ms": ntt_ms, "blobs_per_launch": per_launch,
-                                 "traffic": None,
+                                 "traffic": ntt_traffic if per_launch == BLOBS_PER_GPU else None, "traffic_source": ntt_traffic_source,
                                  "int_mad": {"mad_u64_u32_per_launch": mads, "achieved_Gmad_per_s": mads / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0,
                                              "peak_theoretical_Gmad_per_s": INT_MAD_PEAK_THEORETICAL / 1e9,
                                              "frac_of_theoretical": mads / (ntt_ms * 1e-3) / INT_MAD_PEAK_THEORETICAL if ntt_ms > 0 else 0.0},

@@ -7,6 +7,8 @@ O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench_err.txt
+python bench.py --force-dist --steps 10 --no-cpu-baseline --no-extra-legs > $O/bench_line_force_dist.json 2>> $O/bench_err.txt
+LWKZG_DIRECT_ASM=0 python bench.py --no-cpu-baseline --no-config-legs > $O/bench_line_compiler_scheduled_arm.json 2>> $O/bench_err.txt
 python bench.py --scalars full --no-cpu-baseline --no-extra-legs > $O/bench_line_full_range_scalars.json 2>> $O/bench_err.txt
 python bench.py --mode ckzg --no-cpu-baseline --no-extra-legs > $O/bench_line_ckzg_mode.json 2>> $O/bench_err.txt
 python bench.py --op blob_proof --batch 256 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
@@ -20,6 +22,9 @@ python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/
 python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
 # per-kernel time of the headline command, of the default engine and of the bucket engine
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_line.json 2> $O/kt_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_all -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_all_line.json 2> $O/kt_all_err.txt
+rm -f $O/kt_all/*kernel_trace.csv
+LWKZG_DIRECT_ASM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cpp -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_cpp_line.json 2> $O/kt_cpp_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --direct-bits default > $O/kt_default_line.json 2> $O/kt_default_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bucket -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --direct-bits 0 > $O/kt_bucket_line.json 2> $O/kt_bucket_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_proof -o kt -- python3 bench.py --op blob_proof --batch 1024 --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_proof_line.json 2> $O/kt_proof_err.txt
@@ -32,11 +37,20 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- $P > $O/w
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_bucket -o fetch -- $P --direct-bits 0 > $O/fetch_bucket_line.json 2> $O/fetch_bucket_err.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_bucket -o write -- $P --direct-bits 0 > $O/write_bucket_line.json 2> $O/write_bucket_err.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_default -o fetch -- $P --direct-bits default > $O/fetch_default_line.json 2> $O/fetch_default_err.txt
+# the same two passes over the run with every leg (k_ntt4096, k_challenge_pairs, k_eval_quotient, the verification kernels)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_all -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch_all_line.json 2> $O/fetch_all_err.txt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_all -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write_all_line.json 2> $O/write_all_err.txt
 # issue-side counters of the headline kernel (SQ: 8 slots per pass; GRBM apart)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_sq1 -o sq -- $P > $O/pmc_sq1_line.json 2> $O/pmc_sq1_err.txt
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq2 -o sq -- $P > $O/pmc_sq2_line.json 2> $O/pmc_sq2_err.txt
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d $O/pmc_sq3 -o sq -- $P > $O/pmc_sq3_line.json 2> $O/pmc_sq3_err.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/pmc_grbm -o grbm -- $P > $O/pmc_grbm_line.json 2> $O/pmc_grbm_err.txt
+# the compiler-scheduled arm of the direct kernel (LWKZG_DIRECT_ASM=0): the A/B of the hand-scheduled loop, same passes
+export LWKZG_DIRECT_ASM=0
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_cpp_sq1 -o sq -- $P > $O/pmc_cpp_sq1_line.json 2> $O/pmc_cpp_sq1_err.txt
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_cpp_sq2 -o sq -- $P > $O/pmc_cpp_sq2_line.json 2> $O/pmc_cpp_sq2_err.txt
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/pmc_cpp_grbm -o grbm -- $P > $O/pmc_cpp_grbm_line.json 2> $O/pmc_cpp_grbm_err.txt
+unset LWKZG_DIRECT_ASM
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_bucket -o sq -- $P --direct-bits 0 > $O/pmc_sq_bucket_line.json 2> $O/pmc_sq_bucket_err.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm_bucket -o grbm -- $P --direct-bits 0 > $O/pmc_grbm_bucket_line.json 2> $O/pmc_grbm_bucket_err.txt
 python tools/host_api_timing.py > $O/host_api_timing.txt 2>&1
@@ -47,7 +61,7 @@ find $O -name "*.csv" | wc -l
 du -sh $O
 timeout 2400 python -m pytest tests -m gpu -q --durations=15 > $O/gpu_test_log.txt 2>&1
 echo "pytest rc=$?" >> $O/gpu_test_log.txt
-timeout 1500 python tools/soak.py --batches 300 --direct-bits 16 > $O/soak.json 2> $O/soak_err.txt
+timeout 1200 python tools/soak.py --batches 300 --direct-bits 16 > $O/soak.json 2> $O/soak_err.txt
 echo "{\"soak_rc\": $?}" >> $O/soak.json
 timeout 600 python tools/soak_ckzg.py --batches 60 > $O/soak_ckzg.json 2> $O/soak_ckzg_err.txt
 LWKZG_DIRECT=16 timeout 400 python tools/soak_verify.py 180 2> $O/soak_verify_err.txt | tail -1 > $O/soak_verify_direct16.json

@@ -1019,7 +1019,43 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
     return sim.valu_executed
 
 
+def mix():
+    """opcode mix of one pass of the loop body (one mixed addition incl. the next digit, the gather and the loop control)"""
+    import collections
+    prog = build()
+    names = [i[0] for i in prog.ins]
+    lo = next(k for k, i in enumerate(prog.ins) if i[0] == "label" and i[1][0].startswith("L_loop"))
+    hi = max(k for k, i in enumerate(prog.ins) if i[0] == "s_cbranch_scc0" and i[1][0][1].startswith("L_loop"))
+    body = [i for i in prog.ins[lo:hi + 1] if i[0] not in ("label", "comment", ".p2align")]
+    # the blocks that run once per lane or never on honest data: first-row copy, second filter of the P = 0 test
+    skip = set()
+    for a, b in (("L_same_scalar", None),):
+        pass
+    c = collections.Counter(i[0] for i in body)
+    init_lo = next(k for k, i in enumerate(prog.ins) if i[0] == "s_cbranch_execz" and i[1][0][1].startswith("L_no_init"))
+    init_hi = next(k for k, i in enumerate(prog.ins) if i[0] == "label" and i[1][0].startswith("L_no_init"))
+    cand_lo = next(k for k, i in enumerate(prog.ins) if i[0] == "s_cbranch_vccz")
+    cand_hi = next(k for k, i in enumerate(prog.ins) if i[0] == "label" and i[1][0].startswith("L_no_cand"))
+    ns_lo = next(k for k, i in enumerate(prog.ins) if i[0] == "s_cbranch_scc0" and i[1][0][1].startswith("L_no_new_scalar"))
+    ns_hi = next(k for k, i in enumerate(prog.ins) if i[0] == "label" and i[1][0].startswith("L_no_new_scalar"))
+    rare = collections.Counter()
+    for lo2, hi2 in ((init_lo, init_hi), (cand_lo, cand_hi), (ns_lo, ns_hi)):
+        rare.update(i[0] for i in prog.ins[lo2 + 1:hi2] if i[0] not in ("label", "comment"))
+    hot = c - rare
+    valu = sum(n for op, n in hot.items() if op.startswith("v_"))
+    print("k_direct_accumulate_asm: one pass of the loop body = one mixed addition (tools/gen_direct_asm.py --mix)")
+    print("  VALU instructions on the path every row takes: %d   (the compiler's schedule of the same addition: 4814, SQ_INSTS_VALU)" % valu)
+    for op, n in sorted(hot.items(), key=lambda kv: -kv[1]):
+        print("    %-22s %5d" % (op, n))
+    print("  blocks that run once per lane, once per scalar or never on honest data (first-row copy, second limb of the P = 0 test,")
+    print("  scalar switch): %d instructions, %d of them VALU" % (sum(rare.values()), sum(n for op, n in rare.items() if op.startswith("v_"))))
+    print("  registers: v0..v%d, s%d..s%d; whole stream: %d instructions" % (NUM_VGPRS - 1, SBASE, NUM_SGPRS - 1,
+                                                                          sum(1 for i in prog.ins if i[0] not in ("label", "comment"))))
+
+
 def main():
+    if "--mix" in sys.argv:
+        return mix()
     if "--selftest" in sys.argv:
         for seed, c in ((1, 16), (2, 13), (3, 10), (4, 16)):
             selftest(seed, c)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Instruction mix of k_direct_accumulate<16>'s basic blocks, from hipcc's own assembly (no GPU needed): the evidence
+"""Instruction mix of k_direct_accumulate<16>'s basic blocks (the compiler-scheduled arm, LWKZG_DIRECT_ASM=0; the hand-scheduled
+loop has tools/gen_direct_asm.py --mix), from hipcc's own assembly (no GPU needed): the evidence
 behind "about 5200 instructions per mixed addition, 3571 of them v_mad_u64_u32" in DESIGN.md section 4a.
 
     python tools/isa_mix.py > profiles/rNN_accumulate_isa_mix.txt
@@ -18,9 +19,10 @@ with tempfile.TemporaryDirectory() as tmp:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
                            "-o", out, src], stderr=subprocess.DEVNULL)
     s = open(out).read()
-i = s.index("_ZN3lwk19k_direct_accumulateILi16EEEvPKNS_7AffineT")
-i = s.index("\n", s.index(":", i))
-j = s.index("s_endpgm", i)
+import re as _re
+m = _re.search(r"^_ZN3lwk19k_direct_accumulateILi16EEEvPKNS_7AffineT[^\n]*:", s, _re.M)     # the function's own label, not a mention of it
+i = m.end()
+j = s.index(".end_amdhsa_kernel", i)
 lines = [l.strip() for l in s[i:j].split("\n") if l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".s")
          and not l.strip().startswith(".p")]
 blocks, cur = [], ["entry", []]

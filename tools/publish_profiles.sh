@@ -2,8 +2,8 @@
 # Copies what tools/collect_profiles.sh left under gpurun_out/final into profiles/ (tracked), keeping only our kernels' rows.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/final; P=profiles; TAG=${1:-r02}
-for f in bench_line bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
+O=gpurun_out/final; P=profiles; TAG=${1:-r03}
+for f in bench_line bench_line_force_dist bench_line_compiler_scheduled_arm bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
          bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm; do
   [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${TAG}_$f.json
 done
@@ -15,7 +15,7 @@ tag = sys.argv[1]
 O = 'gpurun_out/final'
 def ours(rows, col):
     return [rows[0]] + [r for r in rows[1:] if 'lwk::' in r[col] or 'rocclr' in r[col]]
-for d, name in (('kt', 'bench_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats')):
+for d, name in (('kt', 'bench_kernel_stats'), ('kt_all', 'bench_all_legs_kernel_stats'), ('kt_cpp', 'compiler_scheduled_arm_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats')):
     f = '%s/%s/kt_kernel_stats.csv' % (O, d)
     if os.path.exists(f):
         rows = list(csv.reader(open(f)))
@@ -32,6 +32,9 @@ def pmc(dirs, out):
     if hdr:
         csv.writer(open(out, 'w'), quoting=csv.QUOTE_ALL).writerows([hdr] + keep)
 pmc(['pmc_sq1', 'pmc_sq2', 'pmc_sq3', 'pmc_grbm'], 'profiles/%s_pmc_sq_counters.csv' % tag)
+pmc(['pmc_cpp_sq1', 'pmc_cpp_sq2', 'pmc_cpp_grbm'], 'profiles/%s_pmc_compiler_scheduled_arm_sq_counters.csv' % tag)
+pmc(['fetch_all'], 'profiles/%s_pmc_all_legs_fetch_size.csv' % tag)
+pmc(['write_all'], 'profiles/%s_pmc_all_legs_write_size.csv' % tag)
 pmc(['pmc_sq_bucket', 'pmc_grbm_bucket'], 'profiles/%s_pmc_bucket_sq_counters.csv' % tag)
 pmc(['fetch'], 'profiles/%s_pmc_fetch_size.csv' % tag)
 pmc(['write'], 'profiles/%s_pmc_write_size.csv' % tag)
@@ -40,7 +43,9 @@ pmc(['write_bucket'], 'profiles/%s_pmc_bucket_write_size.csv' % tag)
 pmc(['fetch_default'], 'profiles/%s_pmc_default_engine_fetch_size.csv' % tag)
 PY
 python3 tools/pmc_summary.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv $TAG 1024 16 | grep -E "direct_acc|wrote"
-python3 tools/pmc_issue_summary.py k_direct_accumulate $P/${TAG}_issue_summary.json $O/pmc_sq1/sq_counter_collection.csv $O/pmc_sq2/sq_counter_collection.csv $O/pmc_sq3/sq_counter_collection.csv $O/pmc_grbm/grbm_counter_collection.csv > /dev/null
+python3 tools/pmc_issue_summary.py k_direct_accumulate $P/${TAG}_issue_summary_compiler_scheduled_arm.json $O/pmc_cpp_sq1/sq_counter_collection.csv $O/pmc_cpp_sq2/sq_counter_collection.csv $O/pmc_cpp_grbm/grbm_counter_collection.csv > /dev/null
+python3 tools/pmc_traffic_all.py $O/fetch_all/fetch_counter_collection.csv $O/write_all/write_counter_collection.csv $TAG > /dev/null
+python3 tools/pmc_issue_summary.py k_direct_accumulate_asm $P/${TAG}_issue_summary.json $O/pmc_sq1/sq_counter_collection.csv $O/pmc_sq2/sq_counter_collection.csv $O/pmc_sq3/sq_counter_collection.csv $O/pmc_grbm/grbm_counter_collection.csv > /dev/null
 python3 tools/pmc_issue_summary.py k_bucket_accumulate $P/${TAG}_issue_summary_bucket.json $O/pmc_sq_bucket/sq_counter_collection.csv $O/pmc_grbm_bucket/grbm_counter_collection.csv > /dev/null
 ls $P | grep $TAG | wc -l
 [ -s $O/kt_two_streams/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_timeline.txt
