@@ -308,11 +308,11 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1A
                                                                        int scalars_per_lane, DirectPlanRt rt, uint32_t row_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t tid = threadIdx.x;
-    const uint32_t first = blockIdx.x * kDirThreads + tid;
+    const uint32_t first = blockIdx.x * blockDim.x + tid;    // (workgroups of 128 or 256 lanes: launch_direct_t)
     const uint4 *sc = scalars + (size_t)blockIdx.y * kBlobElems * 2;
-    uint32_t *out = lane_out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(kDirThreads * kLaneWords);
+    uint32_t *out = lane_out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(blockDim.x * kLaneWords);
     uint32_t *flag = redo + blockIdx.y;
-    const uint32_t lanes_per_blob = gridDim.x * kDirThreads;
+    const uint32_t lanes_per_blob = gridDim.x * blockDim.x;
     const uint32_t top_lo = (uint32_t)rt.top_base, top_hi = (uint32_t)(rt.top_base >> 32);
     asm volatile(
 #include "direct_asm.inc"
@@ -329,7 +329,6 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1A
 // every thread first adds four lane sums in sequence (all 64 lanes busy), then six shuffle levels -- nine additions deep
 // on a quarter of the waves, where a 256-thread tree is eight deep with most lanes idle on four times as many
 // (0.48 ms -> 0.13 ms at 1024 blobs).
-constexpr int kFoldPerThread = kDirThreads / 64;
 
 // LWK_FOLD_CALL: field products of the lane fold as calls of the shared product function (small code) instead of inlined
 #ifdef LWK_FOLD_CALL
@@ -371,11 +370,12 @@ __device__ __forceinline__ FoldPoint load_lane_sum(const uint32_t *src) {
 }
 
 __global__ __launch_bounds__(64) void k_direct_fold_lanes(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
-                                                          const uint32_t *__restrict__ redo) {
+                                                          const uint32_t *__restrict__ redo, int lanes_per_block) {
+    const int kFoldPerThread = lanes_per_block / 64;
     if (redo[blockIdx.y]) return;  // recomputed by the second pass
     __builtin_amdgcn_s_setprio(2);
     const int lane = threadIdx.x;
-    const uint32_t *src = lane_out + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kDirThreads + lane) * (size_t)kLaneWords;
+    const uint32_t *src = lane_out + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * lanes_per_block + lane) * (size_t)kLaneWords;
     FoldPoint acc = load_lane_sum(src);
     // ONE call site of the (inlined, 48 KB) addition for all nine steps, so that the kernel stays inside the instruction cache:
     // steps 0 .. 2 add this thread's other three lane sums, steps 3 .. 8 are the shuffle tree
@@ -441,17 +441,21 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, s
     G1Xyzz29 *dest = parts == 1 ? sums : partials;
     if (direct_asm_enabled() && wsplit == 1) {
         // the hand-scheduled stream, its lane fold, and a second pass of the C++ kernel over the blobs it flagged (none on
-        // honest data: the launch exits at its first instruction)
+        // honest data: the launch exits at its first instruction). (Workgroups of 128 lanes -- one round of workgroups instead
+        // of two, 128 lane sums per blob to fold instead of 256 -- measured 0.9 % slower in the accumulation than they save
+        // in the fold: profiles/r03_experiments.md.)
+        const int threads = kDirThreads;
         hipMemsetAsync(redo, 0, n_blobs * sizeof(uint32_t), st);
         {
             ProfScope p("k_direct_accumulate_asm", st);
-            hipLaunchKernelGGL(k_direct_accumulate_asm, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(kDirThreads), 0, st, table,
-                               (const uint4 *)scalars_raw, (uint32_t *)lane_scratch, redo, scalars_per_lane, plan, (uint32_t)row_bytes);
+            hipLaunchKernelGGL(k_direct_accumulate_asm, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(threads), 0, st, table,
+                               (const uint4 *)scalars_raw, (uint32_t *)lane_scratch, redo, kBlobElems / (threads * blocks_per_blob), plan,
+                               (uint32_t)row_bytes);
         }
         {
             ProfScope p("k_direct_fold_lanes", st);
             hipLaunchKernelGGL(k_direct_fold_lanes, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(64), 0, st,
-                               (const uint32_t *)lane_scratch, dest, (const uint32_t *)redo);
+                               (const uint32_t *)lane_scratch, dest, (const uint32_t *)redo, threads);
         }
         {
             ProfScope p("k_direct_redo", st);

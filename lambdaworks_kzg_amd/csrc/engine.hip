@@ -1212,8 +1212,16 @@ __global__ void k_runtime_init(int *p) {
 extern "C" int lwkzg_runtime_init(void) {
     if (!gpu_available()) return -1;
     if (hipSetDevice(g_default_device.load()) != hipSuccess || hipFree(nullptr) != hipSuccess) return -1;
-    hipLaunchKernelGGL(k_runtime_init, dim3(1), dim3(1), 0, nullptr, (int *)nullptr);
-    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    // the code object is loaded by asking about one of its kernels -- NOT by launching one: a launch here would have to go to
+    // the NULL stream, and a process that has used the NULL stream once keeps a hardware queue for it, after which the
+    // engine's sub-batch streams no longer run side by side (measured: the bucket engine's two overlapped sub-batches fell
+    // from 61.8k to 52.0k ops/s behind a single one-thread launch on stream 0)
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, (const void *)k_runtime_init) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return 0;
 }
 
 // JSON: where the milliseconds of this settings object's load and of its last table build went
