@@ -261,6 +261,25 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                                 % (nb, max(1, n_streams), "s (consecutive calls alternate; the library overlaps one call's hash with the other's MSM)" if n_streams > 1 else ""),
                     "value": nb * steps / el, "unit": "proofs/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
         return run
+    def commit_two_streams():
+        n = BLOBS_PER_GPU
+        d_b = dev_bytes(B.synthetic_batch(0, n))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        outs = [torch.empty(48 * n, dtype=torch.uint8, device=dev) for _ in range(2)]
+        stats = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        ts.reserve(n, caller_streams=2)
+        k = [0]
+
+        def step():
+            i = k[0] % 2
+            k[0] += 1
+            K.blob_to_kzg_commitment_batch_device(outs[i].data_ptr(), d_b.data_ptr(), n, ts, streams[i].cuda_stream, stats[i].data_ptr())
+        steps = 10
+        el, kern = region(step, steps, 4)
+        assert all(int(x.abs().sum().item()) == 0 for x in stats) and torch.equal(outs[0], outs[1])
+        return {"workload": "BASELINE configs[1] as a pipelined producer issues it: batch=%d device-resident blobs per call, consecutive calls alternate "
+                            "between two caller streams, so the latency-shaped tail of one call (lane fold, inversion) runs beside the next call's accumulation" % n,
+                "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
     leg("blob_proof_b256", blob_proof(1))
     leg("blob_proof_b256_two_streams", blob_proof(2))
 
@@ -341,6 +360,7 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                              "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms,
                              "launches_per_step": lps, "traffic": None}}
     leg("tiled_msm_2_pow_20", tiled_msm)
+    leg("commit_b1024_two_streams", commit_two_streams)
     return out
 
 
