@@ -178,3 +178,40 @@ def test_unstructured_tiled_long_msm(K, unstructured_setups, oracle):
     assert bytes(d_out.cpu().numpy().tobytes()) == unstructured_closed_form(oracle, folded)
 
 
+
+
+def test_second_pass_really_runs_when_a_row_equals_the_accumulator(K, oracle, gpu_setup):
+    """The hand-scheduled kernel hands a blob to the compiler-scheduled one (`redo`) when a lane meets P = +-Q. A setup whose
+    4096 points are all the generator (hand-built KZGSettings: the reference accepts any curve points, srs.rs:155-172) makes
+    that certain: with every scalar equal to 1 a lane's second row IS its accumulator (G + G: a doubling), with scalars
+    1, r - 1, 1, ... it is its negative (G - G: infinity, then a fresh start). The results must still be the closed forms, and the
+    library's own kernel clock must show the second pass doing real work (it exits in microseconds otherwise)."""
+    from lambdaworks_kzg_amd import capi
+    g_blst = C.create_string_buffer(gpu_setup.g1_values_bytes()[:144] * 4096)      # P_i = G for every i
+    s = K.KZGSettings()
+    s.fs, s.g1_values, s.g2_values = None, C.cast(g_blst, C.c_void_p), gpu_setup.s.g2_values
+    n = 8                                                                         # enough blobs for the hand-scheduled kernel
+    sets = [[1] * 4096,
+            [1, R - 1] * 2048,
+            [3] * 4096,
+            [(1 << 16) + 1] * 4096,
+            list(range(1, 4097)),
+            [R - 1] * 4096,
+            [0] * 4095 + [5],
+            [2, 2, R - 4, 7] * 1024]
+    blobs = b"".join(b"".join(v.to_bytes(32, "big") for v in ss) for ss in sets)
+    out = C.create_string_buffer(48 * n)
+    bad = C.c_size_t(0)
+    try:
+        capi.profile_reset()
+        capi.profile_enable(True)
+        assert K.lib().lwkzg_blob_to_kzg_commitment_batch(out, blobs, n, C.byref(s), C.byref(bad)) == K.C_KZG_OK
+        capi.profile_enable(False)
+        prof = capi.profile_report()
+        for i, ss in enumerate(sets):
+            assert out.raw[48 * i:48 * i + 48] == oracle.g1_generator_mul(sum(ss) % R), i
+        if "k_direct_accumulate_asm" in prof:                                     # (LWKZG_DIRECT_ASM=0 runs have no second pass)
+            assert prof["k_direct_redo"]["total_ms"] > 0.2, prof["k_direct_redo"]
+    finally:
+        capi.profile_enable(False)
+        K.lib().lwkzg_release_context(C.byref(s))
