@@ -1574,8 +1574,8 @@ static bool combine_commit(Ctx *c, uint8_t *out48, const uint8_t *blob, int mode
     return true;
 }
 
-C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s,
-                                             size_t *first_bad) {
+// (the host-pointer entry points allocate host vectors: nothing may unwind across the C ABI -- the exported symbols wrap these)
+static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s, size_t *first_bad) {
     const int mode = mode_of(s);
     if (!out || !blobs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
@@ -1919,8 +1919,8 @@ static C_KZG_RET combine_point_proof(Ctx *c, KZGProof *proof_out, Bytes32 *y_out
     });
 }
 
-C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
-                                             const KZGSettings *s, size_t *first_bad) {
+static C_KZG_RET blob_proof_batch_impl(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n, const KZGSettings *s,
+                                       size_t *first_bad) {
     const int mode = mode_of(s);
     if (!out || !blobs || !commitments) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
@@ -2011,8 +2011,8 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
     return C_KZG_OK;
 }
 
-C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs,
-                                        size_t n, const KZGSettings *s, size_t *first_bad) {
+static C_KZG_RET point_proof_batch_impl(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs, size_t n,
+                                        const KZGSettings *s, size_t *first_bad) {
     const int mode = mode_of(s);
     if (!proofs_out || !ys_out || !blobs || !zs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
@@ -2054,6 +2054,35 @@ static C_KZG_RET point_proof_batch_host(Ctx *c, KZGProof *proofs_out, Bytes32 *y
         memcpy(ys_out + off, h_y.data(), m * 32);
     }
     return C_KZG_OK;
+}
+
+}  // extern "C" (a template cannot have C linkage)
+namespace {
+template <class F>
+C_KZG_RET guarded(const char *what, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        lwk::set_error("%s: out of host memory", what);
+        return C_KZG_MALLOC;
+    } catch (...) {
+        lwk::set_error("%s: unexpected exception", what);
+        return C_KZG_ERROR;
+    }
+}
+}  // namespace
+extern "C" {
+
+C_KZG_RET lwkzg_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KZGSettings *s, size_t *first_bad) {
+    return guarded("lwkzg_blob_to_kzg_commitment_batch", [&] { return commitment_batch_impl(out, blobs, n, s, first_bad); });
+}
+C_KZG_RET lwkzg_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
+                                             const KZGSettings *s, size_t *first_bad) {
+    return guarded("lwkzg_compute_blob_kzg_proof_batch", [&] { return blob_proof_batch_impl(out, blobs, commitments, n, s, first_bad); });
+}
+C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs, size_t n,
+                                        const KZGSettings *s, size_t *first_bad) {
+    return guarded("lwkzg_compute_kzg_proof_batch", [&] { return point_proof_batch_impl(proofs_out, ys_out, blobs, zs, n, s, first_bad); });
 }
 
 C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KZGSettings *s) {

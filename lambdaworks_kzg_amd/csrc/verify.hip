@@ -11,6 +11,7 @@
 // accept/reject bit with G2 and [tau]G2 taken straight from the setup.
 #include <chrono>
 #include "engine.h"
+#include <memory>
 #include "fp2.h"
 #include "hostfp.h"
 
@@ -519,8 +520,26 @@ bool point_from_bytes(HXyzz &p, const uint8_t *in97) {
 
 extern "C" {
 
-C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
-                                      const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s) {
+}  // extern "C"
+namespace {
+// the verification entry points size host vectors by n: nothing may unwind across the C ABI
+template <class F>
+C_KZG_RET guarded(const char *what, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        lwk::set_error("%s: out of host memory", what);
+        return C_KZG_MALLOC;
+    } catch (...) {
+        lwk::set_error("%s: unexpected exception", what);
+        return C_KZG_ERROR;
+    }
+}
+}  // namespace
+extern "C" {
+
+static C_KZG_RET verify_batch_impl(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes, const Bytes48 *proofs_bytes, size_t n,
+                                   const KZGSettings *s) {
     if (!ok) return C_KZG_BADARGS;
     *ok = false;  // lib.rs:533-535
     const int mode = mode_of(s);
@@ -573,28 +592,36 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
     return rc;
 }
 
+C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
+                                      const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s) {
+    if (ok) *ok = false;
+    return guarded("verify_blob_kzg_proof_batch", [&] { return verify_batch_impl(ok, blobs, commitments_bytes, proofs_bytes, n, s); });
+}
+
 // ---- the same three steps for a batch sharded over several processes / GPUs (include/lambdaworks_kzg_amd.h) ----------
 
-C_KZG_RET lwkzg_verify_shard_begin(LwkzgVerifyShard **shard_out, uint8_t *records_out, const Blob *blobs, const Bytes48 *commitments,
-                                   const Bytes48 *proofs, size_t n_local, const KZGSettings *s) {
+static C_KZG_RET shard_begin_impl(LwkzgVerifyShard **shard_out, uint8_t *records_out, const Blob *blobs, const Bytes48 *commitments,
+                                  const Bytes48 *proofs, size_t n_local, const KZGSettings *s) {
     if (!shard_out) return C_KZG_BADARGS;
     *shard_out = nullptr;
     const int mode = mode_of(s);
     if (!s || (n_local && (!records_out || !blobs || !commitments || !proofs))) return bad(mode);
-    Shard *sh = new (std::nothrow) Shard();
+    std::unique_ptr<Shard> sh(new (std::nothrow) Shard());   // (owned until handed out: shard_begin's host vectors may throw)
     if (!sh) return C_KZG_MALLOC;
     C_KZG_RET rc = shard_begin(*sh, (const uint8_t *)blobs, (const uint8_t *)commitments, (const uint8_t *)proofs, n_local, s, mode, true);
-    if (rc != C_KZG_OK) {
-        delete sh;
-        return rc;
-    }
+    if (rc != C_KZG_OK) return rc;
     shard_records(*sh, records_out);
-    *shard_out = (LwkzgVerifyShard *)sh;
+    *shard_out = (LwkzgVerifyShard *)sh.release();
     return C_KZG_OK;
 }
 
-C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out, LwkzgVerifyShard *shard, const uint8_t *records_all, size_t n_total,
-                                     size_t first_index) {
+C_KZG_RET lwkzg_verify_shard_begin(LwkzgVerifyShard **shard_out, uint8_t *records_out, const Blob *blobs, const Bytes48 *commitments,
+                                   const Bytes48 *proofs, size_t n_local, const KZGSettings *s) {
+    return guarded("lwkzg_verify_shard_begin", [&] { return shard_begin_impl(shard_out, records_out, blobs, commitments, proofs, n_local, s); });
+}
+
+static C_KZG_RET shard_partial_impl(uint8_t *partial_out, LwkzgVerifyShard *shard, const uint8_t *records_all, size_t n_total,
+                                    size_t first_index) {
     if (!partial_out || !shard || (!records_all && n_total)) return C_KZG_BADARGS;
     Shard &sh = *(Shard *)shard;
     if (ctx_of(sh.s) != sh.ctx) {  // the setup was freed (or rebuilt) under the shard: its context is gone
@@ -609,6 +636,11 @@ C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out, LwkzgVerifyShard *sha
     for (int k = 0; k < 3; k++) point_to_bytes(partial_out + 97 * k, sums[k]);
     hfr_to_be(partial_out + 291, ysum);
     return C_KZG_OK;
+}
+
+C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out, LwkzgVerifyShard *shard, const uint8_t *records_all, size_t n_total,
+                                     size_t first_index) {
+    return guarded("lwkzg_verify_shard_partial", [&] { return shard_partial_impl(partial_out, shard, records_all, n_total, first_index); });
 }
 
 void lwkzg_verify_shard_free(LwkzgVerifyShard *shard) { delete (Shard *)shard; }
