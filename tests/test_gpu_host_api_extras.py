@@ -51,7 +51,9 @@ def test_reserve_streams_creates_the_second_context_up_front(K, oracle):
             for k in range(2):
                 K.blob_to_kzg_commitment_batch_device(outs[k].data_ptr(), d_blobs.data_ptr(), n, ts, streams[k].cuda_stream, stats[k].data_ptr())
         torch.cuda.synchronize()
-        assert torch.cuda.mem_get_info()[0] >= free_before - (8 << 20)          # nothing was allocated by the overlapped calls
+        # no workspace was allocated by the overlapped calls (a second one is 1.8 MB per blob = 170 MB here; the runtime's own
+        # first-launch bookkeeping on the two new streams is a few tens of MB)
+        assert torch.cuda.mem_get_info()[0] >= free_before - (96 << 20)
         assert all(int(s.abs().sum()) == 0 for s in stats) and torch.equal(outs[0], outs[1])
         got = bytes(outs[0].cpu().numpy().tobytes())
         for i in (0, n // 2, n - 1):

@@ -190,7 +190,8 @@ def test_second_pass_really_runs_when_a_row_equals_the_accumulator(K, oracle, gp
     g_blst = C.create_string_buffer(gpu_setup.g1_values_bytes()[:144] * 4096)      # P_i = G for every i
     s = K.KZGSettings()
     s.fs, s.g1_values, s.g2_values = None, C.cast(g_blst, C.c_void_p), gpu_setup.s.g2_values
-    n = 8                                                                         # enough blobs for the hand-scheduled kernel
+    # 64 blobs: eight workgroups per blob, so every lane owns TWO scalars (with one scalar of one non-zero window per lane there
+    # would be no addition at all)
     sets = [[1] * 4096,
             [1, R - 1] * 2048,
             [3] * 4096,
@@ -198,7 +199,8 @@ def test_second_pass_really_runs_when_a_row_equals_the_accumulator(K, oracle, gp
             list(range(1, 4097)),
             [R - 1] * 4096,
             [0] * 4095 + [5],
-            [2, 2, R - 4, 7] * 1024]
+            [2, 2, R - 4, 7] * 1024] * 8
+    n = len(sets)
     blobs = b"".join(b"".join(v.to_bytes(32, "big") for v in ss) for ss in sets)
     out = C.create_string_buffer(48 * n)
     bad = C.c_size_t(0)
