@@ -192,6 +192,8 @@ VCC, EXEC = ("vcc",), ("exec",)
 
 def fmt(o):
     k = o[0]
+    if k == "raw":      # s_waitcnt / s_nop / .p2align arguments, printed as they are
+        return o[1]
     if k == "v":
         return "v%d" % o[1]
     if k == "vp":
@@ -372,7 +374,6 @@ NX_B = WIDE_B + 8            # -X3 = PPP (wide) - R^2 - 2(-Q) + 8p
 def build():
     p = Prog()
     e = p.emit
-    C = p.emit
     # ---------------- prologue: operands into fixed registers, constants
     e("comment", "operands -> fixed registers")
     e("s_mov_b64", sp(sTABLE), opnd(0))
@@ -660,19 +661,6 @@ def render(p):
         t = t.replace("\\", "\\\\").replace('"', '\\"')
         lines.append('"%s\\n"' % t)
     return "\n".join(lines) + "\n"
-
-
-def fmt_raw_patch():
-    pass
-
-
-_orig_fmt = fmt
-
-
-def fmt(o):  # noqa: F811  (raw operands: s_waitcnt / s_nop / .p2align arguments)
-    if o[0] == "raw":
-        return o[1]
-    return _orig_fmt(o)
 
 
 def clobbers():
@@ -1023,14 +1011,10 @@ def mix():
     """opcode mix of one pass of the loop body (one mixed addition incl. the next digit, the gather and the loop control)"""
     import collections
     prog = build()
-    names = [i[0] for i in prog.ins]
     lo = next(k for k, i in enumerate(prog.ins) if i[0] == "label" and i[1][0].startswith("L_loop"))
     hi = max(k for k, i in enumerate(prog.ins) if i[0] == "s_cbranch_scc0" and i[1][0][1].startswith("L_loop"))
     body = [i for i in prog.ins[lo:hi + 1] if i[0] not in ("label", "comment", ".p2align")]
-    # the blocks that run once per lane or never on honest data: first-row copy, second filter of the P = 0 test
-    skip = set()
-    for a, b in (("L_same_scalar", None),):
-        pass
+    # the blocks that run once per lane, once per scalar or never on honest data are counted apart
     c = collections.Counter(i[0] for i in body)
     init_lo = next(k for k, i in enumerate(prog.ins) if i[0] == "s_cbranch_execz" and i[1][0][1].startswith("L_no_init"))
     init_hi = next(k for k, i in enumerate(prog.ins) if i[0] == "label" and i[1][0].startswith("L_no_init"))

@@ -1,0 +1,19 @@
+# The library's HOST code under AddressSanitizer + UndefinedBehaviorSanitizer on the GPU box (device code built as always:
+# make -C lambdaworks_kzg_amd/csrc hostasan): the concurrent host front -- coalesced single-blob callers, proof fronts, two caller
+# streams, batch verification, load / free cycles -- with every allocation and every signed overflow of the host side checked.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/host_asan
+rm -rf $O; mkdir -p $O
+cd $R
+ASAN=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so
+export LWKZG_LIBRARY=$R/lambdaworks_kzg_amd/lib_hostasan/liblambdaworks_kzg.so
+# allocator_may_return_null: the test of a table that does not fit makes the HIP runtime's own host allocation fail, which it handles
+export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:protect_shadow_gap=0:handle_segv=0:allocator_may_return_null=1
+export UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
+export LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:$LD_LIBRARY_PATH   # (torch dlopens its own libraries by name: under the sanitizer's dlopen interceptor the RUNPATH of the caller is not consulted)
+# the whole GPU suite ($1 = extra pytest arguments, e.g. -k "threads or everything_at_once" for the concurrency tests only)
+LD_PRELOAD=$ASAN timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider $1 > $O/log.txt 2>&1
+echo "pytest rc=$?" >> $O/log.txt
+tail -6 $O/log.txt
+grep -c "AddressSanitizer\|runtime error" $O/log.txt
