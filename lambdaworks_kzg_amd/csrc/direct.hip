@@ -325,10 +325,10 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1A
 #endif
 }
 
-// the 256 lane sums of one workgroup of k_direct_accumulate_asm -> one partial sum. ONE wave per workgroup's worth of lanes:
-// every thread first adds four lane sums in sequence (all 64 lanes busy), then six shuffle levels -- nine additions deep
-// on a quarter of the waves, where a 256-thread tree is eight deep with most lanes idle on four times as many
-// (0.48 ms -> 0.13 ms at 1024 blobs).
+// the 256 lane sums of one workgroup of k_direct_accumulate_asm -> one partial sum (a "unit"). ONE wave per unit: every thread
+// first adds four lane sums in sequence (all 64 lanes busy), then six shuffle levels -- nine additions deep on a quarter of
+// the waves, where a 256-thread tree is eight deep with most lanes idle on four times as many (0.48 -> 0.30 ms at 1024 blobs).
+// This is the compiler-scheduled arm (LWKZG_FOLD_ASM=0); k_direct_fold_lanes_asm below is what runs.
 
 // LWK_FOLD_CALL: field products of the lane fold as calls of the shared product function (small code) instead of inlined
 #ifdef LWK_FOLD_CALL
@@ -370,12 +370,13 @@ __device__ __forceinline__ FoldPoint load_lane_sum(const uint32_t *src) {
 }
 
 __global__ __launch_bounds__(64) void k_direct_fold_lanes(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
-                                                          const uint32_t *__restrict__ redo, int lanes_per_block) {
+                                                          const uint32_t *__restrict__ redo, int lanes_per_block, int blocks_per_blob) {
+    const int unit = blockIdx.x;  // = blob * blocks_per_blob + block
+    if (redo[unit / blocks_per_blob]) return;  // recomputed by the second pass
     const int kFoldPerThread = lanes_per_block / 64;
-    if (redo[blockIdx.y]) return;  // recomputed by the second pass
     __builtin_amdgcn_s_setprio(2);
     const int lane = threadIdx.x;
-    const uint32_t *src = lane_out + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * lanes_per_block + lane) * (size_t)kLaneWords;
+    const uint32_t *src = lane_out + ((size_t)unit * lanes_per_block + lane) * (size_t)kLaneWords;
     FoldPoint acc = load_lane_sum(src);
     // ONE call site of the (inlined, 48 KB) addition for all nine steps, so that the kernel stays inside the instruction cache:
     // steps 0 .. 2 add this thread's other three lane sums, steps 3 .. 8 are the shuffle tree
@@ -398,7 +399,52 @@ __global__ __launch_bounds__(64) void k_direct_fold_lanes(const uint32_t *__rest
         }
         if (take) acc = xyzz_add(acc, other);
     }
-    if (lane == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = *(G1Xyzz29 *)&acc;
+    if (lane == 0) partials[unit] = *(G1Xyzz29 *)&acc;
+}
+
+// The same fold as a hand-scheduled stream (tools/gen_fold_asm.py, direct_fold_asm.inc): one wave per unit, the additions'
+// independent products three chains at a time; LWKZG_FOLD_ASM=0 selects the compiler's schedule above (the A/B arm). A pair of
+// equal or opposite sums raises the blob's redo flag. Two builds of the one stream: ALONE lists 64 accumulator registers it never
+// touches as clobbers, which takes the kernel past 256 registers per lane, i.e. ONE wave per SIMD -- for launches of a whole
+// chip's worth of units (>= 1024), where the dispatcher otherwise puts two of these dependent chains on some SIMDs and none on
+// others and the pairs set the duration (0.245 -> 0.208 ms; profiles/r03_experiments.md section 6). Smaller launches run beside
+// other streams' kernels and keep the shareable build (the host-pointer slices lost 10 % to the exclusive one).
+__global__ __launch_bounds__(64) void k_direct_fold_lanes_asm(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
+                                                              uint32_t *__restrict__ redo, int lanes_per_block, int blocks_per_blob) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t unit = blockIdx.x;  // = blob * blocks_per_blob + block
+    uint32_t *flag = redo + unit / blocks_per_blob;
+    if (*flag) return;  // recomputed by the second pass
+    const uint32_t *src = lane_out + (size_t)unit * lanes_per_block * kLaneWords;
+    G1Xyzz29 *out = partials + unit;
+    const uint32_t per = lanes_per_block / 64, lane = threadIdx.x, levels = 6;
+    asm volatile(
+#include "direct_fold_asm.inc"
+        :
+        : "s"(src), "s"(out), "s"(flag), "s"(per), "v"(lane), "s"(levels)
+        :
+#include "direct_fold_asm_clobbers.inc"
+    );
+#endif
+}
+
+__global__ __launch_bounds__(64) void k_direct_fold_lanes_asm_alone(const uint32_t *__restrict__ lane_out, G1Xyzz29 *__restrict__ partials,
+                                                                    uint32_t *__restrict__ redo, int lanes_per_block, int blocks_per_blob) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t unit = blockIdx.x;
+    uint32_t *flag = redo + unit / blocks_per_blob;
+    if (*flag) return;
+    const uint32_t *src = lane_out + (size_t)unit * lanes_per_block * kLaneWords;
+    G1Xyzz29 *out = partials + unit;
+    const uint32_t per = lanes_per_block / 64, lane = threadIdx.x, levels = 6;
+    asm volatile(
+#include "direct_fold_asm.inc"
+        :
+        : "s"(src), "s"(out), "s"(flag), "s"(per), "v"(lane), "s"(levels)
+        :
+#include "direct_fold_asm_clobbers_pad.inc"
+    );
+#endif
 }
 
 // sums[blob] = sum of its per-block partial sums (only when a blob was spread over several workgroups):
@@ -454,8 +500,19 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, s
         }
         {
             ProfScope p("k_direct_fold_lanes", st);
-            hipLaunchKernelGGL(k_direct_fold_lanes, dim3(blocks_per_blob, (unsigned)n_blobs), dim3(64), 0, st,
-                               (const uint32_t *)lane_scratch, dest, (const uint32_t *)redo, threads);
+            const int n_units = (int)n_blobs * blocks_per_blob;
+            static const bool fold_asm = !(getenv("LWKZG_FOLD_ASM") && atoi(getenv("LWKZG_FOLD_ASM")) == 0);
+            if (fold_asm) {
+                if (n_units >= 1024 && !fill)   // a chip's worth of units and nobody beside us: one wave per SIMD
+                    hipLaunchKernelGGL(k_direct_fold_lanes_asm_alone, dim3((unsigned)n_units), dim3(64), 0, st, (const uint32_t *)lane_scratch,
+                                       dest, redo, threads, blocks_per_blob);
+                else
+                    hipLaunchKernelGGL(k_direct_fold_lanes_asm, dim3((unsigned)n_units), dim3(64), 0, st, (const uint32_t *)lane_scratch, dest,
+                                       redo, threads, blocks_per_blob);
+            } else {
+                hipLaunchKernelGGL(k_direct_fold_lanes, dim3((unsigned)n_units), dim3(64), 0, st, (const uint32_t *)lane_scratch, dest,
+                                   (const uint32_t *)redo, threads, blocks_per_blob);
+            }
         }
         {
             ProfScope p("k_direct_redo", st);

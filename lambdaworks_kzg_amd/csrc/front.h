@@ -38,7 +38,7 @@ struct LeaderFront {
             if (req.state == Req::QUEUED && !leader_active) {
                 leader_active = true;
                 std::vector<Req *> batch;
-                bool threw = false;
+                bool threw = false, collecting = true;
                 try {
                     for (auto it = queue.begin(); it != queue.end() && batch.size() < max_batch;) {
                         if ((*it)->mode == req.mode) {
@@ -49,6 +49,7 @@ struct LeaderFront {
                             ++it;
                         }
                     }
+                    collecting = false;
                     lk.unlock();
                     try {
                         run(batch);
@@ -64,7 +65,8 @@ struct LeaderFront {
                     if (threw) r->rc = rc_on_throw;
                     r->state = Req::DONE;
                 }
-                if (threw && req.state != Req::DONE) {  // this request never made it into the batch: answer it too
+                // (a leader that is not in its own batch -- 64 requests were ahead of it -- stays queued and leads again)
+                if (threw && collecting && req.state != Req::DONE) {  // the collection itself failed: this request is answered too
                     for (auto it = queue.begin(); it != queue.end(); ++it)
                         if (*it == &req) {
                             queue.erase(it);
@@ -133,7 +135,7 @@ struct LaneFront {
                 lane_busy[lane] = true;
                 leaders++;
                 std::vector<Req *> batch;
-                bool threw = false;
+                bool threw = false, collecting = true;
                 try {
                     for (auto it = queue.begin(); it != queue.end() && batch.size() < max_batch;) {
                         if ((*it)->mode == req.mode) {
@@ -144,6 +146,7 @@ struct LaneFront {
                             ++it;
                         }
                     }
+                    collecting = false;
                     lk.unlock();
                     try {
                         run(lane, batch);
@@ -160,7 +163,7 @@ struct LaneFront {
                     r->state = Req::DONE;
                     free_slots.push_back(r->slot);   // (capacity was reserved by add_slots: no allocation here)
                 }
-                if (threw && req.state != Req::DONE) {
+                if (threw && collecting && req.state != Req::DONE) {
                     for (auto it = queue.begin(); it != queue.end(); ++it)
                         if (*it == &req) {
                             queue.erase(it);

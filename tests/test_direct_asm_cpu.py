@@ -27,3 +27,17 @@ def test_direct_asm_stream_on_a_simulated_lane():
     G.selftest(14, 16, verbose=False, sparse=True)
     redo, _ = G.selftest(15, 16, verbose=False, force_equal=True)
     assert redo == 1
+
+
+def test_fold_asm_inc_is_current_and_adds_on_a_simulated_lane():
+    """the hand-scheduled lane fold (tools/gen_fold_asm.py): committed .inc files are what the generator writes; one simulated
+    lane adds 4 / 7 stored lane sums through the memory path (bounds as the accumulation leaves them) to the affine big-int
+    sum, skips lane sums at infinity, brings the result under 2p, and raises the redo flag on equal points"""
+    import gen_fold_asm as F
+    assert open(F.OUT).read() == F.render(F.build())
+    assert open(F.OUT.replace(".inc", "_clobbers.inc")).read().split("\n", 1)[1].strip() == F.clobbers()
+    assert open(F.OUT.replace(".inc", "_clobbers_pad.inc")).read().split("\n", 1)[1].strip() == F.clobbers(True)
+    F.selftest(21, 4, verbose=False)
+    F.selftest(22, 7, verbose=False)
+    F.selftest(23, 5, verbose=False, with_inf=True)
+    assert F.selftest(24, 3, verbose=False, equal=True) == 1

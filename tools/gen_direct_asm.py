@@ -767,6 +767,10 @@ class Sim:
                 self.p32(a[0], self.g32(a[1]) & self.g32(a[2]))
             elif op == "v_xor_b32":
                 self.p32(a[0], self.g32(a[1]) ^ self.g32(a[2]))
+            elif op == "v_or_b32":
+                self.p32(a[0], self.g32(a[1]) | self.g32(a[2]))
+            elif op == "ds_bpermute_b32":
+                raise ValueError("simulator: cross-lane instruction on a one-lane simulation")
             elif op == "v_lshrrev_b64":
                 self.p64(a[0], self.g64(a[2]) >> (self.g32(a[1]) & 63))
             elif op == "v_lshrrev_b32":
@@ -839,6 +843,12 @@ class Sim:
                 self.p32(a[0], (self.g32(a[1]) * self.g32(a[2])) >> 32)
             elif op == "s_lshl_b32":
                 self.p32(a[0], (self.g32(a[1]) << (self.g32(a[2]) & 31)) & 0xFFFFFFFF)
+            elif op == "s_lshr_b32":
+                self.p32(a[0], self.g32(a[1]) >> (self.g32(a[2]) & 31))
+            elif op == "s_lshr_b64":
+                self.p64(a[0], self.g64(a[1]) >> (self.g32(a[2]) & 63))
+            elif op == "s_lshl_b64":
+                self.p64(a[0], self.g64(a[1]) << (self.g32(a[2]) & 63))
             elif op in ("s_cmp_eq_u32", "s_cmp_lt_u32", "s_cmp_gt_u32"):
                 x, y = self.g32(a[0]), self.g32(a[1])
                 self.scc = int({"eq": x == y, "lt": x < y, "gt": x > y}[op[6:8]])
