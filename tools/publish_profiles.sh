@@ -7,6 +7,7 @@ for f in bench_line bench_line_force_dist bench_line_compiler_scheduled_arm benc
          bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm; do
   [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${TAG}_$f.json
 done
+[ -s $O/kt_line.json ] && tail -1 $O/kt_line.json > $P/${TAG}_bench_kernel_stats_run_line.json   # the line the profiled run itself printed
 for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
 grep -v "amdgpu.ids" $O/host_api_timing.txt > $P/${TAG}_host_api_timing.txt || true
 python3 - "$TAG" <<'PY'
