@@ -718,9 +718,10 @@ def main():
             "direct_table_build_s": t_table if direct_bits else None,
             "direct_table_build_s_max_over_ranks": t_table_max if direct_bits else None,
             "direct_table_build_breakdown_ms": table_breakdown,
-            "direct_table_build_breakdown_note": "free_old = hipFree of the table in place, table_malloc = ONE hipMalloc of the new table: the driver "
-                                                 "provisions device memory at 15-26 ms per GB on the boxes measured, serially, whatever the API or the "
-                                                 "number of calls (tools/alloc_bench.hip, profiles/r03_alloc_bench.txt); kernels = k_direct_qbase + k_direct_build" if direct_bits else None,
+            "direct_table_build_breakdown_note": "free_old = hipFree of the table in place; table_malloc = the hipMallocs of the new table, one per window, summed "
+                                                 "(the driver provisions device memory at 15-26 ms per GB on the boxes measured, serially, whatever the API or "
+                                                 "the number of calls: tools/alloc_bench.hip, profiles/r03_alloc_bench.txt); the GPU builds window j while the host "
+                                                 "allocates window j + 1, and kernels = what was left of k_direct_build after the last allocation returned" if direct_bits else None,
             "direct_table_build_note": "every rank builds its own table from the broadcast setup points, once, outside the timed region" if direct_bits else None,
         }
         res["dist"] = dist_info

@@ -137,9 +137,22 @@ static double wall_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st, double *ms) {
+void free_direct_table(DirectTable &t) {
+    for (int j = 0; j < kDirectMaxWindows; j++)
+        if (t.win[j]) {
+            hipFree(t.win[j]);
+            t.win[j] = nullptr;
+        }
+    if (t.win_dev) hipFree(t.win_dev);
+    t.win_dev = nullptr;
+    t.nw = 0;
+    t.bytes = 0;
+}
+
+hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &t, size_t row_bytes, hipStream_t st, double *ms) {
     const DirectPlanRt P = make_plan(bits);
-    if (!P.entries) return hipErrorInvalidValue;
+    if (!P.entries || P.nw > kDirectMaxWindows) return hipErrorInvalidValue;
+    free_direct_table(t);
     G1Affine29 *qbase = nullptr;
     F29<2> *scratch = nullptr;
     const double t0 = wall_ms();
@@ -148,29 +161,49 @@ hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *tabl
     const size_t n_threads = bits >= 14 ? 256 * 1024 : 64 * 1024;
     hipError_t e = hipMalloc((void **)&qbase, (size_t)P.nw * kBlobElems * sizeof(G1Affine29));
     if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)kChunk * 5 * n_threads * sizeof(F29<2>));
+    if (e == hipSuccess) e = hipMalloc((void **)&t.win_dev, kDirectMaxWindows * sizeof(uint64_t));
     const double t1 = wall_ms();
+    double malloc_ms = 0, t_last_malloc = t1;
     if (e == hipSuccess) {
         {
             ProfScope p("k_direct_qbase", st);
             hipLaunchKernelGGL(k_direct_qbase, dim3(kBlobElems / 64), dim3(64), 0, st, points, qbase, P.c, P.nw);
         }
-        {
+        // window by window: the host allocates window j + 1 while the GPU builds window j (the launches are asynchronous)
+        for (int j = 0; j < P.nw && e == hipSuccess; j++) {
+            const bool top = j == P.nw - 1;
+            const size_t rows = (size_t)kBlobElems * (top ? P.htop : P.h);
+            const double a0 = wall_ms();
+            e = hipMalloc(&t.win[j], rows * row_bytes);
+            t_last_malloc = wall_ms();
+            malloc_ms += t_last_malloc - a0;
+            if (e != hipSuccess) break;
+            t.bytes += rows * row_bytes;
             ProfScope p("k_direct_build", st);
-            hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase, table,
-                               (size_t)(P.nw - 1) * kBlobElems, scratch, n_threads, (int)P.h, row_bytes);
-            hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st,
-                               qbase + (size_t)(P.nw - 1) * kBlobElems, (G1Affine29 *)((char *)table + P.top_base * row_bytes),
-                               (size_t)kBlobElems, scratch, n_threads, (int)P.htop, row_bytes);
+            hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase + (size_t)j * kBlobElems,
+                               (G1Affine29 *)t.win[j], (size_t)kBlobElems, scratch, n_threads, (int)(top ? P.htop : P.h), row_bytes);
         }
-        e = hipStreamSynchronize(st);
+        if (e == hipSuccess) {
+            uint64_t h[kDirectMaxWindows] = {};
+            for (int j = 0; j < P.nw; j++) h[j] = (uint64_t)(uintptr_t)t.win[j];
+            e = hipMemcpyAsync(t.win_dev, h, sizeof h, hipMemcpyHostToDevice, st);
+        }
+        const hipError_t es = hipStreamSynchronize(st);  // (also on failure: the builds of the windows that exist must be over before they are freed)
+        if (e == hipSuccess) e = es;
     }
     const double t2 = wall_ms();
     if (qbase) hipFree(qbase);
     if (scratch) hipFree(scratch);
+    if (e != hipSuccess) {
+        free_direct_table(t);
+    } else {
+        t.nw = P.nw;
+    }
     if (ms) {
         ms[0] = t1 - t0;
-        ms[1] = t2 - t1;
-        ms[2] = wall_ms() - t2;
+        ms[1] = malloc_ms;
+        ms[2] = t2 - t_last_malloc;
+        ms[3] = wall_ms() - t2;
     }
     return e;
 }
@@ -205,7 +238,7 @@ __device__ __forceinline__ G1Xyzz29 wave_fold(const G1Xyzz29 &in, int lane, int 
 
 // CT = the window width as a compile-time constant (14, 15, 16), or 0: the plan is the kernel argument `rt`
 template <int CT>
-__global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affine29 *__restrict__ table,
+__global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const uint64_t *__restrict__ win_dev,
                                                                    const uint4 *__restrict__ scalars,
                                                                    G1Xyzz29 *__restrict__ partials, int scalars_per_lane,
                                                                    DirectPlanRt rt, uint32_t row_bytes,
@@ -216,12 +249,14 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
     const int C = P.c;
     __shared__ uint32_t limbs[8 * kDirThreads];   // the lane's current scalar, for run-time window indexing
     __shared__ G1Xyzz29 wave_sum[kDirThreads / 64];
+    __shared__ uint64_t win_base[kDirectMaxWindows];  // the table is one allocation per window (kernels.h: DirectTable)
+    if (threadIdx.x < kDirectMaxWindows) win_base[threadIdx.x] = win_dev[threadIdx.x];
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t blob = blockIdx.y;
     const int lanes_per_blob = gridDim.x * kDirThreads;
     const int first = blockIdx.x * kDirThreads + tid;
     const uint4 *sc = scalars + blob * (size_t)kBlobElems * 2;
-    const G1Affine29i *tab = (const G1Affine29i *)table;
     // tiny batches also split the windows of a scalar over gridDim.z workgroups; the signed-digit carry chain is
     // still walked from window 0 (a few integer ops per window), only the gathers and additions are confined
     const int wper = (P.nw + (int)gridDim.z - 1) / (int)gridDim.z;
@@ -250,11 +285,8 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
             uint32_t ng = (!top && raw > P.h) ? 1u : 0u;
             uint32_t mag = ng ? (1u << C) - raw : raw;
             carry = ng;
-            size_t idx = top ? P.top_base + (size_t)point * P.htop + (mag - 1)
-                             : ((size_t)j * kBlobElems + point) * P.h + (mag - 1);
-#ifdef LWK_DIRECT_IDX_MASK  // experiment builds only: confine the gathers to a cache-resident part of the table (WRONG results)
-            idx &= (size_t)LWK_DIRECT_IDX_MASK;
-#endif
+            const char *wbase = (const char *)(uintptr_t)win_base[j];
+            const size_t idx = (size_t)point * (top ? P.htop : P.h) + (mag - 1);  // row within window j
             j++;
             if (j == P.nw) {
                 j = 0;
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
                 valid = true;
                 neg = ng;
                 // (plain loads: with the nt hint the seven loads of a row no longer meet in the cache, -7 %)
-                row = *(const G1Affine29i *)((const char *)tab + idx * row_bytes);
+                row = *(const G1Affine29i *)(wbase + idx * row_bytes);
                 return;
             }
         }
@@ -302,7 +334,7 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate(const G1Affin
 // redo[blob]; k_direct_accumulate<CT> then recomputes exactly those blobs with its complete branches.
 constexpr int kLaneWords = 56;
 
-__global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1Affine29 *__restrict__ table,
+__global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const uint64_t *__restrict__ win_dev,
                                                                        const uint4 *__restrict__ scalars,
                                                                        uint32_t *__restrict__ lane_out, uint32_t *__restrict__ redo,
                                                                        int scalars_per_lane, DirectPlanRt rt, uint32_t row_bytes) {
@@ -313,12 +345,11 @@ __global__ __launch_bounds__(kDirThreads) void k_direct_accumulate_asm(const G1A
     uint32_t *out = lane_out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(blockDim.x * kLaneWords);
     uint32_t *flag = redo + blockIdx.y;
     const uint32_t lanes_per_blob = gridDim.x * blockDim.x;
-    const uint32_t top_lo = (uint32_t)rt.top_base, top_hi = (uint32_t)(rt.top_base >> 32);
     asm volatile(
 #include "direct_asm.inc"
         :
-        : "s"(table), "s"(sc), "s"(out), "s"(flag), "s"(scalars_per_lane), "s"(lanes_per_blob), "s"(rt.c), "s"(rt.nw), "s"(rt.wtop),
-          "s"(rt.h), "s"(rt.htop), "s"(top_lo), "s"(top_hi), "s"(row_bytes), "v"(first), "v"(tid)
+        : "s"(win_dev), "s"(sc), "s"(out), "s"(flag), "s"(scalars_per_lane), "s"(lanes_per_blob), "s"(rt.c), "s"(rt.nw), "s"(rt.wtop),
+          "s"(rt.h), "s"(rt.htop), "s"(row_bytes), "v"(first), "v"(tid)
         :
 #include "direct_asm_clobbers.inc"
     );
@@ -469,7 +500,7 @@ static bool direct_asm_enabled() {
 }
 
 template <int CT>
-static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw,
+static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw,
                             G1Xyzz29 *lane_scratch, G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st,
                             int fill) {
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
@@ -530,7 +561,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const G1Affine29 *table, s
     }
 }
 
-void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
+void launch_direct_msm(int bits, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
                        G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
     const DirectPlanRt plan = make_plan(bits);
     if (!plan.entries) return;

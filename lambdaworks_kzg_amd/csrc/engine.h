@@ -151,6 +151,8 @@ typedef LeaderFront<ProofReq> ProofFront;   // front.h
 struct BuildTiming {
     int bits = 0;
     size_t row_bytes = 0, table_bytes = 0;
+    // table_malloc_ms: the windows' hipMallocs, summed (the GPU builds window j meanwhile); kernels_ms: what was left of the build
+    // kernels after the last allocation returned
     double free_old_ms = 0, table_malloc_ms = 0, scratch_malloc_ms = 0, kernels_ms = 0, scratch_free_ms = 0, total_ms = 0;
 };
 struct LoadTiming {
@@ -190,7 +192,8 @@ struct Ctx {
     std::mutex heavy_mu;
     G1Affine *points;  // 4096 affine Montgomery (== table row 0 source)
     G1Affine29 *table;  // kTablePoints, hot-loop representation
-    G1Affine29 *direct_table;  // all multiples of every window base (direct.hip); nullptr unless enabled
+    G1Affine29 *direct_table;  // all multiples of every window base (direct.hip): window 0's rows; nullptr unless enabled
+    DirectTable direct_tab;    // the windows (one allocation each) and their addresses on the device; owned by the primary context
     int direct_bits;           // 14 / 15 / 16 when direct_table is live, else 0
     size_t direct_row_bytes;   // 128 (every row in a line of its own) or 112 (packed), see kernels.h
     Fr *tw_fwd, *tw_inv;

@@ -222,12 +222,14 @@ static void ctx_destroy(Ctx *c) {
         c->points = nullptr;
         c->table = nullptr;
         c->direct_table = nullptr;
+        c->direct_tab = DirectTable();
         c->tw_fwd = c->tw_inv = nullptr;
         c->tw28_fwd = c->tw28_inv = nullptr;
     }
     dev_free(c->points);
     dev_free(c->table);
-    dev_free(c->direct_table);
+    free_direct_table(c->direct_tab);
+    c->direct_table = nullptr;
     dev_free(c->tw_fwd);
     dev_free(c->tw_inv);
     dev_free(c->tw28_fwd);
@@ -317,6 +319,7 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
         c->points = twin_of->points;
         c->table = twin_of->table;
         c->direct_table = twin_of->direct_table;
+        c->direct_tab.win_dev = twin_of->direct_tab.win_dev;  // (addresses only: the windows belong to the primary context)
         c->direct_bits = twin_of->direct_bits;
         c->direct_row_bytes = twin_of->direct_row_bytes;
         c->tw_fwd = twin_of->tw_fwd;
@@ -500,7 +503,7 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
     if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
         // (scratch of the bucket engine, idle on this path: `buckets` holds the per-lane sums of the hand-scheduled kernel,
         // `sorted` the per-workgroup partial sums, `bstart` the redo flags)
-        launch_direct_msm(c->direct_bits, c->direct_table, c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
+        launch_direct_msm(c->direct_bits, c->direct_tab.win_dev, c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
                           st, (c->primary->twin.load(std::memory_order_acquire) || shared_chip) ? 2048 : 0);
         return sums;
     }
@@ -2147,42 +2150,39 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
     const int old_bits = c->direct_bits;
     auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = wall();
-    dev_free(c->direct_table);  // (the old and the new table need not fit side by side)
+    free_direct_table(c->direct_tab);  // (the old and the new table need not fit side by side)
+    c->direct_table = nullptr;
     BuildTiming bt;
     bt.free_old_ms = wall() - t_start;
     c->direct_bits = 0;
     if (twin) {
         twin->direct_table = nullptr;
+        twin->direct_tab.win_dev = nullptr;
         twin->direct_bits = 0;
     }
     if (window_bits == 0) return C_KZG_OK;
     // rows aligned to 128-byte lines when that table leaves kDirectAlignedHeadroom of HBM free (workspaces, the caller's
     // own buffers), packed otherwise; LWKZG_DIRECT_ROW=112|128 forces one (A/B runs)
     auto build_rows = [&](int bits, size_t row) -> hipError_t {
-        G1Affine29 *t = nullptr;
-        const double t0 = wall();
-        hipError_t e = hipMalloc((void **)&t, direct_table_entries(bits) * row);
-        bt.table_malloc_ms += wall() - t0;
-        if (e == hipSuccess) {
-            double ms[3] = {0, 0, 0};
-            e = build_direct_table(bits, c->points, t, row, c->stream, ms);
-            bt.scratch_malloc_ms += ms[0];
-            bt.kernels_ms += ms[1];
-            bt.scratch_free_ms += ms[2];
-            if (e != hipSuccess) hipFree(t);
-        }
+        double ms[4] = {0, 0, 0, 0};
+        const hipError_t e = build_direct_table(bits, c->points, c->direct_tab, row, c->stream, ms);
+        bt.scratch_malloc_ms += ms[0];
+        bt.table_malloc_ms += ms[1];
+        bt.kernels_ms += ms[2];
+        bt.scratch_free_ms += ms[3];
         if (e != hipSuccess) {
             (void)hipGetLastError();  // an out-of-memory here is an answer, not a sticky failure
             return e;
         }
-        c->direct_table = t;
+        c->direct_table = (G1Affine29 *)c->direct_tab.win[0];
         c->direct_bits = bits;
         c->direct_row_bytes = row;
         bt.bits = bits;
         bt.row_bytes = row;
         bt.table_bytes = direct_table_entries(bits) * row;
         if (twin) {
-            twin->direct_table = t;
+            twin->direct_table = c->direct_table;
+            twin->direct_tab.win_dev = c->direct_tab.win_dev;
             twin->direct_bits = bits;
             twin->direct_row_bytes = row;
         }

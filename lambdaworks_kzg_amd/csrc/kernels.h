@@ -47,12 +47,24 @@ constexpr size_t kDirectRowAligned = 128, kDirectRowPacked = 112;
 constexpr size_t kDirectAlignedHeadroom = (size_t)8 << 30;  // what an aligned table must leave free (two workspaces, verification scratch, the caller's buffers)
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
-// ms[0] = the scratch allocations, ms[1] = the build kernels (to completion), ms[2] = freeing the scratch (host wall clock; may be null)
-hipError_t build_direct_table(int bits, const G1Affine *points, G1Affine29 *table, size_t row_bytes, hipStream_t st, double *ms = nullptr);
+// The table is ONE ALLOCATION PER WINDOW: the driver provisions device memory at 15-26 ms per GB, serially (profiles/r03_alloc_bench.txt),
+// so window j + 1 is being allocated by the host while the GPU builds window j, and the build costs max(allocation, kernels) instead
+// of their sum. The kernels index `win_dev`, the windows' base addresses in device memory.
+constexpr int kDirectMaxWindows = 26;  // 10-bit windows
+struct DirectTable {
+    void *win[kDirectMaxWindows] = {};  // rows of window j: 4096 * 2^(bits-1) (the top window: 4096 * 2^wtop) rows of row_bytes
+    uint64_t *win_dev = nullptr;        // the same addresses on the device
+    int nw = 0;
+    size_t bytes = 0;
+};
+// ms[0] = scratch allocations, ms[1] = the windows' hipMallocs (summed), ms[2] = what was left of the build kernels after the
+// last allocation returned, ms[3] = freeing the scratch (host wall clock; may be null). On failure nothing stays allocated.
+hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &table, size_t row_bytes, hipStream_t st, double *ms = nullptr);
+void free_direct_table(DirectTable &table);
 // sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused
 // otherwise); `lane_scratch` 4096 * n_blobs entries (the per-lane sums of the hand-scheduled kernel) and `redo` n_blobs words (its flags).
 // fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
-void launch_direct_msm(int bits, const G1Affine29 *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
+void launch_direct_msm(int bits, const uint64_t *win_dev, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
                        G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0);
 
 // ---- setup (setup.hip)

@@ -136,10 +136,7 @@ sOUT = sregs("OUT", 2, 2)
 sREDO = sregs("REDO", 2, 2)
 sSPL, sLPB, sC, sNW, sH, sHTOP, s2C, sMASKC, sMASKTOP = [sregs(n) for n in
                                                            ("SPL", "LPB", "C", "NW", "H", "HTOP", "TWOC", "MASKC", "MASKTOP")]
-sTOPROW = sregs("TOPROW", 2, 2)
-sROWSTEP = sregs("ROWSTEP", 2, 2)
-sROWBASE = sregs("ROWBASE", 2, 2)
-sROW0 = sregs("ROW0", 2, 2)
+sRB = sregs("RB")
 sQ, sJ = sregs("Q"), sregs("J")
 sVALID = sregs("VALID", 2, 2)
 sNEG = sregs("NEG", 2, 2)
@@ -156,7 +153,7 @@ NUM_SGPRS = _snext[0]
 assert NUM_SGPRS <= 102, NUM_SGPRS
 
 # operands of the asm statement, in this order (direct.hip): all "s" except the last two ("v")
-OPERANDS = ["table", "scalars", "out", "redo", "spl", "lpb", "c", "nw", "wtop", "h", "htop", "top_base_lo", "top_base_hi", "row_bytes",
+OPERANDS = ["window base addresses (device array)", "scalars", "out", "redo", "spl", "lpb", "c", "nw", "wtop", "h", "htop", "row_bytes",
             "first", "tid"]
 
 
@@ -387,12 +384,10 @@ def build():
     e("s_mov_b32", s(sSTMP), opnd(8))              # wtop
     e("s_mov_b32", s(sH), opnd(9))
     e("s_mov_b32", s(sHTOP), opnd(10))
-    e("s_mov_b32", s(sTMP[0]), opnd(11))           # top_base (64 bit)
-    e("s_mov_b32", s(sTMP[1]), opnd(12))
-    e("s_mov_b32", s(sTMPB[0]), opnd(13))          # row_bytes
-    e("v_mov_b32", v(VRB), opnd(13))
-    e("v_mov_b32", v(POINT), opnd(14))
-    e("v_mov_b32", v(VTID), opnd(15))
+    e("s_mov_b32", s(sRB), opnd(11))               # row_bytes
+    e("v_mov_b32", v(VRB), opnd(11))
+    e("v_mov_b32", v(POINT), opnd(12))
+    e("v_mov_b32", v(VTID), opnd(13))
     for i in range(14):
         e("s_mov_b32", s(sMOD[i]), lit(MOD[i]))
     e("s_mov_b32", s(sINV), lit(INV))
@@ -403,20 +398,8 @@ def build():
     e("s_add_u32", s(sMASKC), s(s2C), lit(-1))
     e("s_lshl_b32", s(sMASKTOP), lit(1), s(sSTMP))
     e("s_add_u32", s(sMASKTOP), s(sMASKTOP), lit(-1))
-    # row addressing: address of the row for (window j, point, mag) = ROWBASE_j + (point * hj + mag) * row_bytes with
-    # ROWBASE_j = table + (j * 4096 * h - 1) * row_bytes (signed windows), TOPROW = table + (top_base - 1) * row_bytes
-    rb = s(sTMPB[0])
-    e("s_sub_u32", s(sROW0[0]), s(sTABLE[0]), rb)
-    e("s_subb_u32", s(sROW0[1]), s(sTABLE[1]), lit(0))
-    e("s_mul_i32", s(sTOPROW[0]), s(sTMP[0]), rb)          # top_base * row_bytes, 64 bit
-    e("s_mul_hi_u32", s(sTOPROW[1]), s(sTMP[0]), rb)
-    e("s_mul_i32", s(sSTMP), s(sTMP[1]), rb)
-    e("s_add_u32", s(sTOPROW[1]), s(sTOPROW[1]), s(sSTMP))
-    e("s_add_u32", s(sTOPROW[0]), s(sTOPROW[0]), s(sROW0[0]))
-    e("s_addc_u32", s(sTOPROW[1]), s(sTOPROW[1]), s(sROW0[1]))
-    e("s_lshl_b32", s(sSTMP), s(sH), lit(12))              # 4096 * h < 2^28
-    e("s_mul_i32", s(sROWSTEP[0]), s(sSTMP), rb)
-    e("s_mul_hi_u32", s(sROWSTEP[1]), s(sSTMP), rb)
+    # row addressing: the table is one allocation per window (kernels.h: DirectTable); the row for (window j, point, mag) is at
+    # base[j] + (point * hj + mag - 1) * row_bytes, base[j] read from the device array of window addresses when the window comes up
     # state
     e("s_mov_b64", sp(sINF), lit(-1))
     e("s_mov_b64", sp(sTROUBLE), lit(0))
@@ -624,11 +607,9 @@ def digit_and_address(p):
     e("s_cselect_b32", s(sMASKJ), s(sMASKTOP), s(sMASKC))
     e("s_cselect_b32", s(sHCMP), lit(-1), s(sH))
     e("s_cselect_b32", s(sHJ), s(sHTOP), s(sH))
-    # ROWBASE: window 0 starts at ROW0, each signed window adds ROWSTEP, the top window has its own base
-    e("s_cselect_b64", sp(sTMPB), sp(sTOPROW), sp(sROWBASE))
-    e("s_cmp_eq_u32", s(sJ), lit(0))
-    e("s_cselect_b64", sp(sTMPB), sp(sROW0), sp(sTMPB))
-    # (a one-window plan, nw == 1, would need the top base at j == 0: not a plan this library has -- nw >= 16)
+    # base of window sJ (asked for now, needed by the last instruction below)
+    e("s_lshl_b32", s(sSTMP), s(sJ), lit(3))
+    e("s_load_dwordx2", sp(sTMPB), sp(sTABLE), s(sSTMP))
     e("v_and_b32", v(RAW), s(sMASKJ), v(SC[0]))
     e("v_add_u32", v(RAW), v(RAW), v(CARRY))
     e("v_cmp_lt_u32", VCC, s(sHCMP), v(RAW))
@@ -641,10 +622,10 @@ def digit_and_address(p):
     e("s_mov_b64", sp(sNEGN), VCC)
     e("v_cmp_ne_u32", sp(sVALIDN), lit(0), v(MAG))
     e("v_mad_u32_u24", v(T3), v(POINT), s(sHJ), v(MAG))
+    e("s_waitcnt", ("raw", "lgkmcnt(0)"))
+    e("s_sub_u32", s(sTMPB[0]), s(sTMPB[0]), s(sRB))          # minus one row: mag counts from 1
+    e("s_subb_u32", s(sTMPB[1]), s(sTMPB[1]), lit(0))
     e("v_mad_u64_u32", vp(ADDR[0]), VCC, v(T3), v(VRB), sp(sTMPB))
-    # next window's base
-    e("s_add_u32", s(sROWBASE[0]), s(sTMPB[0]), s(sROWSTEP[0]))
-    e("s_addc_u32", s(sROWBASE[1]), s(sTMPB[1]), s(sROWSTEP[1]))
 
 
 def row_loads(p):
@@ -871,11 +852,15 @@ class Sim:
                 if not (self.vcc & 1):
                     pc = self.labels[a[0][1]]
             elif op == "s_waitcnt":
-                for r, val in self.pending:
-                    self.vr[r] = val
-                self.pending = []
+                if "vmcnt" in a[0][1]:       # (an lgkmcnt wait does not make vector loads land)
+                    for r, val in self.pending:
+                        self.vr[r] = val
+                    self.pending = []
             elif op in ("s_nop", "s_sleep"):
                 pass
+            elif op == "s_load_dwordx2":
+                w = self.rd(self.g64(a[1]) + self.g32(a[2]), 2)
+                self.p64(a[0], w[0] | (w[1] << 32))
             elif op == "s_branch":
                 pc = self.labels[a[0][1]]
             elif op == "global_load_dwordx4":
@@ -948,6 +933,8 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
     lpb = 256
     first = rnd.randrange(256)
     table_addr, sc_addr, out_addr, redo_addr = 0x100000000000, 0x200000000000, 0x300000000000, 0x400000000000
+    win_tab_addr = 0x500000000000                     # the device array of window base addresses
+    win_stride = 1 << 38                              # window j lives at table_addr + j * win_stride (separate allocations; <= 26 windows)
     R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
     scalars = {}
     for q in range(spl):
@@ -978,9 +965,14 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
     stored = {}
 
     def rd(addr, n):
+        if addr >= win_tab_addr:
+            j = (addr - win_tab_addr) // 8
+            a = table_addr + j * win_stride
+            return [a & 0xFFFFFFFF, a >> 32][:n]
         if addr >= table_addr and addr < sc_addr:
-            off = addr - table_addr
-            words = row(off // row_bytes)[0]
+            j, off = (addr - table_addr) // win_stride, (addr - table_addr) % win_stride
+            base_idx = top_base if j == nw - 1 else j * 4096 * h          # first row of window j in the flat numbering row() decodes
+            words = row(base_idx + off // row_bytes)[0]
             k = (off % row_bytes) // 4
             return words[k:k + n]
         off = addr - sc_addr
@@ -992,8 +984,7 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
         for k, wv in enumerate(words):
             stored[addr + 4 * k] = wv
 
-    ops = [table_addr, sc_addr, out_addr, redo_addr, spl, lpb, c, nw, wtop, h, htop, top_base & 0xFFFFFFFF, top_base >> 32, row_bytes,
-           first, 0]
+    ops = [win_tab_addr, sc_addr, out_addr, redo_addr, spl, lpb, c, nw, wtop, h, htop, row_bytes, first, 0]
     sim = Sim(prog, ops, rd, wr)
     steps = sim.run()
     got = [stored[out_addr + 4 * k] for k in range(56)]
