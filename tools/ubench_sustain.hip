@@ -1,0 +1,198 @@
+// tools/ubench_sustain.hip -- what rate does a dense v_mad_u64_u32 stream hold when it is SUSTAINED, and what do random
+// 128-byte gathers beside it cost? tools/ubench_mad.hip measures loops of half a millisecond (2.40-2.45 GHz by GRBM_GUI_ACTIVE);
+// the accumulation kernel runs 9 ms per launch, back to back, at 1.98-2.05 GHz. This runs the same eight-accumulator loop with
+// two waves per SIMD for a launch length given at run time, back to back for ~0.2 s, and prints ns per wave-instruction per SIMD:
+//   plain      multiply-adds only
+//   gather     the same plus one random 112-byte row (seven dwordx4 loads, one 128-byte line) per ~4256 instructions per lane,
+//              out of a buffer of --gb gigabytes (default 128), waited for one body later -- the accumulation's memory pattern
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_sustain.hip -o /tmp/ubench_sustain
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define M(D, A, B) "v_mad_u64_u32 " D ", vcc, " A ", " B ", " D "\n"
+#define BODY8 M("v[8:9]", "v40", "v41") M("v[10:11]", "v40", "v41") M("v[12:13]", "v40", "v41") M("v[14:15]", "v40", "v41") \
+              M("v[16:17]", "v40", "v41") M("v[18:19]", "v40", "v41") M("v[20:21]", "v40", "v41") M("v[22:23]", "v40", "v41")
+#define BODY128 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8 BODY8
+#define BODY512 BODY128 BODY128 BODY128 BODY128
+#define BODY4096 BODY512 BODY512 BODY512 BODY512 BODY512 BODY512 BODY512 BODY512
+#define INIT "v_mov_b32 v40, %1\nv_mov_b32 v41, %2\n" \
+             "v_mov_b32 v8, %1\nv_mov_b32 v9, %2\nv_mov_b32 v10, %1\nv_mov_b32 v11, %2\nv_mov_b32 v12, %1\nv_mov_b32 v13, %2\nv_mov_b32 v14, %1\nv_mov_b32 v15, %2\n" \
+             "v_mov_b32 v16, %1\nv_mov_b32 v17, %2\nv_mov_b32 v18, %1\nv_mov_b32 v19, %2\nv_mov_b32 v20, %1\nv_mov_b32 v21, %2\nv_mov_b32 v22, %1\nv_mov_b32 v23, %2\n"
+#define FINI "v_xor_b32 %0, v8, v10\nv_xor_b32 %0, %0, v12\nv_xor_b32 %0, %0, v14\nv_xor_b32 %0, %0, v16\nv_xor_b32 %0, %0, v18\nv_xor_b32 %0, %0, v20\nv_xor_b32 %0, %0, v22\n"
+#define CLOB "s20", "scc", "vcc", "v40", "v41", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23"
+
+// 232 registers as the accumulation kernel: two waves per SIMD and no more
+#define PAD_CLOB "v231"
+
+__global__ __launch_bounds__(256) void k_plain(uint32_t *out, uint32_t seed, uint32_t iters) {
+    uint32_t a = seed ^ threadIdx.x, b = (seed * 2654435761u) | 1u, r;
+    asm volatile(INIT "s_mov_b32 s20, %3\n1:\n" BODY4096 "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI
+                 : "=&v"(r) : "v"(a), "v"(b), "s"(iters) : CLOB, PAD_CLOB);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+
+// ---- does the rate depend on the DATA? sixteen factor registers with random 28-bit (or 32-bit) contents
+#define INIT16 "v_mov_b32 v40, %1\n" \
+    "v_mul_lo_u32 v41, v40, %4\n v_add_u32 v41, 0x9e3779b9, v41\n v_mul_lo_u32 v42, v41, %4\n v_add_u32 v42, 0x9e3779b9, v42\n" \
+    "v_mul_lo_u32 v43, v42, %4\n v_add_u32 v43, 0x9e3779b9, v43\n v_mul_lo_u32 v44, v43, %4\n v_add_u32 v44, 0x9e3779b9, v44\n" \
+    "v_mul_lo_u32 v45, v44, %4\n v_add_u32 v45, 0x9e3779b9, v45\n v_mul_lo_u32 v46, v45, %4\n v_add_u32 v46, 0x9e3779b9, v46\n" \
+    "v_mul_lo_u32 v47, v46, %4\n v_add_u32 v47, 0x9e3779b9, v47\n v_mul_lo_u32 v48, v47, %4\n v_add_u32 v48, 0x9e3779b9, v48\n" \
+    "v_mul_lo_u32 v49, v48, %4\n v_add_u32 v49, 0x9e3779b9, v49\n v_mul_lo_u32 v50, v49, %4\n v_add_u32 v50, 0x9e3779b9, v50\n" \
+    "v_mul_lo_u32 v51, v50, %4\n v_add_u32 v51, 0x9e3779b9, v51\n v_mul_lo_u32 v52, v51, %4\n v_add_u32 v52, 0x9e3779b9, v52\n" \
+    "v_mul_lo_u32 v53, v52, %4\n v_add_u32 v53, 0x9e3779b9, v53\n v_mul_lo_u32 v54, v53, %4\n v_add_u32 v54, 0x9e3779b9, v54\n" \
+    "v_mul_lo_u32 v55, v54, %4\n v_add_u32 v55, 0x9e3779b9, v55\n" \
+    "v_lshrrev_b32 v40, %5, v40\n v_lshrrev_b32 v41, %5, v41\n v_lshrrev_b32 v42, %5, v42\n v_lshrrev_b32 v43, %5, v43\n" \
+    "v_lshrrev_b32 v44, %5, v44\n v_lshrrev_b32 v45, %5, v45\n v_lshrrev_b32 v46, %5, v46\n v_lshrrev_b32 v47, %5, v47\n" \
+    "v_lshrrev_b32 v48, %5, v48\n v_lshrrev_b32 v49, %5, v49\n v_lshrrev_b32 v50, %5, v50\n v_lshrrev_b32 v51, %5, v51\n" \
+    "v_lshrrev_b32 v52, %5, v52\n v_lshrrev_b32 v53, %5, v53\n v_lshrrev_b32 v54, %5, v54\n v_lshrrev_b32 v55, %5, v55\n" \
+    "v_mov_b32 v8, 0\nv_mov_b32 v9, 0\nv_mov_b32 v10, 0\nv_mov_b32 v11, 0\nv_mov_b32 v12, 0\nv_mov_b32 v13, 0\nv_mov_b32 v14, 0\nv_mov_b32 v15, 0\n" \
+    "v_mov_b32 v16, 0\nv_mov_b32 v17, 0\nv_mov_b32 v18, 0\nv_mov_b32 v19, 0\nv_mov_b32 v20, 0\nv_mov_b32 v21, 0\nv_mov_b32 v22, 0\nv_mov_b32 v23, 0\n"
+#define CLOB16_NOPAD CLOB, "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"
+#define CLOB16 CLOB, PAD_CLOB, "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"
+// both factors change with every instruction (product scanning: a_i b_(k-i))
+#define V16 M("v[8:9]", "v40", "v55") M("v[10:11]", "v41", "v54") M("v[12:13]", "v42", "v53") M("v[14:15]", "v43", "v52") \
+            M("v[16:17]", "v44", "v51") M("v[18:19]", "v45", "v50") M("v[20:21]", "v46", "v49") M("v[22:23]", "v47", "v48") \
+            M("v[8:9]", "v48", "v47") M("v[10:11]", "v49", "v46") M("v[12:13]", "v50", "v45") M("v[14:15]", "v51", "v44") \
+            M("v[16:17]", "v52", "v43") M("v[18:19]", "v53", "v42") M("v[20:21]", "v54", "v41") M("v[22:23]", "v55", "v40")
+// one factor stays for eight instructions (operand scanning: a_i b_j, j = 0 .. 7)
+#define F16 M("v[8:9]", "v40", "v48") M("v[10:11]", "v40", "v49") M("v[12:13]", "v40", "v50") M("v[14:15]", "v40", "v51") \
+            M("v[16:17]", "v40", "v52") M("v[18:19]", "v40", "v53") M("v[20:21]", "v40", "v54") M("v[22:23]", "v40", "v55") \
+            M("v[8:9]", "v41", "v48") M("v[10:11]", "v41", "v49") M("v[12:13]", "v41", "v50") M("v[14:15]", "v41", "v51") \
+            M("v[16:17]", "v41", "v52") M("v[18:19]", "v41", "v53") M("v[20:21]", "v41", "v54") M("v[22:23]", "v41", "v55")
+// the same two factors all the time, random contents
+#define S16 M("v[8:9]", "v40", "v48") M("v[10:11]", "v40", "v48") M("v[12:13]", "v40", "v48") M("v[14:15]", "v40", "v48") \
+            M("v[16:17]", "v40", "v48") M("v[18:19]", "v40", "v48") M("v[20:21]", "v40", "v48") M("v[22:23]", "v40", "v48") \
+            M("v[8:9]", "v40", "v48") M("v[10:11]", "v40", "v48") M("v[12:13]", "v40", "v48") M("v[14:15]", "v40", "v48") \
+            M("v[16:17]", "v40", "v48") M("v[18:19]", "v40", "v48") M("v[20:21]", "v40", "v48") M("v[22:23]", "v40", "v48")
+#define X4(B) B B B B
+#define X256(B) X4(X4(X4(X4(B))))
+#define DATA_KERNEL(NAME, B16) DATA_KERNEL_C(NAME, B16, CLOB16)
+#define DATA_KERNEL_C(NAME, B16, CL)                                                                                              \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift) {            \
+        uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;                                          \
+        asm volatile(INIT16 "s_mov_b32 s20, %3\n1:\n" X256(B16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI \
+                     : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift) : CL);                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                     \
+    }
+DATA_KERNEL(k_varied, V16)
+DATA_KERNEL(k_one_fixed, F16)
+DATA_KERNEL(k_same, S16)
+DATA_KERNEL_C(k_varied_small, V16, CLOB16_NOPAD)   // 56 registers: up to eight waves per SIMD
+
+// one random row per 4096 multiply-adds: address = base + (lcg >> shift) * 128; loads issued at the head of a body, waited at the head of the next
+__global__ __launch_bounds__(256) void k_gather(uint32_t *out, uint32_t seed, uint32_t iters, const uint8_t *table, uint32_t row_mask) {
+    uint32_t a = seed ^ threadIdx.x, b = (seed * 2654435761u) | 1u, r;
+    uint32_t lcg = (seed + blockIdx.x * 256 + threadIdx.x) * 747796405u + 2891336453u;
+    asm volatile(INIT
+                 "v_mov_b32 v50, %6\n"
+                 "s_mov_b32 s20, %3\n1:\n"
+                 "s_waitcnt vmcnt(0)\n"
+                 "v_xor_b32 v40, v40, v60\n v_or_b32 v40, 1, v40\n"          /* the loaded data is used */
+                 "v_mul_lo_u32 v50, v50, %7\n v_add_u32 v50, 0x9e3779b9, v50\n"
+                 "v_lshrrev_b32 v51, 2, v50\n v_and_b32 v51, %5, v51\n"
+                 "v_mov_b32 v52, 128\n"
+                 "v_mad_u64_u32 v[54:55], vcc, v51, v52, %4\n"
+                 "global_load_dwordx4 v[60:63], v[54:55], off\n"
+                 "global_load_dwordx4 v[64:67], v[54:55], off offset:16\n"
+                 "global_load_dwordx4 v[68:71], v[54:55], off offset:32\n"
+                 "global_load_dwordx4 v[72:75], v[54:55], off offset:48\n"
+                 "global_load_dwordx4 v[76:79], v[54:55], off offset:64\n"
+                 "global_load_dwordx4 v[80:83], v[54:55], off offset:80\n"
+                 "global_load_dwordx4 v[84:87], v[54:55], off offset:96\n"
+                 BODY4096 "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n" FINI
+                 : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "v"((uint64_t)table), "s"(row_mask), "v"(lcg), "s"(747796405u)
+                 : CLOB, PAD_CLOB, "v50", "v51", "v52", "v54", "v55", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72",
+                   "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+int main(int argc, char **argv) {
+    double gb = 128;
+    for (int i = 1; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "--gb")) gb = atof(argv[i + 1]);
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int n_cu = prop.multiProcessorCount;
+    uint32_t *d_out;
+    CHECK(hipMalloc(&d_out, (size_t)n_cu * 2 * 256 * 4));
+    size_t rows = 1;
+    while (rows * 2 * 128 <= (size_t)(gb * (1 << 30))) rows *= 2;
+    uint8_t *table;
+    CHECK(hipMalloc(&table, rows * 128));
+    CHECK(hipMemset(table, 1, rows * 128));
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    int grid = n_cu * 2;  // two workgroups of four waves per CU: two waves per SIMD
+    printf("table %.1f GB (%zu rows of 128 bytes), %d workgroups of 256 lanes\n", rows * 128 / 1e9, rows, grid);
+    for (int pass = 0; pass < 2; pass++)
+        for (int with_gather = 0; with_gather < 2; with_gather++)
+            for (uint32_t iters : {32u, 128u, 512u, 2048u}) {  // x 4096 instructions: ~0.25, 1, 4, 16 ms per launch
+                int launches = (int)(200.0 / (iters * 4096 * 2 * 1.9e-6)) + 2;
+                for (int rep = 0; rep < 2; rep++) {  // the second repetition is reported: the board has been under this load for 0.2 s
+                    CHECK(hipEventRecord(e0, st));
+                    for (int l = 0; l < launches; l++) {
+                        if (with_gather)
+                            hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, table, (uint32_t)(rows - 1));
+                        else
+                            hipLaunchKernelGGL(k_plain, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters);
+                    }
+                    CHECK(hipEventRecord(e1, st));
+                    CHECK(hipEventSynchronize(e1));
+                    float ms;
+                    CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    double per_launch = ms / launches;
+                    double ns = per_launch * 1e6 / ((double)iters * 4096 * 2);  // two waves share a SIMD
+                    if (rep == 1)
+                        printf("{\"stream\": \"%s\", \"ms_per_launch\": %.3f, \"launches\": %d, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n",
+                               with_gather ? "mad + gathers" : "mad only", per_launch, launches, ns, ns * 2.4);
+                }
+            }
+    struct { const char *name; void (*k)(uint32_t *, uint32_t, uint32_t, uint32_t); uint32_t shift; } dk[] = {
+        {"same two factors, random 28-bit contents", k_same, 4}, {"one factor fixed for 8 instructions, random 28-bit", k_one_fixed, 4},
+        {"both factors change every instruction, random 28-bit", k_varied, 4}, {"both factors change every instruction, random 32-bit", k_varied, 0},
+        {"both factors change every instruction, 8-bit contents", k_varied, 24}};
+    for (int pass = 0; pass < 2; pass++)
+        for (auto &d : dk) {
+            uint32_t iters = 1024;  // ~7 ms per launch
+            int launches = 28;
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0, st));
+                for (int l = 0; l < launches; l++) hipLaunchKernelGGL(d.k, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, d.shift);
+                CHECK(hipEventRecord(e1, st));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                double per_launch = ms / launches;
+                double ns = per_launch * 1e6 / ((double)iters * 4096 * 2);
+                if (rep == 1)
+                    printf("{\"stream\": \"%s\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n", d.name, per_launch, ns, ns * 2.4);
+            }
+        }
+    for (int pass = 0; pass < 2; pass++)
+        for (int w : {1, 2, 4, 8}) {
+            uint32_t iters = 1024 / w;
+            int launches = 28;
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0, st));
+                for (int l = 0; l < launches; l++) hipLaunchKernelGGL(k_varied_small, dim3(n_cu * w), dim3(256), 0, st, d_out, 12345u + l, iters, 4u);
+                CHECK(hipEventRecord(e1, st));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                double per_launch = ms / launches;
+                double ns = per_launch * 1e6 / ((double)iters * 4096 * w);
+                if (rep == 1)
+                    printf("{\"stream\": \"both factors change every instruction, random 28-bit, %d waves per SIMD\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n", w, per_launch, ns, ns * 2.4);
+            }
+        }
+    return 0;
+}
