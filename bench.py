@@ -737,8 +737,9 @@ def main():
             "direct_table_build_s_max_over_ranks": t_table_max if direct_bits else None,
             "direct_table_build_breakdown_ms": table_breakdown,
             "direct_table_build_breakdown_note": "free_old = hipFree of the table in place; table_malloc = the hipMallocs of the new table, one per window, summed "
-                                                 "(the driver provisions device memory at 15-26 ms per GB on the boxes measured, serially, whatever the API or "
-                                                 "the number of calls: tools/alloc_bench.hip, profiles/r03_alloc_bench.txt); the GPU builds window j while the host "
+                                                 "(on idle memory they return in a millisecond; what they wait for is the driver's background scrub, ~25 ms per GB, of memory released "
+                                                 "shortly before -- by the previous process of this box, or by this process freeing the default table just above: "
+                                                 "tools/alloc_pieces.hip, profiles/r03_alloc_pieces.txt); the GPU builds window j while the host "
                                                  "allocates window j + 1, and kernels = what was left of k_direct_build after the last allocation returned" if direct_bits else None,
             "direct_table_build_note": "every rank builds its own table from the broadcast setup points, once, outside the timed region" if direct_bits else None,
         }

@@ -288,8 +288,8 @@ size_t lwkzg_profile_report(char *buf, size_t cap);
 /* JSON: the wall-clock milliseconds of this settings object's load (context, points + tables, G2 + FFT settings, the
  * default engine's table) and of its last lwkzg_enable_direct_table: freeing the old table, the hipMallocs of the new one
  * (one per window, summed: the GPU builds window j while the host allocates window j + 1), scratch, and what was left of the
- * build kernels after the last allocation returned; returns bytes needed (incl. NUL). The allocations dominate: the driver
- * provisions device memory at 15-26 ms per GB on the boxes measured (tools/alloc_bench.hip). */
+ * build kernels after the last allocation returned; returns bytes needed (incl. NUL). The allocations return in a millisecond on idle memory
+ * and wait ~25 ms per GB for the driver's scrub of memory released shortly before (tools/alloc_pieces.hip). */
 size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap);
 /* First use of the HIP runtime by this process (device context + this library's code object), so that a caller can pay
  * and time it apart from its first real call. 0, or -1 without a GPU. */

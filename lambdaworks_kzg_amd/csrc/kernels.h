@@ -47,9 +47,9 @@ constexpr size_t kDirectRowAligned = 128, kDirectRowPacked = 112;
 constexpr size_t kDirectAlignedHeadroom = (size_t)8 << 30;  // what an aligned table must leave free (two workspaces, verification scratch, the caller's buffers)
 size_t direct_table_entries(int bits);
 int direct_num_windows(int bits);
-// The table is ONE ALLOCATION PER WINDOW: the driver provisions device memory at 15-26 ms per GB, serially (profiles/r03_alloc_bench.txt),
-// so window j + 1 is being allocated by the host while the GPU builds window j, and the build costs max(allocation, kernels) instead
-// of their sum. The kernels index `win_dev`, the windows' base addresses in device memory.
+// The table is ONE ALLOCATION PER WINDOW: a hipMalloc that needs memory released shortly before (by the previous process, or by the table
+// this one replaces) waits for the driver's scrub of it, ~25 ms per GB (profiles/r03_alloc_pieces.txt), so window j + 1 is being allocated
+// by the host while the GPU builds window j, and the build costs max(wait, kernels) instead of their sum. The kernels index `win_dev`, the windows' base addresses in device memory.
 constexpr int kDirectMaxWindows = 26;  // 10-bit windows
 struct DirectTable {
     void *win[kDirectMaxWindows] = {};  // rows of window j: 4096 * 2^(bits-1) (the top window: 4096 * 2^wtop) rows of row_bytes
