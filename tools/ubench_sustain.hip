@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t *out, uint32_t seed, ui
 
 int main(int argc, char **argv) {
     double gb = 128;
-    for (int i = 1; i + 1 < argc; i++)
-        if (!strcmp(argv[i], "--gb")) gb = atof(argv[i + 1]);
+    bool quick = false;   // --quick: one size of launch (8.39e6 wave-instructions per SIMD each), six launches per stream: for a rocprofv3 --pmc pass
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--gb") && i + 1 < argc) gb = atof(argv[i + 1]);
+        if (!strcmp(argv[i], "--quick")) quick = true;
+    }
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     int n_cu = prop.multiProcessorCount;
@@ -133,10 +136,13 @@ int main(int argc, char **argv) {
     CHECK(hipEventCreate(&e1));
     int grid = n_cu * 2;  // two workgroups of four waves per CU: two waves per SIMD
     printf("table %.1f GB (%zu rows of 128 bytes), %d workgroups of 256 lanes\n", rows * 128 / 1e9, rows, grid);
-    for (int pass = 0; pass < 2; pass++)
+    const int passes = quick ? 1 : 2;
+    for (int pass = 0; pass < passes; pass++)
         for (int with_gather = 0; with_gather < 2; with_gather++)
             for (uint32_t iters : {32u, 128u, 512u, 2048u}) {  // x 4096 instructions: ~0.25, 1, 4, 16 ms per launch
-                int launches = (int)(200.0 / (iters * 4096 * 2 * 1.9e-6)) + 2;
+                if (quick && iters != 2048u) continue;
+                if (quick) iters = 1024;
+                int launches = quick ? 6 : (int)(200.0 / (iters * 4096 * 2 * 1.9e-6)) + 2;
                 for (int rep = 0; rep < 2; rep++) {  // the second repetition is reported: the board has been under this load for 0.2 s
                     CHECK(hipEventRecord(e0, st));
                     for (int l = 0; l < launches; l++) {
@@ -160,10 +166,10 @@ int main(int argc, char **argv) {
         {"same two factors, random 28-bit contents", k_same, 4}, {"one factor fixed for 8 instructions, random 28-bit", k_one_fixed, 4},
         {"both factors change every instruction, random 28-bit", k_varied, 4}, {"both factors change every instruction, random 32-bit", k_varied, 0},
         {"both factors change every instruction, 8-bit contents", k_varied, 24}};
-    for (int pass = 0; pass < 2; pass++)
+    for (int pass = 0; pass < passes; pass++)
         for (auto &d : dk) {
             uint32_t iters = 1024;  // ~7 ms per launch
-            int launches = 28;
+            int launches = quick ? 6 : 28;
             for (int rep = 0; rep < 2; rep++) {
                 CHECK(hipEventRecord(e0, st));
                 for (int l = 0; l < launches; l++) hipLaunchKernelGGL(d.k, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, d.shift);
@@ -177,10 +183,10 @@ int main(int argc, char **argv) {
                     printf("{\"stream\": \"%s\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n", d.name, per_launch, ns, ns * 2.4);
             }
         }
-    for (int pass = 0; pass < 2; pass++)
+    for (int pass = 0; pass < passes; pass++)
         for (int w : {1, 2, 4, 8}) {
-            uint32_t iters = 1024 / w;
-            int launches = 28;
+            uint32_t iters = 2048 / w;   // the same 8.39e6 wave-instructions per SIMD per launch at every occupancy
+            int launches = quick ? 6 : 14;
             for (int rep = 0; rep < 2; rep++) {
                 CHECK(hipEventRecord(e0, st));
                 for (int l = 0; l < launches; l++) hipLaunchKernelGGL(k_varied_small, dim3(n_cu * w), dim3(256), 0, st, d_out, 12345u + l, iters, 4u);
