@@ -465,7 +465,7 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
         dist_info = {"initialised": True, "backend": dist.get_backend(), "ranks": dist.get_world_size(),
                      "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
-                     "note": "backend nccl IS RCCL on ROCm; collectives of this run: one broadcast of the setup image, barriers, "
+                     "note": ("backend nccl IS RCCL on ROCm" if dist.get_backend() == "nccl" else "backend %s: a plumbing rehearsal, not the RCCL path" % dist.get_backend()) + "; collectives of this run: one broadcast of the setup image, barriers, "
                              "the max-over-ranks of the timings"}
 
     # first use of the HIP runtime by this process, timed apart from the load (a fresh process on a fresh box pays about a
@@ -722,7 +722,9 @@ def main():
                                    "tiled_msm": "BASELINE configs[4]: one 2^20-term G1 MSM over the setup tiled 256 times, tiles split over "
                                                 "the GPUs, partial sums gathered and added on the host (%d is unused here)"}[args.op] % n,
                        "blobs_per_gpu_per_step": n, "caller_streams": n_cs, "scalars": args.scalars, "direct_bits": direct_bits, "direct_bits_min_over_ranks": direct_bits_min, "mode": "reference (big-endian monomial)" if args.mode == "reference" else "ckzg (little-endian evaluations, inverse NTT)", "op": args.op,
-                       "parallelism": "blob-sharded x%d, setup broadcast once (RCCL), no data-path collective" % world},
+                       "parallelism": ("blob-sharded x%d, setup broadcast once (%s), no data-path collective"
+                                       % (world, "RCCL" if dist_info.get("backend") == "nccl" else dist_info["backend"]))
+                                      if dist_info["initialised"] else "one GPU, no process group"},
             "roofline": roofline,
             "kernels": kernels,
             "hip_first_use_init_s": t_hip_init,
