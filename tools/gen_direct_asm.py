@@ -69,6 +69,13 @@ R1 = limbs(RMONT % P)
 # experiment knobs (A/B builds only; the committed .inc is generated with none of them set)
 KNOB_SDST = int(os.environ.get("LWK_ASM_SDST", "0"))      # 1: every chain writes its multiply-add carry-out to a scalar pair of its own
 KNOB_BLOCK = int(os.environ.get("LWK_ASM_BLOCK", "1"))    # instructions a chain issues before the next chain takes its turn
+KNOB_CONFINE = int(os.environ.get("LWK_ASM_CONFINE", "0"))   # 1: WRONG RESULTS -- every gather lands in a 1 MB part of the table (8 points x 64 rows x the windows): what does the memory side cost?
+KNOB_ROTWIN = int(os.environ.get("LWK_ASM_ROTWIN", "0"))     # 1: WRONG RESULTS -- workgroup g reads window (j + g) mod (nw - 1)'s allocation for its window j (all but the top one):
+                                                              # the same instructions and gathers, spread over the windows' allocations instead of all in one at a time
+KNOB_E64 = int(os.environ.get("LWK_ASM_E64", "1"))           # 1 (shipped): every vector instruction of the loop in an 8-byte encoding (4-byte VOP1 / VOP2 / VOPC forms take their _e64 one) and the
+                                                              # vector runs start 8-byte aligned, so no multiply-add sits at 4 mod 8 or straddles a fetch line: -3.3 % time, same box
+                                                              # (0: 2340 of the 3548 multiply-adds at 4 mod 8, 340 instructions across a 64-byte line; profiles/r03_experiments.md section 9)
+KNOB_PAUSE = os.environ.get("LWK_ASM_PAUSE", "")          # "nop_top" / "sleep_top": s_nop 15 / s_sleep 1 at the head of the loop; "nop_groups": s_nop 15 in front of every product group
 
 # ---- register map ------------------------------------------------------------------------------------------------
 V = {}
@@ -149,6 +156,7 @@ sTMP = sregs("TMP", 2, 2)
 sTMPB = sregs("TMPB", 2, 2)
 sHCMP, sHJ, sMASKJ, sSTMP = sregs("HCMP"), sregs("HJ"), sregs("MASKJ"), sregs("STMP")
 sCARRY2 = sregs("CARRY2", 2, 2) if KNOB_SDST else None
+sROT = sregs("ROT") if KNOB_ROTWIN else None
 NUM_SGPRS = _snext[0]
 assert NUM_SGPRS <= 102, NUM_SGPRS
 
@@ -217,6 +225,11 @@ def fmt(o):
     raise ValueError(o)
 
 
+# vector instructions with a 4-byte encoding (VOP1 / VOP2 / VOPC) that the generator uses; a 32-bit literal makes them 8 bytes anyway (and VOP3 takes none)
+E64_OPS = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_lshlrev_b32", "v_lshrrev_b32", "v_mov_b32", "v_cndmask_b32",
+           "v_cmp_lt_u32", "v_cmp_gt_u32", "v_cmp_ne_u32", "v_cmp_eq_u32"}
+
+
 class Prog:
     def __init__(self):
         self.ins = []
@@ -237,6 +250,8 @@ class Prog:
                 out.append("; " + args[0])
                 continue
             line = op
+            if KNOB_E64 and op in E64_OPS and not any(a[0] == "op" or (a[0] == "lit" and 64 < a[1] < 0xFFFFFFF0) for a in args):
+                line += "_e64"
             if args:
                 line += " " + ", ".join(fmt(a) for a in args)
             if "offset" in kw and kw["offset"]:
@@ -345,6 +360,8 @@ def _chain(pairs, square, out, m, acc, tmp, wide=False):
 
 def interleave(prog, *chains):
     """merge instruction lists proportionally (each list keeps its order)."""
+    if KNOB_E64:
+        prog.emit(".p2align", ("raw", "3"))      # (scalar instructions in front of a run of products are 4 bytes each)
     n = [len(c) for c in chains]
     pos = [0] * len(chains)
     total = sum(n)
@@ -388,6 +405,10 @@ def build():
     e("v_mov_b32", v(VRB), opnd(11))
     e("v_mov_b32", v(POINT), opnd(12))
     e("v_mov_b32", v(VTID), opnd(13))
+    if KNOB_ROTWIN:
+        e("v_lshrrev_b32", v(T1), lit(8), v(VTID))
+        e("s_nop", ("raw", "0"))
+        e("v_readfirstlane_b32", s(sROT), v(T1))
     for i in range(14):
         e("s_mov_b32", s(sMOD[i]), lit(MOD[i]))
     e("s_mov_b32", s(sINV), lit(INV))
@@ -419,8 +440,18 @@ def build():
     row_loads(p)
     e("s_mov_b64", EXEC, lit(-1))
     # ---------------- the loop
-    e(".p2align", ("raw", "3"))
+    e(".p2align", ("raw", "6" if KNOB_PAUSE in ("align64", "align64_nop0") else "3"))
     p.label("L_loop%=")
+    if KNOB_PAUSE in ("nop_top", "nop_groups", "nop_top2"):
+        e("s_nop", ("raw", "15"))
+    if KNOB_PAUSE == "nop_top2":
+        e("s_nop", ("raw", "15"))
+    if KNOB_PAUSE == "nop_top_half":
+        e("s_nop", ("raw", "7"))
+    if KNOB_PAUSE in ("nop0", "align64_nop0"):
+        e("s_nop", ("raw", "0"))
+    if KNOB_PAUSE == "sleep_top":
+        e("s_sleep", ("raw", "1"))
     e("s_mov_b64", sp(sVALID), sp(sVALIDN))
     e("s_mov_b64", sp(sNEG), sp(sNEGN))
     e("s_waitcnt", ("raw", "vmcnt(0)"))
@@ -531,8 +562,12 @@ def build():
     for i in range(14):
         e("v_lshlrev_b32", v(D1[i]), lit(1), v(U[i]))
         e("v_lshlrev_b32", v(D2[i]), lit(1), v(S[i]))
+    if KNOB_PAUSE in ("nop_groups", "nop_mid"):
+        e("s_nop", ("raw", "15"))
     interleave(p, chain_sqr(pp_, D1, PP, M1, ACC1, T1, wide=True), chain_sqr(rr, D2, RR2, M2, ACC2, T2r))
     pp, rr2 = Val(PP, WIDE_B, 1), Val(RR2, NARROW_B, 1)
+    if KNOB_PAUSE == "nop_groups":
+        e("s_nop", ("raw", "15"))
     interleave(p, chain_mul(pp_, pp, D1, M1, ACC1, T1, wide=True), chain_mul(nx, pp, D2, M2, ACC2, T2r))
     ppp, nq = Val(D1, WIDE_B, 1), Val(D2, NARROW_B, 1)          # nq = (-X1) PP = -Q
     assert rr2.B + 2 * nq.B <= 8
@@ -558,6 +593,8 @@ def build():
     t2 = Val(U, 32, 2)
     # ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP, -Y3 = R t1 + (-Y1) t2   (three chains; each output overwrites an input limb by limb:
     # output limb k - 14 is written at column k, the input limb k - 14 was last read at column k - 1)
+    if KNOB_PAUSE == "nop_groups":
+        e("s_nop", ("raw", "15"))
     interleave(p, chain_mul(zz, pp, ZZ, M1, ACC1, T1, wide=True), chain_mul(zzz, ppp, ZZZ, M2, ACC2, T2r, wide=True),
                chain_mul_add(rr, t1, ny, t2, NY, RR2, ACC3, T3, wide=True))
     assert nx3.B <= nx.B and nx3.L <= nx.L
@@ -608,7 +645,27 @@ def digit_and_address(p):
     e("s_cselect_b32", s(sHCMP), lit(-1), s(sH))
     e("s_cselect_b32", s(sHJ), s(sHTOP), s(sH))
     # base of window sJ (asked for now, needed by the last instruction below)
-    e("s_lshl_b32", s(sSTMP), s(sJ), lit(3))
+    if KNOB_ROTWIN:
+        # index = j == nw - 1 ? j : (j + rot) mod (nw - 1)      (sSTMP = nw - 1 here, scc = (j == nw - 1))
+        e("s_add_u32", s(sTMPB[0]), s(sJ), s(sROT))
+        e("s_and_b32", s(sTMPB[0]), s(sTMPB[0]), lit(0xffff))
+        e("v_cvt_f32_u32", v(T3), s(sTMPB[0]))                   # (a cheap exact mod for small numbers: t - floor(t / m) m)
+        e("v_cvt_f32_u32", v(RAW), s(sSTMP))
+        e("v_rcp_iflag_f32", v(RAW), v(RAW))
+        e("v_mul_f32", v(T3), v(T3), v(RAW))
+        e("v_cvt_u32_f32", v(T3), v(T3))
+        e("s_nop", ("raw", "0"))
+        e("v_readfirstlane_b32", s(sTMPB[1]), v(T3))
+        e("s_mul_i32", s(sTMPB[1]), s(sTMPB[1]), s(sSTMP))
+        e("s_sub_u32", s(sTMPB[0]), s(sTMPB[0]), s(sTMPB[1]))
+        e("s_cmp_ge_u32", s(sTMPB[0]), s(sSTMP))                  # (the reciprocal may be one short)
+        e("s_cselect_b32", s(sTMPB[1]), s(sSTMP), lit(0))
+        e("s_sub_u32", s(sTMPB[0]), s(sTMPB[0]), s(sTMPB[1]))
+        e("s_cmp_eq_u32", s(sJ), s(sSTMP))
+        e("s_cselect_b32", s(sSTMP), s(sJ), s(sTMPB[0]))
+        e("s_lshl_b32", s(sSTMP), s(sSTMP), lit(3))
+    else:
+        e("s_lshl_b32", s(sSTMP), s(sJ), lit(3))
     e("s_load_dwordx2", sp(sTMPB), sp(sTABLE), s(sSTMP))
     e("v_and_b32", v(RAW), s(sMASKJ), v(SC[0]))
     e("v_add_u32", v(RAW), v(RAW), v(CARRY))
@@ -621,7 +678,16 @@ def digit_and_address(p):
     e("v_cndmask_b32", v(CARRY), lit(0), lit(1), VCC)
     e("s_mov_b64", sp(sNEGN), VCC)
     e("v_cmp_ne_u32", sp(sVALIDN), lit(0), v(MAG))
-    e("v_mad_u32_u24", v(T3), v(POINT), s(sHJ), v(MAG))
+    if KNOB_CONFINE:
+        # 1: 8 points x 64 rows per window (1 MB: cache)   2: 64 points x all rows (4 GB in 1024 runs of 4 MB: HBM, few pages)
+        # 3: all points x 16 rows (134 MB in 65,536 runs of 2 KB: every page of the table, little of its data)
+        pmask, mmask = {1: (7, 0x3f), 2: (63, 0x7fff), 3: (4095, 0xf)}[KNOB_CONFINE]
+        e("v_and_b32", v(T3), lit(pmask), v(POINT))
+        e("v_mad_u32_u24", v(T3), v(T3), s(sHJ), v(MAG))
+        e("v_and_b32", v(T3), lit(mmask | (pmask << 15)), v(T3))       # (hj = 2^15 on every window but the top one)
+        e("v_or_b32", v(T3), lit(1), v(T3))
+    else:
+        e("v_mad_u32_u24", v(T3), v(POINT), s(sHJ), v(MAG))
     e("s_waitcnt", ("raw", "lgkmcnt(0)"))
     e("s_sub_u32", s(sTMPB[0]), s(sTMPB[0]), s(sRB))          # minus one row: mag counts from 1
     e("s_subb_u32", s(sTMPB[1]), s(sTMPB[1]), lit(0))

@@ -85,6 +85,95 @@ DATA_KERNEL(k_one_fixed, F16)
 DATA_KERNEL(k_same, S16)
 DATA_KERNEL_C(k_varied_small, V16, CLOB16_NOPAD)   // 56 registers: up to eight waves per SIMD
 
+// the random-operand stream WITH the accumulation's memory pattern: one random 112-byte row per 4096 instructions per lane, used one body later
+__global__ __launch_bounds__(256) void k_varied_gather(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift, const uint8_t *table, uint32_t row_mask) {
+    uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;
+    asm volatile(INIT16
+                 "v_mov_b32 v56, %1\n"
+                 "s_mov_b32 s20, %3\n1:\n"
+                 "s_waitcnt vmcnt(0)\n"
+                 "v_mul_lo_u32 v56, v56, %4\n v_add_u32 v56, 0x9e3779b9, v56\n"
+                 "v_lshrrev_b32 v57, 2, v56\n v_and_b32 v57, %7, v57\n"
+                 "v_mov_b32 v58, 128\n"
+                 "v_mad_u64_u32 v[60:61], vcc, v57, v58, %6\n"
+                 "global_load_dwordx4 v[64:67], v[60:61], off\n"
+                 "global_load_dwordx4 v[68:71], v[60:61], off offset:16\n"
+                 "global_load_dwordx4 v[72:75], v[60:61], off offset:32\n"
+                 "global_load_dwordx4 v[76:79], v[60:61], off offset:48\n"
+                 "global_load_dwordx4 v[80:83], v[60:61], off offset:64\n"
+                 "global_load_dwordx4 v[84:87], v[60:61], off offset:80\n"
+                 "global_load_dwordx4 v[88:91], v[60:61], off offset:96\n"
+                 X256(V16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n"
+                 "v_xor_b32 v8, v8, v64\n" FINI
+                 : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift), "v"((uint64_t)table), "s"(row_mask)
+                 : CLOB16, "v56", "v57", "v58", "v60", "v61", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
+                   "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+// ---- what in the accumulation's stream costs more than pure multiply-adds? (all with an s_nop 15 per 4096 instructions: the fast regime)
+// one factor from scalar registers (the modulus limbs of the reduction half)
+#define SG16 M("v[8:9]", "v40", "s40") M("v[10:11]", "v41", "s41") M("v[12:13]", "v42", "s42") M("v[14:15]", "v43", "s43") \
+             M("v[16:17]", "v44", "s44") M("v[18:19]", "v45", "s45") M("v[20:21]", "v46", "s46") M("v[22:23]", "v47", "s47") \
+             M("v[8:9]", "v48", "s47") M("v[10:11]", "v49", "s46") M("v[12:13]", "v50", "s45") M("v[14:15]", "v51", "s44") \
+             M("v[16:17]", "v52", "s43") M("v[18:19]", "v53", "s42") M("v[20:21]", "v54", "s41") M("v[22:23]", "v55", "s40")
+#define SGINIT "v_readfirstlane_b32 s40, v48\n v_readfirstlane_b32 s41, v49\n v_readfirstlane_b32 s42, v50\n v_readfirstlane_b32 s43, v51\n" \
+               "v_readfirstlane_b32 s44, v52\n v_readfirstlane_b32 s45, v53\n v_readfirstlane_b32 s46, v54\n v_readfirstlane_b32 s47, v55\n"
+// the kernel's mix: 13 multiply-adds, one 64-bit shift, one mask, one 32-bit multiply per 16
+#define MIX16 M("v[8:9]", "v40", "v55") M("v[10:11]", "v41", "v54") M("v[12:13]", "v42", "v53") M("v[14:15]", "v43", "v52") \
+              M("v[16:17]", "v44", "v51") "v_lshrrev_b64 v[24:25], 28, v[8:9]\n" M("v[18:19]", "v45", "v50") M("v[20:21]", "v46", "v49") M("v[22:23]", "v47", "v48") \
+              "v_and_b32 v26, 0xfffffff, v10\n" M("v[8:9]", "v48", "v47") M("v[10:11]", "v49", "v46") M("v[12:13]", "v50", "v45") "v_mul_lo_u32 v27, v12, v41\n" \
+              M("v[14:15]", "v51", "v44") M("v[16:17]", "v52", "v43")
+// three interleaved dependent chains (what three products in flight look like), and two
+#define C3_16 M("v[8:9]", "v40", "v55") M("v[10:11]", "v41", "v54") M("v[12:13]", "v42", "v53") M("v[8:9]", "v43", "v52") M("v[10:11]", "v44", "v51") M("v[12:13]", "v45", "v50") \
+              M("v[8:9]", "v46", "v49") M("v[10:11]", "v47", "v48") M("v[12:13]", "v48", "v47") M("v[8:9]", "v49", "v46") M("v[10:11]", "v50", "v45") M("v[12:13]", "v51", "v44") \
+              M("v[8:9]", "v52", "v43") M("v[10:11]", "v53", "v42") M("v[12:13]", "v54", "v41") M("v[8:9]", "v55", "v40")
+#define C2_16 M("v[8:9]", "v40", "v55") M("v[10:11]", "v41", "v54") M("v[8:9]", "v42", "v53") M("v[10:11]", "v43", "v52") M("v[8:9]", "v44", "v51") M("v[10:11]", "v45", "v50") \
+              M("v[8:9]", "v46", "v49") M("v[10:11]", "v47", "v48") M("v[8:9]", "v48", "v47") M("v[10:11]", "v49", "v46") M("v[8:9]", "v50", "v45") M("v[10:11]", "v51", "v44") \
+              M("v[8:9]", "v52", "v43") M("v[10:11]", "v53", "v42") M("v[8:9]", "v54", "v41") M("v[10:11]", "v55", "v40")
+#define SCLOB "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "v24", "v25", "v26", "v27"
+#define STREAM_KERNEL(NAME, PRE, B16)                                                                                       \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift) {            \
+        uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;                                          \
+        asm volatile(INIT16 PRE "s_mov_b32 s20, %3\n1:\n s_nop 15\n" X256(B16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI \
+                     : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift) : CLOB16, SCLOB);              \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                     \
+    }
+STREAM_KERNEL(k_s_base, "", V16)
+STREAM_KERNEL(k_s_sgpr, SGINIT, SG16)
+STREAM_KERNEL(k_s_mix, "", MIX16)
+STREAM_KERNEL(k_s_chain3, "", C3_16)
+STREAM_KERNEL(k_s_chain2, "", C2_16)
+
+// ---- which ingredient of the gather changes the rate? the random-operand stream with something else at the head of every body of PER x 16 instructions
+#define XN_16(B) B B B B B B B B B B B B B B B B
+#define X64(B) X4(X4(X4(B)))
+#define EXTRA_KERNEL(NAME, BODYX, EXTRA)                                                                                                           \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift, const uint8_t *table, uint32_t row_mask) { \
+        uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;                                                                 \
+        asm volatile(INIT16 "v_mov_b32 v56, %1\n v_lshrrev_b64 v[60:61], 0, %6\n"                                                         \
+                     "s_mov_b32 s20, %3\n1:\n" EXTRA BODYX "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n" FINI \
+                     : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift), "v"((uint64_t)table), "s"(row_mask)                      \
+                     : CLOB16, "v56", "v57", "v58", "v60", "v61", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", \
+                       "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");                                 \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                                            \
+    }
+#define ADDR_ONLY "v_mul_lo_u32 v56, v56, %4\n v_add_u32 v56, 0x9e3779b9, v56\n v_lshrrev_b32 v57, 2, v56\n v_and_b32 v57, %7, v57\n v_mov_b32 v58, 128\n v_mad_u64_u32 v[64:65], vcc, v57, v58, %6\n"
+#define ONE_LOAD_SAME "s_waitcnt vmcnt(0)\n global_load_dword v64, v[60:61], off\n"
+#define SEVEN_LOADS_SAME "s_waitcnt vmcnt(0)\n global_load_dwordx4 v[64:67], v[60:61], off\n global_load_dwordx4 v[68:71], v[60:61], off offset:16\n global_load_dwordx4 v[72:75], v[60:61], off offset:32\n" \
+                         "global_load_dwordx4 v[76:79], v[60:61], off offset:48\n global_load_dwordx4 v[80:83], v[60:61], off offset:64\n global_load_dwordx4 v[84:87], v[60:61], off offset:80\n global_load_dwordx4 v[88:91], v[60:61], off offset:96\n"
+#define SLEEP1 "s_sleep 1\n"
+#define NOP16 "s_nop 15\n"
+#define SETPRIO "s_setprio 1\n s_setprio 0\n"
+EXTRA_KERNEL(k_x_addr, X256(V16), ADDR_ONLY)
+EXTRA_KERNEL(k_x_load1, X256(V16), ONE_LOAD_SAME)
+EXTRA_KERNEL(k_x_load7, X256(V16), SEVEN_LOADS_SAME)
+EXTRA_KERNEL(k_x_sleep, X256(V16), SLEEP1)
+EXTRA_KERNEL(k_x_nop, X256(V16), NOP16)
+EXTRA_KERNEL(k_x_load1_per1024, X64(V16), ONE_LOAD_SAME)
+EXTRA_KERNEL(k_x_sleep_per1024, X64(V16), SLEEP1)
+EXTRA_KERNEL(k_x_none, X256(V16), "")
+
 // one random row per 4096 multiply-adds: address = base + (lcg >> shift) * 128; loads issued at the head of a body, waited at the head of the next
 __global__ __launch_bounds__(256) void k_gather(uint32_t *out, uint32_t seed, uint32_t iters, const uint8_t *table, uint32_t row_mask) {
     uint32_t a = seed ^ threadIdx.x, b = (seed * 2654435761u) | 1u, r;
@@ -181,6 +270,69 @@ int main(int argc, char **argv) {
                 double ns = per_launch * 1e6 / ((double)iters * 4096 * 2);
                 if (rep == 1)
                     printf("{\"stream\": \"%s\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n", d.name, per_launch, ns, ns * 2.4);
+            }
+        }
+    {   // the random-operand stream with one random row per 4096 instructions per lane out of regions of different sizes (the whole table; one 17 GB
+        // window's worth; what the memory-side cache holds; what an L2 holds), against the stream with a pause instead of the loads
+        struct { const char *name; uint32_t mask; } gm[] = {{"no loads (s_nop 15 per 4096)", 0}, {"rows out of the whole 137 GB", (uint32_t)(rows - 1)},
+            {"rows out of 17 GB", (1u << 27) - 1}, {"rows out of 268 MB", (1u << 21) - 1}, {"rows out of 1 MB", (1u << 13) - 1}};
+        for (int pass = 0; pass < 2 * passes; pass++)
+            for (auto &g : gm) {
+                uint32_t iters = 1024;
+                int launches = quick ? 6 : 20;
+                for (int rep = 0; rep < 2; rep++) {
+                    CHECK(hipEventRecord(e0, st));
+                    for (int l = 0; l < launches; l++) {
+                        if (g.mask) hipLaunchKernelGGL(k_varied_gather, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, 4u, table, g.mask);
+                        else hipLaunchKernelGGL(k_x_nop, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, 4u, table, (uint32_t)(rows - 1));
+                    }
+                    CHECK(hipEventRecord(e1, st));
+                    CHECK(hipEventSynchronize(e1));
+                    float ms;
+                    CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    double ns = ms / launches * 1e6 / ((double)iters * 4096 * 2);
+                    if (rep == 1)
+                        printf("{\"stream\": \"random 28-bit, both factors change, %s\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f}\n", g.name, ms / launches, ns);
+                }
+            }
+    }
+    struct { const char *name; void (*k)(uint32_t *, uint32_t, uint32_t, uint32_t); } sk[] = {
+        {"eight accumulators, both factors vector registers", k_s_base}, {"one factor from scalar registers", k_s_sgpr},
+        {"13 multiply-adds + 64-bit shift + mask + 32-bit multiply per 16", k_s_mix}, {"three interleaved dependent chains", k_s_chain3},
+        {"two interleaved dependent chains", k_s_chain2}, {"eight accumulators (again)", k_s_base}};
+    for (int pass = 0; pass < passes; pass++)
+        for (auto &x : sk) {
+            int launches = quick ? 6 : 20;
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0, st));
+                for (int l = 0; l < launches; l++) hipLaunchKernelGGL(x.k, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, 1024u, 4u);
+                CHECK(hipEventRecord(e1, st));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                double ns = ms / launches * 1e6 / ((double)1024 * 4096 * 2);
+                if (rep == 1)
+                    printf("{\"stream\": \"random 28-bit + s_nop 15 per 4096, %s\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f}\n", x.name, ms / launches, ns);
+            }
+        }
+    struct { const char *name; void (*k)(uint32_t *, uint32_t, uint32_t, uint32_t, const uint8_t *, uint32_t); uint32_t iters; } xk[] = {
+        {"nothing extra", k_x_none, 1024}, {"+ the six address instructions per 4096", k_x_addr, 1024}, {"+ one dword load (same address) per 4096", k_x_load1, 1024},
+        {"+ seven dwordx4 loads (same address) per 4096", k_x_load7, 1024}, {"+ s_sleep 1 per 4096", k_x_sleep, 1024}, {"+ s_nop 15 per 4096", k_x_nop, 1024},
+        {"+ one dword load per 1024", k_x_load1_per1024, 4096}, {"+ s_sleep 1 per 1024", k_x_sleep_per1024, 4096}, {"nothing extra (again)", k_x_none, 1024}};
+    for (int pass = 0; pass < passes; pass++)
+        for (auto &x : xk) {
+            int launches = quick ? 6 : 20;
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0, st));
+                for (int l = 0; l < launches; l++) hipLaunchKernelGGL(x.k, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, x.iters, 4u, table, (uint32_t)(rows - 1));
+                CHECK(hipEventRecord(e1, st));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                double per_launch = ms / launches;
+                double ns = per_launch * 1e6 / ((double)1024 * 4096 * 2);
+                if (rep == 1)
+                    printf("{\"stream\": \"random 28-bit, both factors change, %s\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f}\n", x.name, per_launch, ns);
             }
         }
     for (int pass = 0; pass < passes; pass++)
