@@ -242,7 +242,12 @@ class Prog:
 
     def text(self):
         out = []
+        prev_vector = False
         for op, args, kw in self.ins:
+            if KNOB_E64 and op.startswith("v_") and not prev_vector and out:
+                out.append("  .p2align 3")        # a run of vector instructions starts 8-byte aligned (the scalar ones in front of it are 4 bytes each)
+            if op not in ("label", "comment"):
+                prev_vector = op.startswith("v_")
             if op == "label":
                 out.append("%s:" % args[0])
                 continue
