@@ -137,12 +137,12 @@ INT_MAD_PEAK_MEASURED = 256 * 4 * 64 / 4.17 * 2.4e9
 INT_MAD_CYCLES_2_WAVES = 4.63
 KERNEL_CLOCK_HZ = 2.05e9                         # GRBM_GUI_ACTIVE under this kernel: 1.99-2.08 GHz (profiles/r02_issue_summary.json)
 INT_MAD_PEAK_THEORETICAL = 256 * 4 * 64 / 4 * 2.4e9   # 256 CUs x 4 SIMDs x 64 lanes / 4 cycles per wave-instruction x 2.4 GHz = 3.93e13
-# tools/ubench_sustain.hip (profiles/r03_ubench_sustain.txt): the same multiply-add loop SUSTAINED (7-28 ms launches back to back for 0.2 s).
-# The rate depends on the DATA: 1.71 ns per wave-instruction per SIMD with the near-constant operands of ubench_mad, 2.06 ns with random
-# 28-bit factors that change every instruction at 2 waves per SIMD, 1.90 ns at 8 waves -- the board slows a stream the more its multipliers
-# toggle (sensors: 290 W of 1400 W, a reported 2402 MHz all along). Field elements ARE random limbs, so this is the kernel's ceiling.
-INT_MAD_NS_RANDOM_2_WAVES = 2.057e-9
-INT_MAD_NS_RANDOM_8_WAVES = 1.898e-9
+# tools/ubench_sustain.hip (profiles/r03_ubench_sustain.txt): the same multiply-add loop SUSTAINED (7-28 ms launches back to back), every instruction 8-byte
+# aligned. The rate depends on the DATA, not on the occupancy: 1.70 ns per wave-instruction per SIMD with the near-constant operands of ubench_mad, 1.83 ns with
+# random 28-bit factors that change every instruction (the same at 1, 2, 4 and 8 waves per SIMD), 1.75 ns for the kernel's own mix (13 multiply-adds, a 64-bit
+# shift, a mask and a 32-bit multiply per 16), +2.4 % with one random table row per 4096 instructions per lane out of HBM -- on the box where the kernel itself ran
+# 1.93-1.96 ns per instruction; another box gave 2.04-2.09 ns for the random stream. Field elements ARE random limbs, so this is the kernel's ceiling.
+INT_MAD_NS_RANDOM = 1.832e-9
 VALU_PER_MIXED_ADD = {"k_direct_accumulate_asm": 4256, "k_direct_accumulate": 4814}   # tools/gen_direct_asm.py --mix; SQ_INSTS_VALU of the compiler's schedule
 GATHER_PEAK_ROWS = 1.31e10                       # tools/gather_bench.hip on MI355X: random 112-byte rows/s out of a 128-200 GiB table
 
@@ -176,16 +176,16 @@ def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launc
                           "(table far larger than every cache); ceiling measured by tools/gather_bench.hip"}
     mads_per_launch = msms_per_launch * adds_per_msm * MADS_PER_MIXED_ADD
     mad_rate = mads_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
-    sustained = {"peak_sustained_random_operands_Gmad_per_s": 256 * 4 * 64 / INT_MAD_NS_RANDOM_8_WAVES / 1e9,
-                 "frac_of_sustained_random_operands": mad_rate / (256 * 4 * 64 / INT_MAD_NS_RANDOM_8_WAVES),
-                 "peak_sustained_random_operands_note": "tools/ubench_sustain.hip (profiles/r03_ubench_sustain.txt): a pure v_mad_u64_u32 stream whose two factors are random "
-                                                        "28-bit values and change with every instruction, held for 0.2 s, 8 waves per SIMD: 1.90 ns per wave-instruction per "
-                                                        "SIMD (2.06 ns at the 2 waves per SIMD the accumulation's registers allow; 1.71 ns with near-constant operands: the "
-                                                        "board slows a multiplier stream with its switching activity)"}
+    sustained = {"peak_sustained_random_operands_Gmad_per_s": 256 * 4 * 64 / INT_MAD_NS_RANDOM / 1e9,
+                 "frac_of_sustained_random_operands": mad_rate / (256 * 4 * 64 / INT_MAD_NS_RANDOM),
+                 "peak_sustained_random_operands_note": "tools/ubench_sustain.hip (profiles/r03_ubench_sustain.txt): a pure v_mad_u64_u32 stream, 8-byte aligned, whose two factors "
+                                                        "are random 28-bit values and change with every instruction, held for 0.3 s: 1.83 ns per wave-instruction per SIMD at any "
+                                                        "occupancy (1.70 ns with near-constant operands: the board slows busy multipliers; 2.00 ns at two waves per SIMD when the "
+                                                        "instructions sit at 4 mod 8), on a box where this kernel ran 8.42-8.55 ms; boxes differ by several per cent on both"}
     if dom in VALU_PER_MIXED_ADD and avg_ms > 0:
         valu_rate = msms_per_launch * adds_per_msm * VALU_PER_MIXED_ADD[dom] / (avg_ms * 1e-3)
         sustained["valu_instructions_per_mixed_addition"] = VALU_PER_MIXED_ADD[dom]
-        sustained["valu_instruction_rate_frac_of_a_pure_random_mad_stream_at_2_waves_per_simd"] = valu_rate / (256 * 4 * 64 / INT_MAD_NS_RANDOM_2_WAVES)
+        sustained["valu_instruction_rate_frac_of_a_pure_random_mad_stream"] = valu_rate / (256 * 4 * 64 / INT_MAD_NS_RANDOM)
     return {
         "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
@@ -205,7 +205,8 @@ def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launc
                     "peak_at_kernel_occupancy_and_clock_Gmad_per_s": 256 * 4 * 64 / INT_MAD_CYCLES_2_WAVES * KERNEL_CLOCK_HZ / 1e9,
                     "frac_at_kernel_occupancy_and_clock": mad_rate / (256 * 4 * 64 / INT_MAD_CYCLES_2_WAVES * KERNEL_CLOCK_HZ),
                     "peak_at_kernel_occupancy_and_clock_note": "the same micro-benchmark with 2 waves per SIMD (all that 204 VGPRs allow: 4.63 cycles) "
-                                                               "at the ~2.05 GHz effective the board holds under this kernel (GRBM_GUI_ACTIVE / launch time)",
+                                                               "at the ~2.05 GHz effective the board holds under this kernel (GRBM_GUI_ACTIVE / launch time). Round 3 found that micro-benchmark's loops were not "
+                                                               "alignment-controlled (multiply-adds at 4 mod 8 make the rate occupancy-dependent): peak_sustained_random_operands is the measured ceiling",
                     "peak_theoretical_Gmad_per_s": INT_MAD_PEAK_THEORETICAL / 1e9,
                     "peak_theoretical_note": "256 CUs x 4 SIMDs x 64 lanes / 4 cycles per wave-instruction at the 2.4 GHz maximum clock; "
                                              "the kernel holds 1.99-2.08 GHz (GRBM_GUI_ACTIVE, profiles/r02_pmc_*)",

@@ -49,10 +49,10 @@ def test_headline_roofline_object_from_a_known_kernel_clock():
     assert abs(im["achieved_Gmad_per_s"] - rate / 1e9) < 1e-3
     assert abs(im["frac_of_theoretical"] - rate / (256 * 4 * 64 / 4 * 2.4e9)) < 1e-9
     # the measured ceilings: a pure multiply-add stream on random 28-bit operands (profiles/r03_ubench_sustain.txt)
-    assert abs(im["peak_sustained_random_operands_Gmad_per_s"] - 65536 / 1.898e-9 / 1e9) < 1e-6
-    assert 0.70 < im["frac_of_sustained_random_operands"] < 0.85
+    assert abs(im["peak_sustained_random_operands_Gmad_per_s"] - 65536 / 1.832e-9 / 1e9) < 1e-6
+    assert 0.68 < im["frac_of_sustained_random_operands"] < 0.80
     assert im["valu_instructions_per_mixed_addition"] == 4256
-    assert 0.97 < im["valu_instruction_rate_frac_of_a_pure_random_mad_stream_at_2_waves_per_simd"] < 1.01
+    assert 0.86 < im["valu_instruction_rate_frac_of_a_pure_random_mad_stream"] < 0.92
     g = r["gather"]
     assert abs(g["rows_per_launch"] - adds) < 1.0 and g["bytes_per_launch"] == g["rows_per_launch"] * 112
 

@@ -31,7 +31,7 @@
 
 __global__ __launch_bounds__(256) void k_plain(uint32_t *out, uint32_t seed, uint32_t iters) {
     uint32_t a = seed ^ threadIdx.x, b = (seed * 2654435761u) | 1u, r;
-    asm volatile(INIT "s_mov_b32 s20, %3\n1:\n" BODY4096 "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI
+    asm volatile(INIT "s_mov_b32 s20, %3\n1:\n.p2align 3\n" BODY4096 "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI
                  : "=&v"(r) : "v"(a), "v"(b), "s"(iters) : CLOB, PAD_CLOB);
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
@@ -72,18 +72,20 @@ __global__ __launch_bounds__(256) void k_plain(uint32_t *out, uint32_t seed, uin
             M("v[16:17]", "v40", "v48") M("v[18:19]", "v40", "v48") M("v[20:21]", "v40", "v48") M("v[22:23]", "v40", "v48")
 #define X4(B) B B B B
 #define X256(B) X4(X4(X4(X4(B))))
-#define DATA_KERNEL(NAME, B16) DATA_KERNEL_C(NAME, B16, CLOB16)
-#define DATA_KERNEL_C(NAME, B16, CL)                                                                                              \
+#define DATA_KERNEL(NAME, B16) DATA_KERNEL_C(NAME, B16, CLOB16, "")
+#define DATA_KERNEL_C(NAME, B16, CL, MIS)                                                                                              \
     __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift) {            \
         uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;                                          \
-        asm volatile(INIT16 "s_mov_b32 s20, %3\n1:\n" X256(B16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI \
+        asm volatile(INIT16 "s_mov_b32 s20, %3\n1:\n.p2align 3\n" MIS X256(B16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI \
                      : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift) : CL);                     \
         out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                     \
     }
 DATA_KERNEL(k_varied, V16)
 DATA_KERNEL(k_one_fixed, F16)
 DATA_KERNEL(k_same, S16)
-DATA_KERNEL_C(k_varied_small, V16, CLOB16_NOPAD)   // 56 registers: up to eight waves per SIMD
+DATA_KERNEL_C(k_varied_small, V16, CLOB16_NOPAD, "")
+DATA_KERNEL_C(k_varied_mis, V16, CLOB16, "s_nop 0\n")                // every multiply-add at 4 mod 8: one in eight straddles a 64-byte line
+DATA_KERNEL_C(k_varied_small_mis, V16, CLOB16_NOPAD, "s_nop 0\n")   // 56 registers: up to eight waves per SIMD
 
 // the random-operand stream WITH the accumulation's memory pattern: one random 112-byte row per 4096 instructions per lane, used one body later
 __global__ __launch_bounds__(256) void k_varied_gather(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift, const uint8_t *table, uint32_t row_mask) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void k_varied_gather(uint32_t *out, uint32_t s
                  "global_load_dwordx4 v[76:79], v[60:61], off offset:48\n"
                  "global_load_dwordx4 v[80:83], v[60:61], off offset:64\n"
                  "global_load_dwordx4 v[84:87], v[60:61], off offset:80\n"
-                 "global_load_dwordx4 v[88:91], v[60:61], off offset:96\n"
+                 "global_load_dwordx4 v[88:91], v[60:61], off offset:96\n.p2align 3\n"
                  X256(V16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n"
                  "v_xor_b32 v8, v8, v64\n" FINI
                  : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift), "v"((uint64_t)table), "s"(row_mask)
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void k_varied_gather(uint32_t *out, uint32_t s
 #define STREAM_KERNEL(NAME, PRE, B16)                                                                                       \
     __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift) {            \
         uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;                                          \
-        asm volatile(INIT16 PRE "s_mov_b32 s20, %3\n1:\n s_nop 15\n" X256(B16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI \
+        asm volatile(INIT16 PRE "s_mov_b32 s20, %3\n1:\n s_nop 15\n.p2align 3\n" X256(B16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n" FINI \
                      : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift) : CLOB16, SCLOB);              \
         out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                     \
     }
@@ -152,7 +154,7 @@ STREAM_KERNEL(k_s_chain2, "", C2_16)
     __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift, const uint8_t *table, uint32_t row_mask) { \
         uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = 0, r;                                                                 \
         asm volatile(INIT16 "v_mov_b32 v56, %1\n v_lshrrev_b64 v[60:61], 0, %6\n"                                                         \
-                     "s_mov_b32 s20, %3\n1:\n" EXTRA BODYX "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n" FINI \
+                     "s_mov_b32 s20, %3\n1:\n" EXTRA ".p2align 3\n" BODYX "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n" FINI \
                      : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift), "v"((uint64_t)table), "s"(row_mask)                      \
                      : CLOB16, "v56", "v57", "v58", "v60", "v61", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", \
                        "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");                                 \
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t *out, uint32_t seed, ui
                  "global_load_dwordx4 v[72:75], v[54:55], off offset:48\n"
                  "global_load_dwordx4 v[76:79], v[54:55], off offset:64\n"
                  "global_load_dwordx4 v[80:83], v[54:55], off offset:80\n"
-                 "global_load_dwordx4 v[84:87], v[54:55], off offset:96\n"
+                 "global_load_dwordx4 v[84:87], v[54:55], off offset:96\n.p2align 3\n"
                  BODY4096 "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n" FINI
                  : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "v"((uint64_t)table), "s"(row_mask), "v"(lcg), "s"(747796405u)
                  : CLOB, PAD_CLOB, "v50", "v51", "v52", "v54", "v55", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72",
@@ -254,7 +256,8 @@ int main(int argc, char **argv) {
     struct { const char *name; void (*k)(uint32_t *, uint32_t, uint32_t, uint32_t); uint32_t shift; } dk[] = {
         {"same two factors, random 28-bit contents", k_same, 4}, {"one factor fixed for 8 instructions, random 28-bit", k_one_fixed, 4},
         {"both factors change every instruction, random 28-bit", k_varied, 4}, {"both factors change every instruction, random 32-bit", k_varied, 0},
-        {"both factors change every instruction, 8-bit contents", k_varied, 24}};
+        {"both factors change every instruction, 8-bit contents", k_varied, 24},
+        {"both factors change every instruction, random 28-bit, every multiply-add at 4 mod 8", k_varied_mis, 4}};
     for (int pass = 0; pass < passes; pass++)
         for (auto &d : dk) {
             uint32_t iters = 1024;  // ~7 ms per launch
@@ -336,12 +339,13 @@ int main(int argc, char **argv) {
             }
         }
     for (int pass = 0; pass < passes; pass++)
+      for (int mis = 0; mis < 2; mis++)
         for (int w : {1, 2, 4, 8}) {
             uint32_t iters = 2048 / w;   // the same 8.39e6 wave-instructions per SIMD per launch at every occupancy
             int launches = quick ? 6 : 14;
             for (int rep = 0; rep < 2; rep++) {
                 CHECK(hipEventRecord(e0, st));
-                for (int l = 0; l < launches; l++) hipLaunchKernelGGL(k_varied_small, dim3(n_cu * w), dim3(256), 0, st, d_out, 12345u + l, iters, 4u);
+                for (int l = 0; l < launches; l++) hipLaunchKernelGGL(mis ? k_varied_small_mis : k_varied_small, dim3(n_cu * w), dim3(256), 0, st, d_out, 12345u + l, iters, 4u);
                 CHECK(hipEventRecord(e1, st));
                 CHECK(hipEventSynchronize(e1));
                 float ms;
@@ -349,7 +353,7 @@ int main(int argc, char **argv) {
                 double per_launch = ms / launches;
                 double ns = per_launch * 1e6 / ((double)iters * 4096 * w);
                 if (rep == 1)
-                    printf("{\"stream\": \"both factors change every instruction, random 28-bit, %d waves per SIMD\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n", w, per_launch, ns, ns * 2.4);
+                    printf("{\"stream\": \"both factors change every instruction, random 28-bit, %s, %d waves per SIMD\", \"ms_per_launch\": %.3f, \"ns_per_wave_instruction_per_simd\": %.4f, \"cycles_at_2.4GHz\": %.3f}\n", mis ? "at 4 mod 8" : "8-byte aligned", w, per_launch, ns, ns * 2.4);
             }
         }
     return 0;
