@@ -176,6 +176,39 @@ EXTRA_KERNEL(k_x_load1_per1024, X64(V16), ONE_LOAD_SAME)
 EXTRA_KERNEL(k_x_sleep_per1024, X64(V16), SLEEP1)
 EXTRA_KERNEL(k_x_none, X256(V16), "")
 
+// the random-operand stream with the ACCUMULATION's address pattern: iteration t of every workgroup reads window (t mod 8) of a table laid out as 8 windows x 4096 points x 32768
+// rows of 128 bytes; lane l of a workgroup owns point l + 256 (t / 8 mod 16), so a wave's 64 rows lie 4 MB apart and all workgroups walk the windows in lockstep
+__global__ __launch_bounds__(256) void k_varied_gather_kernel_pattern(uint32_t *out, uint32_t seed, uint32_t iters, uint32_t shift, const uint8_t *table, uint32_t unused) {
+    uint32_t a = (seed ^ (threadIdx.x * 2246822519u)) * 3266489917u, b = threadIdx.x, r;
+    asm volatile(INIT16
+                 "v_mov_b32 v56, %1\n v_mov_b32 v59, %2\n s_mov_b32 s21, 0\n"
+                 "s_mov_b32 s20, %3\n1:\n"
+                 "s_waitcnt vmcnt(0)\n"
+                 "v_mul_lo_u32 v56, v56, %4\n v_add_u32 v56, 0x9e3779b9, v56\n"
+                 "v_lshrrev_b32 v57, 17, v56\n"                                /* 15 random bits: the row within (window, point) */
+                 "s_lshr_b32 s22, s21, 3\n s_and_b32 s22, s22, 15\n s_lshl_b32 s22, s22, 8\n"
+                 "v_add_u32 v58, s22, v59\n"                                     /* point = lane + 256 (t / 8 mod 16) */
+                 "v_lshl_add_u32 v57, v58, 15, v57\n"                            /* row index within the window */
+                 "s_and_b32 s22, s21, 7\n s_lshl_b32 s23, s22, 2\n s_mov_b32 s22, 0\n"   /* window t mod 8 at 2^34 bytes: high word 4 (t mod 8) */
+                 "v_mov_b32 v58, 128\n"
+                 "v_mad_u64_u32 v[60:61], vcc, v57, v58, %6\n"
+                 "v_add_u32 v61, s23, v61\n"
+                 "s_add_u32 s21, s21, 1\n"
+                 "global_load_dwordx4 v[64:67], v[60:61], off\n"
+                 "global_load_dwordx4 v[68:71], v[60:61], off offset:16\n"
+                 "global_load_dwordx4 v[72:75], v[60:61], off offset:32\n"
+                 "global_load_dwordx4 v[76:79], v[60:61], off offset:48\n"
+                 "global_load_dwordx4 v[80:83], v[60:61], off offset:64\n"
+                 "global_load_dwordx4 v[84:87], v[60:61], off offset:80\n"
+                 "global_load_dwordx4 v[88:91], v[60:61], off offset:96\n.p2align 3\n"
+                 X256(V16) "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\ns_waitcnt vmcnt(0)\n"
+                 "v_xor_b32 v8, v8, v64\n" FINI
+                 : "=&v"(r) : "v"(a), "v"(b), "s"(iters), "s"(747796405u), "s"(shift), "v"((uint64_t)table), "s"(unused)
+                 : CLOB16, "s21", "s22", "s23", "v56", "v57", "v58", "v59", "v60", "v61", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
+                   "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 // one random row per 4096 multiply-adds: address = base + (lcg >> shift) * 128; loads issued at the head of a body, waited at the head of the next
 __global__ __launch_bounds__(256) void k_gather(uint32_t *out, uint32_t seed, uint32_t iters, const uint8_t *table, uint32_t row_mask) {
     uint32_t a = seed ^ threadIdx.x, b = (seed * 2654435761u) | 1u, r;
@@ -203,12 +236,24 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t *out, uint32_t seed, ui
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+__global__ void k_fill_random(uint4 *p, size_t n16) {   // what a table of field elements looks like to the memory system: no two words alike
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) {
+        uint64_t x = i * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
+        x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 32;
+        uint64_t y = x * 0x94d049bb133111ebull; y ^= y >> 31;
+        p[i] = make_uint4((uint32_t)x & 0xfffffff, (uint32_t)(x >> 32) & 0xfffffff, (uint32_t)y & 0xfffffff, (uint32_t)(y >> 32) & 0xfffffff);
+    }
+}
+
 int main(int argc, char **argv) {
     double gb = 128;
+    bool random_table = false;   // --random-table: the gathered table holds random 28-bit words (as the real one does) instead of one repeated byte
     bool quick = false;   // --quick: one size of launch (8.39e6 wave-instructions per SIMD each), six launches per stream: for a rocprofv3 --pmc pass
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--gb") && i + 1 < argc) gb = atof(argv[i + 1]);
         if (!strcmp(argv[i], "--quick")) quick = true;
+        if (!strcmp(argv[i], "--random-table")) random_table = true;
     }
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -220,6 +265,11 @@ int main(int argc, char **argv) {
     uint8_t *table;
     CHECK(hipMalloc(&table, rows * 128));
     CHECK(hipMemset(table, 1, rows * 128));
+    if (random_table) {
+        hipLaunchKernelGGL(k_fill_random, dim3(8192), dim3(256), 0, 0, (uint4 *)table, rows * 8);
+        CHECK(hipDeviceSynchronize());
+    }
+    printf("table contents: %s\n", random_table ? "random 28-bit words" : "the byte 0x01 throughout");
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -278,7 +328,7 @@ int main(int argc, char **argv) {
     {   // the random-operand stream with one random row per 4096 instructions per lane out of regions of different sizes (the whole table; one 17 GB
         // window's worth; what the memory-side cache holds; what an L2 holds), against the stream with a pause instead of the loads
         struct { const char *name; uint32_t mask; } gm[] = {{"no loads (s_nop 15 per 4096)", 0}, {"rows out of the whole 137 GB", (uint32_t)(rows - 1)},
-            {"rows out of 17 GB", (1u << 27) - 1}, {"rows out of 268 MB", (1u << 21) - 1}, {"rows out of 1 MB", (1u << 13) - 1}};
+            {"rows out of 17 GB", (1u << 27) - 1}, {"the accumulation's pattern (8 windows in lockstep, a wave's rows 4 MB apart)", 0xffffffffu}, {"rows out of 268 MB", (1u << 21) - 1}, {"rows out of 1 MB", (1u << 13) - 1}};
         for (int pass = 0; pass < 2 * passes; pass++)
             for (auto &g : gm) {
                 uint32_t iters = 1024;
@@ -286,7 +336,8 @@ int main(int argc, char **argv) {
                 for (int rep = 0; rep < 2; rep++) {
                     CHECK(hipEventRecord(e0, st));
                     for (int l = 0; l < launches; l++) {
-                        if (g.mask) hipLaunchKernelGGL(k_varied_gather, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, 4u, table, g.mask);
+                        if (g.mask == 0xffffffffu) hipLaunchKernelGGL(k_varied_gather_kernel_pattern, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, 4u, table, 0u);
+                        else if (g.mask) hipLaunchKernelGGL(k_varied_gather, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, 4u, table, g.mask);
                         else hipLaunchKernelGGL(k_x_nop, dim3(grid), dim3(256), 0, st, d_out, 12345u + l, iters, 4u, table, (uint32_t)(rows - 1));
                     }
                     CHECK(hipEventRecord(e1, st));
