@@ -323,6 +323,7 @@ def _chain(pairs, square, out, m, acc, tmp, wide=False):
     if KNOB_SDST and acc[0] == ACC3[0]:
         sink = sp(sTMP)
 
+    # (the modulus limb goes FIRST: a scalar register as the first source of v_mad_u64_u32 runs 3 % faster than as the second, tools/ubench_sustain.hip)
     def mad(x, y):
         ins.append(("v_mad_u64_u32", (A, sink, x, y, lit(0) if first[0] else A), {}))
         first[0] = False
@@ -343,18 +344,18 @@ def _chain(pairs, square, out, m, acc, tmp, wide=False):
     for k in range(14):
         column(k)
         for i in range(k):
-            mad(v(m[i]), s(sMOD[k - i]))
+            mad(s(sMOD[k - i]), v(m[i]))
         if wide:
             ins.append(("v_mul_lo_u32", (v(m[k]), v(acc[0]), s(sINV)), {}))
         else:
             ins.append(("v_mul_lo_u32", (v(tmp), v(acc[0]), s(sINV)), {}))
             ins.append(("v_and_b32", (v(m[k]), s(sMASK), v(tmp)), {}))
-        mad(v(m[k]), s(sMOD[0]))
+        mad(s(sMOD[0]), v(m[k]))
         ins.append(("v_lshrrev_b64", (A, lit(W), A), {}))
     for k in range(14, 27):
         column(k)
         for i in range(k - 13, 14):
-            mad(v(m[i]), s(sMOD[k - i]))
+            mad(s(sMOD[k - i]), v(m[i]))
         ins.append(("v_and_b32", (v(out[k - 14]), s(sMASK), v(acc[0])), {}))
         if k < 26:
             ins.append(("v_lshrrev_b64", (A, lit(W), A), {}))

@@ -119,6 +119,15 @@ __global__ __launch_bounds__(256) void k_varied_gather(uint32_t *out, uint32_t s
              M("v[16:17]", "v44", "s44") M("v[18:19]", "v45", "s45") M("v[20:21]", "v46", "s46") M("v[22:23]", "v47", "s47") \
              M("v[8:9]", "v48", "s47") M("v[10:11]", "v49", "s46") M("v[12:13]", "v50", "s45") M("v[14:15]", "v51", "s44") \
              M("v[16:17]", "v52", "s43") M("v[18:19]", "v53", "s42") M("v[20:21]", "v54", "s41") M("v[22:23]", "v55", "s40")
+#define SG16_SRC0 M("v[8:9]", "s40", "v40") M("v[10:11]", "s41", "v41") M("v[12:13]", "s42", "v42") M("v[14:15]", "s43", "v43") \
+             M("v[16:17]", "s44", "v44") M("v[18:19]", "s45", "v45") M("v[20:21]", "s46", "v46") M("v[22:23]", "s47", "v47") \
+             M("v[8:9]", "s47", "v48") M("v[10:11]", "s46", "v49") M("v[12:13]", "s45", "v50") M("v[14:15]", "s44", "v51") \
+             M("v[16:17]", "s43", "v52") M("v[18:19]", "s42", "v53") M("v[20:21]", "s41", "v54") M("v[22:23]", "s40", "v55")
+// one factor kept for eight instructions, as the FIRST source or as the second
+#define F16_SRC1 M("v[8:9]", "v48", "v40") M("v[10:11]", "v49", "v40") M("v[12:13]", "v50", "v40") M("v[14:15]", "v51", "v40") \
+            M("v[16:17]", "v52", "v40") M("v[18:19]", "v53", "v40") M("v[20:21]", "v54", "v40") M("v[22:23]", "v55", "v40") \
+            M("v[8:9]", "v48", "v41") M("v[10:11]", "v49", "v41") M("v[12:13]", "v50", "v41") M("v[14:15]", "v51", "v41") \
+            M("v[16:17]", "v52", "v41") M("v[18:19]", "v53", "v41") M("v[20:21]", "v54", "v41") M("v[22:23]", "v55", "v41")
 #define SGINIT "v_readfirstlane_b32 s40, v48\n v_readfirstlane_b32 s41, v49\n v_readfirstlane_b32 s42, v50\n v_readfirstlane_b32 s43, v51\n" \
                "v_readfirstlane_b32 s44, v52\n v_readfirstlane_b32 s45, v53\n v_readfirstlane_b32 s46, v54\n v_readfirstlane_b32 s47, v55\n"
 // the kernel's mix: 13 multiply-adds, one 64-bit shift, one mask, one 32-bit multiply per 16
@@ -143,6 +152,9 @@ __global__ __launch_bounds__(256) void k_varied_gather(uint32_t *out, uint32_t s
     }
 STREAM_KERNEL(k_s_base, "", V16)
 STREAM_KERNEL(k_s_sgpr, SGINIT, SG16)
+STREAM_KERNEL(k_s_sgpr_src0, SGINIT, SG16_SRC0)
+STREAM_KERNEL(k_s_fixed_src0, "", F16)
+STREAM_KERNEL(k_s_fixed_src1, "", F16_SRC1)
 STREAM_KERNEL(k_s_mix, "", MIX16)
 STREAM_KERNEL(k_s_chain3, "", C3_16)
 STREAM_KERNEL(k_s_chain2, "", C2_16)
@@ -351,7 +363,8 @@ int main(int argc, char **argv) {
             }
     }
     struct { const char *name; void (*k)(uint32_t *, uint32_t, uint32_t, uint32_t); } sk[] = {
-        {"eight accumulators, both factors vector registers", k_s_base}, {"one factor from scalar registers", k_s_sgpr},
+        {"eight accumulators, both factors vector registers", k_s_base}, {"one factor from scalar registers (second source)", k_s_sgpr}, {"one factor from scalar registers (first source)", k_s_sgpr_src0},
+        {"one factor kept for 8 instructions, first source", k_s_fixed_src0}, {"one factor kept for 8 instructions, second source", k_s_fixed_src1},
         {"13 multiply-adds + 64-bit shift + mask + 32-bit multiply per 16", k_s_mix}, {"three interleaved dependent chains", k_s_chain3},
         {"two interleaved dependent chains", k_s_chain2}, {"eight accumulators (again)", k_s_base}};
     for (int pass = 0; pass < passes; pass++)
