@@ -8,7 +8,10 @@ A "step" is one pass of the hot path (blob bytes -> 48-byte commitments: parse, 
 of synthetic 4096-element blobs that is already resident in HBM. Each GPU works on its own shard (weak scaling: 1024
 blobs per GPU per step); the only collective is the one broadcast of the prepared trusted setup before the timed region.
 
-Rank 0 prints ONE JSON line. Besides the contract's fields it carries
+Rank 0 prints ONE JSON line of at most 8,000 bytes (compact_line below: the contract's fields first, numbers only, no prose --
+the driver keeps a bounded tail of stdout and round 3's 21 KB line lost its head there) and writes everything else -- every
+note, breakdown and per-kernel table -- to bench_detail.json beside this file (path on stderr; LWKZG_BENCH_DETAIL overrides).
+`python bench.py --gpus N` without a launcher starts its N ranks itself (spawn_ranks). The detail file carries
   roofline        the dominant kernel (k_direct_accumulate / k_bucket_accumulate) priced against HBM as the north star
                   mandates AND the integer-multiply picture, because the kernel is integer-ALU bound (DESIGN.md section 4);
                   `traffic` comes from committed PMC passes and says so in `traffic_source`;
@@ -299,8 +302,9 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         return {"workload": "BASELINE configs[1] as a pipelined producer issues it: batch=%d device-resident blobs per call, consecutive calls alternate "
                             "between two caller streams, so the latency-shaped tail of one call (lane fold, inversion) runs beside the next call's accumulation" % n,
                 "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
+    # every single-stream leg runs before either two-stream leg: the second caller stream creates the settings' twin context
+    # (the library now picks the two-stream geometry only while the other context is busy, engine.hip: peer_busy)
     leg("blob_proof_b256", blob_proof(1))
-    leg("blob_proof_b256_two_streams", blob_proof(2))
 
     def commit_prove():
         d_c2 = torch.empty(48 * nb, dtype=torch.uint8, device=dev)
@@ -379,8 +383,137 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                              "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms,
                              "launches_per_step": lps, "traffic": None}}
     leg("tiled_msm_2_pow_20", tiled_msm)
+    leg("blob_proof_b256_two_streams", blob_proof(2))
     leg("commit_b1024_two_streams", commit_two_streams)
+
+    def commit_after_two_streams():
+        # the headline's call again, on ONE stream, after the twin context exists: must be the single-stream geometry again
+        n = BLOBS_PER_GPU
+        d_b = dev_bytes(B.synthetic_batch(0, n))
+        d_o = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+        d_s = torch.zeros(n, dtype=torch.int32, device=dev)
+        steps = 10
+        el, kern = region(lambda: K.blob_to_kzg_commitment_batch_device(d_o.data_ptr(), d_b.data_ptr(), n, ts, stream, d_s.data_ptr()), steps, 3)
+        assert int(d_s.abs().sum().item()) == 0
+        return {"workload": "BASELINE configs[1] once more on ONE caller stream after the two-stream legs (the twin context exists and is idle)",
+                "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern}
+    leg("commit_b1024_one_stream_after_twin", commit_after_two_streams)
     return out
+
+LINE_LIMIT = 8000            # bytes of the one stdout line (the driver keeps a bounded tail of stdout)
+
+
+def _round(x, sig=6):
+    """floats to `sig` significant digits, recursively (the line is read by a parser, not by a person)"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _round(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _dominant(kernels):
+    """(name, avg ms) of the kernel a leg spent most of its time in"""
+    if not kernels:
+        return None, None
+    name = max(kernels, key=lambda k: kernels[k].get("avg_ms", 0.0) * kernels[k].get("launches", 1))
+    return name, kernels[name].get("avg_ms")
+
+
+def _roof_compact(r):
+    out = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step"))
+    out.setdefault("traffic", None)
+    if r.get("traffic_source"):
+        out["traffic_source"] = r["traffic_source"].split(":")[0][:80]
+    if isinstance(r.get("int_mad"), dict):
+        out["int_mad"] = _pick(r["int_mad"], ("achieved_Gmad_per_s", "peak_theoretical_Gmad_per_s", "frac_of_theoretical", "frac_whole_step"))
+    return out
+
+
+def _leg_compact(l):
+    if not isinstance(l, dict):
+        return l
+    if "error" in l:
+        return {"error": str(l["error"])[:120]}
+    out = _pick(l, ("value", "unit", "ms_per_step", "steps"))
+    name, ms = _dominant(l.get("kernels"))
+    if name:
+        out["kernel"], out["kernel_ms"] = name, ms
+    for sub in ("ntt_roofline", "roofline"):
+        if isinstance(l.get(sub), dict):
+            out[sub] = _pick(l[sub], ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "traffic"))
+            if isinstance(l[sub].get("int_mad"), dict):
+                out[sub]["int_mad_frac_of_theoretical"] = l[sub]["int_mad"].get("frac_of_theoretical")
+    return out
+
+
+def compact_line(res, detail_path=None):
+    """The ONE stdout line: the contract's fields first, then one small object per engine and per leg. Numbers only; every note,
+    breakdown and per-kernel table stays in the detail file. Pure function of the detail dictionary (tests/test_bench_accounting_cpu.py
+    runs it on committed detail files and on a synthetic worst case and asserts the size and the keys)."""
+    line = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(res.get("config", {}), ("workload", "blobs_per_gpu_per_step", "caller_streams", "scalars", "direct_bits",
+                                                    "direct_bits_min_over_ranks", "mode", "op", "parallelism"))
+    line["roofline"] = _roof_compact(res.get("roofline", {}))
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "value_without_srs_rebuild", "single_thread_ops_per_s",
+                                          "single_thread_ops_per_s_without_srs_rebuild", "srs_rebuild_ms_per_call", "gpu_outputs_match_oracle"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    line["kernels_avg_ms"] = {k: v.get("avg_ms") for k, v in (res.get("kernels") or {}).items()}
+    for eng in ("default_engine", "bucket_engine"):
+        e = res.get(eng)
+        if isinstance(e, dict):
+            line[eng] = _pick(e, ("value", "unit", "ms_per_step", "table_bytes"))
+            line[eng]["bits"] = e.get("direct_bits")
+            r = e.get("roofline") or {}
+            line[eng]["kernel"], line[eng]["kernel_ms"] = r.get("kernel"), r.get("avg_launch_ms")
+            line[eng]["int_mad_frac_of_theoretical"] = (r.get("int_mad") or {}).get("frac_of_theoretical")
+            line[eng]["frac"] = r.get("frac")
+    if isinstance(res.get("host_abi"), dict):
+        line["host_abi"] = _pick(res["host_abi"], ("value", "unit", "ms_per_call_median", "blobs_per_call"))
+    if isinstance(res.get("configs"), dict):
+        line["configs"] = {k: _leg_compact(v) for k, v in res["configs"].items()}
+    line["dist"] = _pick(res.get("dist") or {}, ("initialised", "backend", "ranks", "nccl_version"))
+    line.update(_pick(res, ("msm_path", "hip_first_use_init_s", "setup_load_s", "direct_table_build_s", "direct_table_build_s_max_over_ranks")))
+    if detail_path:
+        line["detail"] = detail_path
+    line = _round(line)
+    text = json.dumps(line, separators=(",", ":"))
+    # belt and braces: whatever a future field does, the contract's head of the line survives
+    for drop in ("kernels_avg_ms", "host_abi", "configs", "bucket_engine", "default_engine", "dist"):
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        line["dropped_for_size"] = line.get("dropped_for_size", []) + [drop]
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes through torch.distributed.run --
+    BEFORE this process has touched the GPU (nothing has imported torch yet) -- relay their stdout (rank 0's one line) and exit with
+    their return code. The launcher form (WORLD_SIZE / RANK in the environment) never comes here."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: no launcher in the environment, starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -421,6 +554,8 @@ def main():
     args = ap.parse_args()
     if args.op == "commit_prove" and args.caller_streams > 1:
         ap.error("--op commit_prove runs on one caller stream")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 meanwhile (RCCL
     # prints a version banner there when its first communicator comes up) goes to stderr
@@ -441,8 +576,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     dev_index = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a real N-GPU node
     torch.cuda.set_device(dev_index)
@@ -709,7 +842,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.op == "tiled_msm" else "weak",
             "vs_baseline": None,
-            "dtype": "u32 limbs (381-bit Fp / 255-bit Fr Montgomery, integer)",
+            "dtype": "u32",
+            "dtype_note": "28-bit limbs in 32-bit registers, 64-bit column sums (v_mad_u64_u32): 381-bit Fp / 255-bit Fr Montgomery arithmetic, all integer",
             "data": "synthetic (SplitMix64 blobs, seed 0x4B5A47 + blob index; tau=1337 testing trusted setup)",
             "config": {"workload": {"commit": "BASELINE configs[1]: single-GPU 4096-scalar G1 MSM (blob -> commitment), batch=%d synthetic blobs "
                                              "per GPU per step, device-resident, bit-exact vs CPU",
@@ -754,8 +888,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mode == "reference" and args.scalars == "31byte":
             outs = bytes(d_out.cpu().numpy().tobytes()) if args.op == "commit" else b""
             res["cpu_baseline"] = cpu_baseline([outs[48 * i:48 * i + 48] for i in range(len(outs) // 48)], ts.g2_values_bytes())
+        detail_path = os.environ.get("LWKZG_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(res, f, indent=1)
+            print("bench.py: detail (notes, breakdowns, per-kernel tables) written to %s" % detail_path, file=sys.stderr)
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (detail_path, e), file=sys.stderr)
+            detail_path = None
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(res) + "\n").encode())
+        os.write(result_fd, (compact_line(res, os.path.relpath(detail_path, ROOT) if detail_path else None) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -243,6 +243,37 @@ size_t lwkzg_setup_image_bytes(void);
 C_KZG_RET lwkzg_setup_export_device(const KZGSettings *s, void *image_dev, void *stream);
 C_KZG_RET lwkzg_setup_import_device(KZGSettings *out, const void *image_dev);
 
+/* ONE process, SEVERAL GPUs (csrc/multi.hip): the node-level form of the batch entry points for the reference's own kind of caller
+ * -- plain C calls, /root/reference/fuzz/base_fuzz.h:17-34, src/lib.rs:253-283 -- which has no torch.distributed. lwkzg_multi_load*
+ * parses, validates and prepares the setup on devices[0] exactly as load_trusted_setup* does (src/lib.rs:709-802), delivers the
+ * 10.3 MB setup image to the other devices device-to-device (hipMemcpyPeer: xGMI on an MI355X node) and lets every device build
+ * its own MSM engine (all at once). The batch calls cut the batch into contiguous shards, blob k of n -> device floor(k G / n)
+ * (SURVEY 8e), run each shard through the single-device entry point above on a host thread of its own, and write the results
+ * in place: no reduction, no data-path collective. The batch verification is the reference's single check (ONE Fiat-Shamir r,
+ * ONE linear combination, ONE pairing; src/lib.rs:639-692) via the lwkzg_verify_shard_* steps below. Bytes equal to the
+ * single-device calls. A device ordinal may appear more than once (several contexts on one GPU: how the one-GPU tests run it).
+ * lwkzg_multi_settings(m, k) is the k-th device's KZGSettings, for everything that is per device (lwkzg_reserve, timing, ...). */
+typedef struct LwkzgMulti LwkzgMulti;
+C_KZG_RET lwkzg_multi_load(LwkzgMulti **out, const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices,
+                           size_t n_devices);
+C_KZG_RET lwkzg_multi_load_file(LwkzgMulti **out, FILE *in, const int *devices, size_t n_devices);
+void lwkzg_multi_free(LwkzgMulti *m);
+size_t lwkzg_multi_device_count(const LwkzgMulti *m);
+int lwkzg_multi_device(const LwkzgMulti *m, size_t k);                    /* ordinal of the k-th entry, -1 out of range */
+const KZGSettings *lwkzg_multi_settings(const LwkzgMulti *m, size_t k);  /* NULL out of range */
+C_KZG_RET lwkzg_multi_set_mode(const LwkzgMulti *m, int mode);           /* lwkzg_settings_set_mode on every device */
+C_KZG_RET lwkzg_multi_enable_direct_table(const LwkzgMulti *m, int window_bits); /* every device at once; first failure returned */
+C_KZG_RET lwkzg_multi_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const LwkzgMulti *m, size_t *first_bad);
+C_KZG_RET lwkzg_multi_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n, const LwkzgMulti *m,
+                                                   size_t *first_bad);
+C_KZG_RET lwkzg_multi_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, const Blob *blobs, const Bytes32 *zs, size_t n,
+                                              const LwkzgMulti *m, size_t *first_bad);
+C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments, const Bytes48 *proofs, size_t n,
+                                                  const LwkzgMulti *m);
+/* BASELINE configs[4] over the devices: out = sum_k scalars[k] * g1[k mod 4096], n_terms a positive multiple of 4096, HOST-resident
+ * big-endian scalars; whole tiles per device, one 48-byte partial sum back from each, added on the host. */
+C_KZG_RET lwkzg_multi_g1_msm_tiled(uint8_t out48[48], const uint8_t *scalars_be, size_t n_terms, const LwkzgMulti *m);
+
 /* verify_blob_kzg_proof_batch (src/lib.rs:525-692) for a batch SHARDED over several processes / GPUs, as the
  * reference computes it: ONE Fiat-Shamir scalar r over the whole batch (compute_r_powers, src/utils.rs:166-206), ONE
  * random linear combination, ONE pairing check. Rank k holds blobs [first_k, first_k + n_k) of the n_total:

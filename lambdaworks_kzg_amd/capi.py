@@ -51,6 +51,10 @@ EXPORTED_SYMBOLS = [
     "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
     "lwkzg_timing_report", "lwkzg_runtime_init",
+    "lwkzg_multi_load", "lwkzg_multi_load_file", "lwkzg_multi_free", "lwkzg_multi_device_count", "lwkzg_multi_device", "lwkzg_multi_settings",
+    "lwkzg_multi_set_mode", "lwkzg_multi_enable_direct_table", "lwkzg_multi_blob_to_kzg_commitment_batch",
+    "lwkzg_multi_compute_blob_kzg_proof_batch", "lwkzg_multi_compute_kzg_proof_batch", "lwkzg_multi_verify_blob_kzg_proof_batch",
+    "lwkzg_multi_g1_msm_tiled",
     "lwkzg_release_context", "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
 ]
 
@@ -119,6 +123,23 @@ def lib():
     l.lwkzg_challenge_digests_host.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz]
     l.lwkzg_g1_msm_tiled_device.argtypes = [vp, vp, sz, ps, vp]
     l.lwkzg_g1_sum_compressed.argtypes = [C.c_char_p, C.c_char_p, sz]
+    pi = C.POINTER(C.c_int)
+    l.lwkzg_multi_load.argtypes = [C.POINTER(vp), C.c_char_p, sz, C.c_char_p, sz, pi, sz]
+    l.lwkzg_multi_load_file.argtypes = [C.POINTER(vp), vp, pi, sz]
+    l.lwkzg_multi_free.argtypes = [vp]
+    l.lwkzg_multi_free.restype = None
+    l.lwkzg_multi_device_count.argtypes = [vp]
+    l.lwkzg_multi_device_count.restype = sz
+    l.lwkzg_multi_device.argtypes = [vp, sz]
+    l.lwkzg_multi_settings.argtypes = [vp, sz]
+    l.lwkzg_multi_settings.restype = ps
+    l.lwkzg_multi_set_mode.argtypes = [vp, ci]
+    l.lwkzg_multi_enable_direct_table.argtypes = [vp, ci]
+    l.lwkzg_multi_blob_to_kzg_commitment_batch.argtypes = [C.c_char_p, C.c_char_p, sz, vp, C.POINTER(sz)]
+    l.lwkzg_multi_compute_blob_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz, vp, C.POINTER(sz)]
+    l.lwkzg_multi_compute_kzg_proof_batch.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, vp, C.POINTER(sz)]
+    l.lwkzg_multi_verify_blob_kzg_proof_batch.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, C.c_char_p, sz, vp]
+    l.lwkzg_multi_g1_msm_tiled.argtypes = [C.c_char_p, C.c_char_p, sz, vp]
     _lib = l
     return l
 
@@ -258,6 +279,110 @@ class TrustedSetup:
         if self._loaded:
             lib().free_trusted_setup(C.byref(self.s))
             self._loaded = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _DeviceSettings:
+    """the k-th device's KZGSettings of a MultiSetup, usable wherever a TrustedSetup is (the MultiSetup owns it)"""
+
+    def __init__(self, ptr):
+        self._p = ptr
+
+    def ref(self):
+        return self._p
+
+
+class MultiSetup:
+    """One process, several GPUs (lwkzg_multi_*, csrc/multi.hip): the setup loaded once and delivered device-to-device, batches cut
+    into contiguous shards, one host thread per device, no reduction. `devices` may name a device more than once."""
+
+    def __init__(self, h):
+        self.h = h
+
+    @classmethod
+    def from_file(cls, path, devices):
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        fp = _libc.fopen(os.fsencode(path), b"r")
+        if not fp:
+            raise FileNotFoundError(path)
+        try:
+            _check("lwkzg_multi_load_file", lib().lwkzg_multi_load_file(C.byref(h), fp, arr, len(devices)))
+        finally:
+            _libc.fclose(fp)
+        return cls(h)
+
+    @classmethod
+    def from_bytes(cls, g1_bytes, g2_bytes, devices):
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check("lwkzg_multi_load", lib().lwkzg_multi_load(C.byref(h), g1_bytes, len(g1_bytes) // 48, g2_bytes, len(g2_bytes) // 96, arr, len(devices)))
+        return cls(h)
+
+    def device_count(self):
+        return lib().lwkzg_multi_device_count(self.h)
+
+    def devices(self):
+        return [lib().lwkzg_multi_device(self.h, k) for k in range(self.device_count())]
+
+    def settings(self, k):
+        p = lib().lwkzg_multi_settings(self.h, k)
+        if not p:
+            raise IndexError(k)
+        return _DeviceSettings(p)
+
+    def set_mode(self, mode):
+        _check("lwkzg_multi_set_mode", lib().lwkzg_multi_set_mode(self.h, mode))
+
+    def enable_direct_table(self, window_bits):
+        _check("lwkzg_multi_enable_direct_table", lib().lwkzg_multi_enable_direct_table(self.h, window_bits))
+
+    def blob_to_kzg_commitment_batch(self, blobs):
+        n = len(blobs) // BYTES_PER_BLOB
+        assert len(blobs) == n * BYTES_PER_BLOB
+        out = C.create_string_buffer(48 * max(n, 1))
+        self.first_bad = C.c_size_t(0)
+        _check("lwkzg_multi_blob_to_kzg_commitment_batch", lib().lwkzg_multi_blob_to_kzg_commitment_batch(out, blobs, n, self.h, C.byref(self.first_bad)))
+        return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+    def compute_blob_kzg_proof_batch(self, blobs, commitments):
+        n = len(blobs) // BYTES_PER_BLOB
+        assert len(blobs) == n * BYTES_PER_BLOB and len(commitments) == 48 * n
+        out = C.create_string_buffer(48 * max(n, 1))
+        self.first_bad = C.c_size_t(0)
+        _check("lwkzg_multi_compute_blob_kzg_proof_batch",
+               lib().lwkzg_multi_compute_blob_kzg_proof_batch(out, blobs, commitments, n, self.h, C.byref(self.first_bad)))
+        return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+    def compute_kzg_proof_batch(self, blobs, zs):
+        n = len(blobs) // BYTES_PER_BLOB
+        assert len(blobs) == n * BYTES_PER_BLOB and len(zs) == 32 * n
+        out, ys = C.create_string_buffer(48 * max(n, 1)), C.create_string_buffer(32 * max(n, 1))
+        self.first_bad = C.c_size_t(0)
+        _check("lwkzg_multi_compute_kzg_proof_batch",
+               lib().lwkzg_multi_compute_kzg_proof_batch(out, ys, blobs, zs, n, self.h, C.byref(self.first_bad)))
+        return [(out.raw[48 * i:48 * i + 48], ys.raw[32 * i:32 * i + 32]) for i in range(n)]
+
+    def verify_blob_kzg_proof_batch(self, blobs, commitments, proofs, n):
+        ok = C.c_bool(False)
+        _check("lwkzg_multi_verify_blob_kzg_proof_batch",
+               lib().lwkzg_multi_verify_blob_kzg_proof_batch(C.byref(ok), blobs, commitments, proofs, n, self.h))
+        return bool(ok.value)
+
+    def g1_msm_tiled(self, scalars_be):
+        out = C.create_string_buffer(48)
+        _check("lwkzg_multi_g1_msm_tiled", lib().lwkzg_multi_g1_msm_tiled(out, scalars_be, len(scalars_be) // 32, self.h))
+        return out.raw
+
+    def free(self):
+        if self.h:
+            lib().lwkzg_multi_free(self.h)
+            self.h = C.c_void_p()
 
     def __del__(self):
         try:

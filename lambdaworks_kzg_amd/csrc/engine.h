@@ -176,6 +176,7 @@ struct Ctx {
     // makes its stream wait for the event the previous user of the workspace recorded (WsUse, engine.hip).
     hipEvent_t ws_done;
     hipStream_t ws_last;
+    std::atomic<bool> ws_recorded{false};  // ws_done has been recorded at least once (peer_busy reads it without mu)
     hipEvent_t lane_done[kCombineLanes];  // last use of a workspace half by a lane of the coalescing front
     Combiner comb;
     ProofFront blob_proof_front, point_proof_front;

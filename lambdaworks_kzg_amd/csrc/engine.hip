@@ -92,6 +92,7 @@ struct RegEntry {
 static std::map<const void *, RegEntry> g_registry;
 static std::set<const void *> g_live_fs;  // every live Ctx (== the fs pointer it handed out)
 static std::atomic<int> g_default_device{0};
+thread_local int tl_device_override = -1;  // multi.hip: the device the next context of THIS thread is created on (-1: g_default_device)
 
 static uint64_t g1_values_digest(const g1_t *g1) {
     uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a over the first and the last setup point
@@ -113,8 +114,21 @@ struct WsUse {
     ~WsUse() {
         hipEventRecord(c->ws_done, st);
         c->ws_last = st;
+        c->ws_recorded.store(true, std::memory_order_release);
     }
 };
+
+// Is the settings' OTHER context (the twin of a primary, the primary of a twin) at work on the GPU right now? Its last
+// whole-workspace user left ws_done behind: an event that has not completed yet means a call of the other caller stream is
+// in flight. This -- not the mere existence of a twin -- is what makes the direct MSM pick finer workgroups (VERDICT r03:
+// a settings object that once saw two streams kept the two-stream geometry for the rest of its life).
+static bool peer_busy(const Ctx *c) {
+    const Ctx *p = c->is_twin ? c->primary : c->primary->twin.load(std::memory_order_acquire);
+    if (!p || !p->ws_recorded.load(std::memory_order_acquire)) return false;
+    const bool busy = hipEventQuery(p->ws_done) != hipSuccess;
+    (void)hipGetLastError();  // hipErrorNotReady is an answer
+    return busy;
+}
 
 // A lane of the coalescing front uses ONE half of the workspace on its own stream: it waits for the last user of the
 // whole workspace and leaves an event of its own; the two lanes do not wait for each other.
@@ -279,7 +293,7 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
     Ctx *c = new Ctx();
     memset(&c->fs, 0, sizeof c->fs);
     c->magic = kCtxMagic;
-    c->device = twin_of ? twin_of->device : g_default_device.load();
+    c->device = twin_of ? twin_of->device : tl_device_override >= 0 ? tl_device_override : g_default_device.load();
     c->is_twin = twin_of != nullptr;
     c->primary = twin_of ? const_cast<Ctx *>(twin_of) : c;
     c->stream = nullptr;
@@ -350,9 +364,13 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
 // Which of the settings' two contexts a device-resident call on caller stream `st` runs on. The engine's own stream and
 // a stream that used this context last stay here (stream order is all the synchronisation they need); a call on another
 // stream goes to the twin while this context's workspace is still busy, so that the two calls overlap on the GPU.
-static Ctx *pick_ctx(Ctx *c, hipStream_t st) {
+static bool twin_off() {
     static const bool off = getenv("LWKZG_TWIN") && atoi(getenv("LWKZG_TWIN")) == 0;
-    if (off || !st || st == c->stream) return c;
+    return off;
+}
+
+static Ctx *pick_ctx(Ctx *c, hipStream_t st) {
+    if (twin_off() || !st || st == c->stream) return c;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->ws_last == st || c->ws_last == nullptr || hipEventQuery(c->ws_done) == hipSuccess) {
         (void)hipGetLastError();
@@ -492,7 +510,7 @@ Ctx *ctx_of(const KZGSettings *s) {
 // `base` = first workspace slot (in blobs) this launch set may use: sub-batches running on different streams
 // work in disjoint slices of the same workspace.
 // `shared_chip`: latency-chain kernels of the same call run beside this MSM (the fused commit-and-prove's hash): finer
-// workgroups, as when a twin context exists, so that the compute units they sit on do not set the launch's end
+// workgroups, as when the settings' other context is busy, so that the compute units they sit on do not set the launch's end
 static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0, bool shared_chip = false) {
     Workspace &w = c->ws;
     uint32_t *sorted = w.sorted + base * (size_t)kMaxEntries;
@@ -504,7 +522,7 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
         // (scratch of the bucket engine, idle on this path: `buckets` holds the per-lane sums of the hand-scheduled kernel,
         // `sorted` the per-workgroup partial sums, `bstart` the redo flags)
         launch_direct_msm(c->direct_bits, c->direct_tab.win_dev, c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
-                          st, (c->primary->twin.load(std::memory_order_acquire) || shared_chip) ? 2048 : 0);
+                          st, (shared_chip || peer_busy(c)) ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
@@ -2116,14 +2134,15 @@ C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch) {
 // the first overlapped call neither allocates nor synchronises the device
 C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int caller_streams) {
     C_KZG_RET rc = lwkzg_reserve(s, max_batch);
-    if (rc != C_KZG_OK || caller_streams < 2) return rc;
+    if (rc != C_KZG_OK || caller_streams < 2 || twin_off()) return rc;  // LWKZG_TWIN=0: pick_ctx never uses a twin
     Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
     Ctx *t = nullptr;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         t = c->twin.load(std::memory_order_acquire);
         if (!t) {
-            if (ctx_new(&t, c) != C_KZG_OK) return C_KZG_MALLOC;
+            if ((rc = ctx_new(&t, c)) != C_KZG_OK) return rc;
             c->twin.store(t, std::memory_order_release);
         }
     }

@@ -67,3 +67,98 @@ def test_compiler_arm_and_bucket_engine_pick_their_own_kernel():
     assert r["kernel"] == "k_bucket_accumulate" and nwin == 20 and r["launches_per_step"] == 2 and r["gather"] is None
     assert r["algorithmic_bytes_per_launch"] == 512 * 524336
     assert "valu_instructions_per_mixed_addition" not in r["int_mad"]
+
+
+# ---- the ONE stdout line (a 21 KB line lost its head in the driver's bounded tail of stdout) ------------------------------
+
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+             "config", "roofline", "cpu_baseline")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "int_mad")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "single_thread_ops_per_s", "gpu_outputs_match_oracle")
+
+
+def _detail_files():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_line.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_detail.json")))
+
+
+def _check_line(b, text):
+    import json
+    assert len(text.encode()) < b.LINE_LIMIT <= 8000, len(text)
+    assert "\n" not in text
+    line = json.loads(text)
+    assert list(line)[:12] == list(LINE_KEYS[:12])                # the contract's fields lead the line
+    for k in LINE_KEYS:
+        assert k in line, k
+    assert "workload" in line["config"]
+    for k in ROOFLINE_KEYS:
+        assert k in line["roofline"], k
+    assert "frac_of_theoretical" in line["roofline"]["int_mad"]
+    for k in CPU_KEYS:
+        assert k in line["cpu_baseline"], k
+    assert line["dtype"] in ("u32", "u32 limbs (381-bit Fp / 255-bit Fr Montgomery, integer)")
+    return line
+
+
+def test_stdout_line_of_every_committed_detail_file_fits_the_drivers_tail():
+    """compact_line on the detail dictionaries of earlier rounds' real runs (round 3's was the 21 KB line itself)"""
+    import json
+    b = _bench()
+    files = _detail_files()
+    assert files
+    for f in files:
+        res = json.load(open(f))
+        if "cpu_baseline" not in res or "frac_of_theoretical" not in res.get("roofline", {}).get("int_mad", {}):
+            continue                                               # (round 1's line had no theoretical ceiling yet)
+        line = _check_line(b, b.compact_line(res, "bench_detail.json"))
+        assert line["value"] == float("%.6g" % res["value"])
+        if "configs" in res:
+            for name, leg in res["configs"].items():
+                if isinstance(leg, dict) and "value" in leg:
+                    assert set(line["configs"][name]) <= {"value", "unit", "ms_per_step", "steps", "kernel", "kernel_ms", "ntt_roofline", "roofline"}
+            assert "achieved" in line["configs"]["ckzg_commit_b1024_with_ntt"]["ntt_roofline"]
+
+
+def test_stdout_line_worst_case_stays_under_the_limit_and_keeps_its_head():
+    """a detail dictionary far fatter than any real one: thirty legs with forty kernels each, every string padded, every float at full
+    precision -- the line sheds its optional tail, never the contract's fields"""
+    import json
+    import math
+    b = _bench()
+    res = json.load(open(_detail_files()[-1]))
+    kern = {"k_some_kernel_with_a_long_name_%02d" % i: {"launches": 10 + i, "avg_ms": math.pi * (i + 1)} for i in range(40)}
+    res["kernels"] = kern
+    res.setdefault("configs", {})
+    for i in range(30):
+        res["configs"]["leg_%02d_with_a_long_descriptive_name" % i] = {"workload": "w" * 600, "value": math.e * 1e5, "unit": "ops/s", "steps": 10, "warmup": 3,
+                                                                     "ms_per_step": math.pi, "kernels": kern, "note": "n" * 900}
+    res["configs"]["broken_leg"] = {"error": "RuntimeError(" + "x" * 5000 + ")"}
+    res["config"]["workload"] = res["config"]["workload"] + " " + "y" * 300
+    res["cpu_baseline"]["sample"] = "s" * 2000
+    res["roofline"]["traffic_source"] = "t" * 1000
+    line = _check_line(b, b.compact_line(res, "bench_detail.json"))
+    assert "dropped_for_size" in line and "configs" in line["dropped_for_size"]
+
+
+def test_line_numbers_are_rounded_not_truncated():
+    b = _bench()
+    assert b._round({"a": 116634.22217, "b": [0.00799717123, 3], "c": float("nan"), "d": "s"}) == {"a": 116634.0, "b": [0.00799717, 3], "c": None, "d": "s"}
+
+
+def test_launcher_free_multi_gpu_command(monkeypatch):
+    """`python bench.py --gpus N` with no launcher in the environment starts torch.distributed.run itself, before anything touches the GPU"""
+    b = _bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert b.spawn_ranks(4, ["--gpus", "4", "--steps", "2"]) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch" not in b.__dict__                         # bench.py imports torch inside main(), after the spawn decision

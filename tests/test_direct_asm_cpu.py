@@ -7,6 +7,8 @@ run the assembled kernel."""
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
@@ -27,6 +29,23 @@ def test_direct_asm_stream_on_a_simulated_lane():
     G.selftest(14, 16, verbose=False, sparse=True)
     redo, _ = G.selftest(15, 16, verbose=False, force_equal=True)
     assert redo == 1
+
+
+def test_single_collision_after_the_accumulator_has_widened_raises_redo():
+    """exactly ONE addition of the lane meets a row equal to +-(the sum of the rows before it), at the 3rd .. 15th
+    addition -- by then -X of the accumulator sits at its loop bound and P = U2 - X1 is k p with k up to 41, where the second-limb test
+    once dropped the carry of k MOD0 (a 34-bit product taken with v_mul_lo_u32) for k >= 17 and left the flag down (26 of 120 such
+    lanes before the fix). The flag must come up every time: it is the only thing between the incomplete formulas and a wrong
+    commitment."""
+    import gen_direct_asm as G
+    for t in range(3, 16):
+        for neg in (False, True):
+            for seed in (100 + t, 200 + 3 * t):
+                redo, _ = G.selftest(seed, 16, spl=1, verbose=False, collide_at=t, collide_neg=neg)
+                assert redo == 1, (t, neg, seed)
+    for t, c in ((5, 13), (19, 13), (9, 10), (25, 10)):      # the generic-plan widths (20 / 26 additions per scalar)
+        redo, _ = G.selftest(300 + t, c, spl=1, verbose=False, collide_at=t)
+        assert redo == 1, (t, c)
 
 
 def test_fold_asm_inc_is_current_and_adds_on_a_simulated_lane():

@@ -209,3 +209,26 @@ def test_rccl_path_at_world_size_1(K, gpu_setup, tmp_path):
     assert res["verify_honest"] is True and res["verify_tampered"] is False and res["verify_invalid"] == K.C_KZG_ERROR
     vdata = B.synthetic_batch(62000, W.N_VERIFY)
     assert bytes.fromhex(res["comms"]) == b"".join(K.blob_to_kzg_commitment_batch(vdata, gpu_setup))
+
+
+def test_bench_gpus_2_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with NO torch.distributed.run in front of it must start its ranks itself (fresh child
+    processes, created before the parent touches the GPU) and print the one parseable line: two ranks on this one device over gloo
+    (RCCL refuses two ranks on one device), small batch, the bucket-free 10-bit table. The launcher form is what the rehearsal above
+    and the driver use."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LWKZG_BENCH_DETAIL=str(tmp_path / "detail.json"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LWKZG_MODE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--direct-bits", "10", "--no-extra-legs", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-4000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8000, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["dist"]["initialised"] is True and line["dist"]["ranks"] == 2 and line["dist"]["backend"] == "gloo"
+    assert line["config"]["direct_bits"] == 10 and line["config"]["direct_bits_min_over_ranks"] == 10
+    assert line["roofline"]["kernel"].startswith("k_direct_accumulate") and line["roofline"]["avg_launch_ms"] > 0
+    detail = json.load(open(env["LWKZG_BENCH_DETAIL"]))
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-5) and "scaling_note" in detail

@@ -4,7 +4,7 @@ behave as include/lambdaworks_kzg_amd.h says (nothing the reference has a counte
 import pytest
 
 import blobs as B
-from conftest import SETUP_PATH, tau_closed_form
+from conftest import R, SETUP_PATH, tau_closed_form
 
 pytestmark = pytest.mark.gpu
 
@@ -58,5 +58,25 @@ def test_reserve_streams_creates_the_second_context_up_front(K, oracle):
         got = bytes(outs[0].cpu().numpy().tobytes())
         for i in (0, n // 2, n - 1):
             assert got[48 * i:48 * i + 48] == tau_closed_form(oracle, B.blob_scalars(data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB]))
+    finally:
+        ts.free()
+
+
+def test_default_engine_exactly_one_colliding_lane_per_blob(K, oracle):
+    """ADVICE r03, on the engine a plain load selects (the generic-plan stream of k_direct_accumulate_asm): one lane per blob meets a
+    row equal / opposite to its accumulator, late in its walk; the redo pass must put every such blob right (closed form).
+    tests/test_gpu_parity.py runs the same on the 10 / 12 / 14 / 15 / 16-bit tables."""
+    import random
+    from test_gpu_parity import _one_colliding_lane_blob
+    ts = K.TrustedSetup.from_file(SETUP_PATH)
+    try:
+        c = ts.direct_table_bits()
+        assert c in (10, 11, 12, 13)
+        rnd = random.Random(4099)
+        sets = [_one_colliding_lane_blob(rnd, c, negate=(b % 2 == 1)) for b in range(512)]
+        data = b"".join(b"".join(x.to_bytes(32, "big") for x in ss) for ss in sets)
+        got = K.blob_to_kzg_commitment_batch(data, ts)
+        bad = [b for b in range(len(sets)) if got[b] != tau_closed_form(oracle, sets[b])]
+        assert not bad, (len(bad), bad[:8])
     finally:
         ts.free()

@@ -713,6 +713,40 @@ def test_direct_adversarial_digits_closed_form(K, direct_setup, oracle):
         assert g == tau_closed_form(oracle, ss)
 
 
+def _one_colliding_lane_blob(rnd, c, negate):
+    """Random full-range scalars, except that ONE lane of the direct kernel meets a table row equal to (negate: opposite to) its
+    accumulator, once, late: with P_k = [tau^k]G, s_i = +-e tau^2048 (i < 256: the lane's first scalar in every launch geometry),
+    s_(i + 256 m) = 0 for m = 1 .. 7 (skipped), s_(i + 2048) = e -- after the 255 bits of s_i the lane holds +-[e]P_(i + 2048) and the
+    next row it gathers is [e]P_(i + 2048)."""
+    ss = [rnd.randrange(R) for _ in range(4096)]
+    i = rnd.randrange(256)
+    e = rnd.randrange(1, 1 << (c - 1))
+    for m in range(1, 8):
+        ss[i + 256 * m] = 0
+    ss[i + 2048] = e
+    ss[i] = e * pow(TAU, 2048, R) % R
+    if negate:
+        ss[i] = (R - ss[i]) % R
+    return ss
+
+
+@pytest.mark.parametrize("n", [8, 40, 200, 1024])
+def test_direct_exactly_one_colliding_lane_per_blob(K, direct_setup, oracle, n):
+    """the hand-scheduled accumulation has no P = +-Q branches; a lane that meets one must raise its blob's redo flag so
+    that the complete-branches kernel recomputes the blob. One such lane per blob, with the accumulator at its loop bounds (the
+    17th+ addition of the lane). Every commitment against the closed form. (The round-3 stream, whose flag test dropped the carry
+    of k MOD0 for k >= 17, passes this test too: with the row coordinates as the table build leaves them -- Montgomery outputs,
+    below p but for one in about a thousand -- P = U2 - X1 stays under 17 p; the missed case needs a row coordinate >= p, which
+    tests/test_direct_asm_cpu.py produces on the simulated lane. What this test pins is the whole redo path, one lane at a time.)"""
+    ts, c = direct_setup
+    rnd = random.Random(4100 + n + c)
+    sets = [_one_colliding_lane_blob(rnd, c, negate=(b % 2 == 1)) for b in range(n)]
+    data = b"".join(b"".join(x.to_bytes(32, "big") for x in ss) for ss in sets)
+    got = K.blob_to_kzg_commitment_batch(data, ts)
+    bad = [b for b in range(n) if got[b] != tau_closed_form(oracle, sets[b])]
+    assert not bad, (len(bad), bad[:8])
+
+
 @pytest.mark.parametrize("n", [1, 3, 64, 200, 700, 1024])
 def test_direct_commitments_match_default_path(K, direct_setup, bucket_setup, oracle, n):
     """every launch geometry of the direct kernel (16 .. 1 workgroups per blob): every commitment against the tau closed

@@ -544,10 +544,13 @@ def build():
     e("s_cbranch_vccz", ("label", "L_no_cand%="))
     # second limb of k p: ((k MOD0) >> 28) + k MOD1, against limb 1 of P plus limb 0's carry
     e("s_mov_b64", sp(sTMP), VCC)
-    e("v_mul_lo_u32", v(T2r), v(T1), s(sMOD[0]))
-    e("v_lshrrev_b32", v(T2r), lit(W), v(T2r))
-    e("v_mul_lo_u32", v(T3), v(T1), s(sMOD[1]))
-    e("v_add_u32", v(T2r), v(T2r), v(T3))
+    # (k MOD0 needs up to 34 bits -- k < 64, MOD0 < 2^28 --, so the carry is taken from the 64-bit product: a v_mul_lo_u32
+    # here lost it for k >= 17 and the flag stayed down; VCC, the sink of the multiply-add, was saved above)
+    assert 63 * MOD[0] >= 1 << 32 and 63 * MOD[0] < 1 << 36
+    e("v_mad_u64_u32", vp(ACC1[0]), VCC, s(sMOD[0]), v(T1), lit(0))
+    e("v_lshrrev_b64", vp(ACC1[0]), lit(W), vp(ACC1[0]))
+    e("v_mul_lo_u32", v(T3), v(T1), s(sMOD[1]))              # (only its low 28 bits are compared: exact in 32)
+    e("v_add_u32", v(T2r), v(ACC1[0]), v(T3))
     e("v_lshrrev_b32", v(T3), lit(W), v(U[0]))
     e("v_add_u32", v(T3), v(T3), v(U[1]))
     e("v_xor_b32", v(T2r), v(T2r), v(T3))
@@ -991,10 +994,13 @@ G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83f
       0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
 
 
-def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False):
+def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False, collide_at=0, collide_neg=False):
     """One lane through the whole instruction stream: `spl` scalars of nw windows, rows served from a synthetic table
     (row index -> an honest multiple of the generator, weakly reduced as the table stores it), result against affine
-    big-int arithmetic."""
+    big-int arithmetic.
+    collide_at = t > 1: every digit of every scalar is positive and non-zero, and the t-th row the lane gathers IS the sum of
+    the t - 1 rows before it (negated with collide_neg), i.e. exactly ONE addition of the lane meets P = +-Q, after the
+    accumulator's -X has widened to its loop bound: returns the redo flag (the flag must be raised every time)."""
     rnd = random.Random(seed)
     prog = build()
     nw = (255 + c - 1) // c
@@ -1011,12 +1017,15 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
     scalars = {}
     for q in range(spl):
         k = rnd.randrange(R_ORDER)
+        if collide_at:      # windows in [1, h - 1] (no carries, no negative digits, nothing skipped); the top window small enough for k < r
+            k = sum(rnd.randrange(1, h) << (c * j) for j in range(nw - 1)) + (rnd.randrange(1, min(htop, 1 << (wtop - 2))) << (c * (nw - 1)))
         if sparse:
             k &= ((1 << c) - 1) << (c * rnd.randrange(nw - 1))      # a single non-zero window
         scalars[first + q * lpb] = k
     # point i of the setup = [i + 2] G; window j base = 2^(c j) of it
     pts = {i: ec_mul(i + 2, G1) for i in scalars}
     cache = {}
+    served = []            # the points of the distinct rows, in the order the lane first asked for them
 
     def row(idx):
         if idx not in cache:
@@ -1028,6 +1037,13 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
             pt = ec_mul(d << (c * j), pts[point])
             if force_equal:
                 pt = pts[min(pts)]                                  # every row the same point: P + P on the second addition
+            if collide_at and len(served) == collide_at - 1:
+                pt = None
+                for q_ in served:
+                    pt = ec_add(pt, q_)
+                if collide_neg:
+                    pt = (pt[0], (P - pt[1]) % P)
+            served.append(pt)
             # weakly reduced Montgomery limbs (< 2p), as a table row holds them
             xs = to_mont(pt[0]) + (P if rnd.random() < 0.5 else 0)
             ys = to_mont(pt[1]) + (P if rnd.random() < 0.5 else 0)
@@ -1064,7 +1080,7 @@ def selftest(seed=1, c=16, spl=2, verbose=True, sparse=False, force_equal=False)
     want = None
     for i, k in scalars.items():
         want = ec_add(want, ec_mul(k, pts[i]) if not force_equal else None)
-    if force_equal:
+    if force_equal or collide_at:
         return redo, sim.valu_executed
     nxv, nyv, zzv, zzzv = (from_mont_limbs(got[14 * t:14 * t + 14]) for t in range(4))
     if want is None:
