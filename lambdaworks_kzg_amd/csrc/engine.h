@@ -163,10 +163,21 @@ struct LoadTiming {
     double total_ms = 0;
 };
 
+// Pinned host staging of the host-assisted Fiat-Shamir step of SMALL device-resident proof calls (engine.hip:
+// blob_proof_batch_device): the GPU hash is a 3.2 ms latency chain whatever the batch, a host core with SHA extensions needs
+// 0.07 ms per blob, so up to a few dozen blobs are copied out, hashed and validated on the host threads in stream order
+// (hipLaunchHostFunc) and only the 32-byte digests go back.
+struct SmallProofHost {
+    uint8_t *blobs = nullptr, *comm = nullptr, *canon = nullptr, *dig = nullptr;  // cap x 131072 / 48 / 48 / 32, hipHostMalloc
+    int32_t *code = nullptr;                                                      // cap status words (0 or the mode's rejection code)
+    size_t cap = 0;
+};
+
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {
     FFTSettings fs;
     uint64_t magic;
+    uint64_t generation = 0;        // unique per context of this process (ctx_is_live: a shard must not mistake a new context at an old address for its own)
     int device;
     hipStream_t stream;
     hipStream_t vstream;            // point-validation kernels (a plain stream of their own; see ctx_new on CU masks)
@@ -200,6 +211,7 @@ struct Ctx {
     Fr *tw_fwd, *tw_inv;
     Fr28 *tw28_fwd, *tw28_inv;  // the same twiddles in the transform's own arithmetic (fr28.cuh)
     Workspace ws;
+    SmallProofHost sph;
     VerifyBuffers vs;   // verify-side scratch, sized for vs_cap blobs
     size_t vs_cap;
     std::mutex verify_mu;
@@ -209,7 +221,9 @@ struct Ctx {
     LoadTiming load_timing;
 };
 
-Ctx *ctx_of(const KZGSettings *s);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise
+Ctx *ctx_of(const KZGSettings *s);
+// is `c` still the live context that was given generation `gen`? Looks only at the registry, never at a caller's KZGSettings
+bool ctx_is_live(const Ctx *c, uint64_t gen);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise
 
 int mode_of(const KZGSettings *s);    // the semantics a call on `s` answers in: its own mode if it has one, else the default
 

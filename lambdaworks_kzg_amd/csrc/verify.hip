@@ -320,6 +320,7 @@ constexpr size_t kPartial = LWKZG_VERIFY_PARTIAL_BYTES;  // 3 x (flag 1 | x 48 |
 
 struct Shard {
     Ctx *ctx = nullptr;
+    uint64_t ctx_generation = 0;   // the context's identity (engine.h: ctx_is_live): the caller's KZGSettings is never read again
     const KZGSettings *s = nullptr;
     int device = 0;   // kept here: the shard may outlive its settings' context (a caller that frees the setup first)
     size_t n = 0;
@@ -340,6 +341,7 @@ C_KZG_RET shard_begin(Shard &sh, const uint8_t *blobs, const uint8_t *comms, con
     sh.ctx = ctx_of(s);
     if (!sh.ctx) return C_KZG_ERROR;
     sh.device = sh.ctx->device;
+    sh.ctx_generation = sh.ctx->generation;
     sh.s = s;
     sh.n = n;
     sh.mode = mode;
@@ -624,7 +626,8 @@ static C_KZG_RET shard_partial_impl(uint8_t *partial_out, LwkzgVerifyShard *shar
                                     size_t first_index) {
     if (!partial_out || !shard || (!records_all && n_total)) return C_KZG_BADARGS;
     Shard &sh = *(Shard *)shard;
-    if (ctx_of(sh.s) != sh.ctx) {  // the setup was freed (or rebuilt) under the shard: its context is gone
+    if (!ctx_is_live(sh.ctx, sh.ctx_generation)) {  // the setup was freed (or rebuilt) under the shard: its context is gone (decided from the registry,
+                                                     // not by dereferencing the caller's settings pointer, which may be freed or reused by now)
         set_error("lwkzg_verify_shard_partial: the shard's trusted setup is no longer loaded");
         return C_KZG_BADARGS;
     }

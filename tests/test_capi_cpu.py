@@ -254,3 +254,17 @@ def test_transform_lazy_bounds_walkthrough():
     assert (worst_val * r) >> 252 < 1 << 16      # limb 9 as a halfword
     # the exit product takes the laziest element
     assert 10 * (worst_limb + 1) * (1 << 56) + (1 << 36) < 1 << 64
+
+
+def test_every_environment_knob_is_in_the_integration_table():
+    """the getenv knobs of csrc/ were documented in five places; INTEGRATION.md carries the one table, and a knob that exists
+    in the sources without a row there (or a row without a knob) fails here"""
+    src_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "csrc")
+    knobs = set()
+    for f in os.listdir(src_dir):
+        if f.endswith((".hip", ".h", ".cuh")):
+            knobs |= set(re.findall(r'getenv\("(LWKZG_[A-Z_0-9]+)"\)', open(os.path.join(src_dir, f)).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rows = set(re.findall(r"^\s*\| `(LWKZG_[A-Z_0-9]+)` \|", doc, flags=re.M))
+    assert len(knobs) >= 20
+    assert knobs == rows, (sorted(knobs - rows), sorted(rows - knobs))

@@ -69,7 +69,7 @@ def main():
     capi.blob_to_kzg_commitment_batch_device(d_comm.data_ptr(), d_blobs.data_ptr(), nmax, ts)
     sync()
     comms = bytes(d_comm.cpu().numpy().tobytes())
-    for n in (1, 16, 256, 1024):
+    for n in (1, 16, 64, 128, 256, 1024):
         dev = median_ms(lambda: capi.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts), sync)
         sub = data[:n * B.BYTES_PER_BLOB]
         host = median_ms(lambda: K.compute_blob_kzg_proof_batch(sub, comms[:48 * n], ts), lambda: None, warm=2, runs=7)
