@@ -234,41 +234,47 @@ __device__ __forceinline__ PX wave_shfl_down(const PX &v, int d) {
 constexpr int kHeavyBlocks = 2;                       // x 4 waves = 8 heavy buckets in flight per blob
 constexpr int kLightBlocks = kNumBuckets / kAccThreads;
 
-__global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine29 *__restrict__ table,
-                                                                   const uint32_t *__restrict__ sorted,
-                                                                   const uint32_t *__restrict__ bucket_start,
-                                                                   const uint32_t *__restrict__ perm,
-                                                                   G1Xyzz29 *__restrict__ buckets) {
-    const size_t blob = blockIdx.y;
-    const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
-    const uint32_t n_heavy = pm[kNumBuckets];
-    const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
-    const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
-
-    if (blockIdx.x < kHeavyBlocks) {
-        const int lane = threadIdx.x & 63;
-        const uint32_t wave = blockIdx.x * (kAccThreads / 64) + (threadIdx.x >> 6);
-        for (uint32_t h = wave; h < n_heavy; h += kHeavyBlocks * (kAccThreads / 64)) {
-            const uint32_t b = pm[h];
-            const uint32_t begin = bs[b], end = bs[b + 1];
-            G1Xyzz29 acc = G1Xyzz29::infinity();
-            for (uint32_t k = begin + lane; k < end; k += 64) {
-                uint32_t e = ent[k];
-                G1Affine29 p = table[e & ~kEntryNegBit];
-                acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
-            }
-            for (int d = 32; d >= 1; d >>= 1) {
-                G1Xyzz29 other = wave_shfl_down(acc, d);
-                if (lane < d) acc = xyzz_add(acc, other);
-            }
-            if (lane == 0) buckets[blob * (size_t)kNumBuckets + b] = acc;
+// heavy buckets of one blob: one WAVE per bucket, entries strided over the 64 lanes, then a shuffle tree (blocks 0 .. kHeavyBlocks - 1)
+__device__ __forceinline__ void bucket_heavy_blocks(const G1Affine29 *__restrict__ table, const uint32_t *__restrict__ ent,
+                                                    const uint32_t *__restrict__ bs, const uint32_t *__restrict__ pm, uint32_t n_heavy,
+                                                    G1Xyzz29 *__restrict__ out, uint32_t heavy_block) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = heavy_block * (kAccThreads / 64) + (threadIdx.x >> 6);
+    for (uint32_t h = wave; h < n_heavy; h += kHeavyBlocks * (kAccThreads / 64)) {
+        const uint32_t b = pm[h];
+        const uint32_t begin = bs[b], end = bs[b + 1];
+        G1Xyzz29 acc = G1Xyzz29::infinity();
+        for (uint32_t k = begin + lane; k < end; k += 64) {
+            uint32_t e = ent[k];
+            G1Affine29 p = table[e & ~kEntryNegBit];
+            acc = xyzz_madd(acc, p.x, cneg(p.y, (e & kEntryNegBit) != 0));
         }
-        return;
+        for (int d = 32; d >= 1; d >>= 1) {
+            G1Xyzz29 other = wave_shfl_down(acc, d);
+            if (lane < d) acc = xyzz_add(acc, other);
+        }
+        if (lane == 0) out[b] = acc;
     }
+}
 
-    const uint32_t t = (blockIdx.x - kHeavyBlocks) * kAccThreads + threadIdx.x;  // rank in the population order
-    if (t < n_heavy) return;
-    const uint32_t b = pm[t];
+// (block, blob) of this workgroup: blocks 0 .. kHeavyBlocks - 1 of a blob are its heavy blocks, the rest its light ones. (One row of
+// workgroups with every blob's heavy blocks at the head of the launch was tried -- the last blobs' heavy waves would no longer start
+// last -- and lost 20 %: 13.6 instead of 10.7 ms per 512-blob launch, gpurun_out r04g; the interleaved order keeps a few latency-bound
+// heavy waves beside many light ones on every compute unit all the time.)
+struct BucketBlock {
+    size_t blob;
+    uint32_t block;   // heavy: 0 .. kHeavyBlocks - 1; light: 0 .. kLightBlocks - 1
+    bool heavy;
+};
+__device__ __forceinline__ BucketBlock bucket_block() {
+    if (blockIdx.x < (uint32_t)kHeavyBlocks) return {blockIdx.y, blockIdx.x, true};
+    return {blockIdx.y, blockIdx.x - kHeavyBlocks, false};
+}
+
+// one light bucket on one lane, compiler-scheduled, complete by branches (P + P, P - P, infinity): the whole light path of the A/B arm,
+// and the repair of the rare lane of the hand-scheduled stream that met P = +-Q
+__device__ __forceinline__ void bucket_light_lane(const G1Affine29 *__restrict__ table, const uint32_t *__restrict__ ent,
+                                                  const uint32_t *__restrict__ bs, uint32_t b, G1Xyzz29 *__restrict__ out) {
     const uint32_t begin = bs[b], end = bs[b + 1];
     const G1Affine29i *tab = (const G1Affine29i *)table;
     G1Xyzz29i acc = G1Xyzz29i::infinity();
@@ -288,14 +294,82 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affin
             });
         }
     }
-    ((G1Xyzz29i *)buckets)[blob * (size_t)kNumBuckets + b] = acc;
+    ((G1Xyzz29i *)out)[b] = acc;
+}
+
+// the whole accumulation, compiler-scheduled (LWKZG_BUCKET_ASM=0: the A/B arm)
+__global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate(const G1Affine29 *__restrict__ table,
+                                                                   const uint32_t *__restrict__ sorted,
+                                                                   const uint32_t *__restrict__ bucket_start,
+                                                                   const uint32_t *__restrict__ perm,
+                                                                   G1Xyzz29 *__restrict__ buckets) {
+    const BucketBlock bb = bucket_block();
+    const size_t blob = bb.blob;
+    const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t n_heavy = pm[kNumBuckets];
+    const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
+    G1Xyzz29 *out = buckets + blob * (size_t)kNumBuckets;
+    if (bb.heavy) {
+        bucket_heavy_blocks(table, ent, bs, pm, n_heavy, out, bb.block);
+        return;
+    }
+    const uint32_t t = bb.block * kAccThreads + threadIdx.x;  // rank in the population order
+    if (t < n_heavy) return;
+    bucket_light_lane(table, ent, bs, pm[t], out);
+}
+
+// The light buckets as a hand-scheduled instruction stream (tools/gen_bucket_asm.py writes bucket_asm.inc and explains it): the
+// mixed-addition loop of the direct-table kernel (tools/gen_direct_asm.py) fed from the lane's entry list
+// instead of its scalars' digits. The heavy buckets stay with the C++ wave-per-bucket path, in the same launch (their few long
+// waves are dispatched first and run beside the light blocks). The stream has no P = +-Q branches: a lane that meets one says so
+// in the statement's output and its bucket is recomputed right here by the C++ formulas (never on honest data: two entries of one
+// bucket would have to be the same or opposite points, or a partial sum would have to hit a table row).
+__global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate_asm(const G1Affine29 *__restrict__ table,
+                                                                       const uint32_t *__restrict__ sorted,
+                                                                       const uint32_t *__restrict__ bucket_start,
+                                                                       const uint32_t *__restrict__ perm,
+                                                                       G1Xyzz29 *__restrict__ buckets) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const BucketBlock bb = bucket_block();
+    const size_t blob = bb.blob;
+    const uint32_t *pm = perm + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t n_heavy = pm[kNumBuckets];
+    const uint32_t *bs = bucket_start + blob * (size_t)(kNumBuckets + 1);
+    const uint32_t *ent = sorted + blob * (size_t)kMaxEntries;
+    G1Xyzz29 *out = buckets + blob * (size_t)kNumBuckets;
+    if (bb.heavy) {
+        bucket_heavy_blocks(table, ent, bs, pm, n_heavy, out, bb.block);
+        return;
+    }
+    const uint32_t rank = bb.block * kAccThreads + threadIdx.x;
+    uint32_t trouble;
+    asm volatile(
+#include "bucket_asm.inc"
+        : "=&v"(trouble)
+        : "s"(table), "s"(ent), "s"(bs), "s"(pm), "s"(out), "s"(n_heavy), "v"(rank)
+        :
+#include "bucket_asm_clobbers.inc"
+    );
+    if (trouble && rank >= n_heavy) bucket_light_lane(table, ent, bs, pm[rank], out);
+#endif
+}
+
+static bool bucket_asm_enabled() {
+    static const bool on = !(getenv("LWKZG_BUCKET_ASM") && atoi(getenv("LWKZG_BUCKET_ASM")) == 0);
+    return on;
 }
 
 void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, const uint32_t *bucket_start,
                               const uint32_t *perm, G1Xyzz29 *buckets, size_t n_blobs, hipStream_t st) {
-    ProfScope p("k_bucket_accumulate", st);
-    hipLaunchKernelGGL(k_bucket_accumulate, dim3(kHeavyBlocks + kLightBlocks, (unsigned)n_blobs), dim3(kAccThreads), 0,
-                       st, table, sorted, bucket_start, perm, buckets);
+    const dim3 grid(kHeavyBlocks + kLightBlocks, (unsigned)n_blobs);
+    if (bucket_asm_enabled()) {
+        ProfScope p("k_bucket_accumulate_asm", st);
+        hipLaunchKernelGGL(k_bucket_accumulate_asm, grid, dim3(kAccThreads), 0, st, table, sorted, bucket_start, perm, buckets);
+    } else {
+        ProfScope p("k_bucket_accumulate", st);
+        hipLaunchKernelGGL(k_bucket_accumulate, grid, dim3(kAccThreads), 0, st, table, sorted, bucket_start, perm, buckets);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -48,6 +48,24 @@ def test_single_collision_after_the_accumulator_has_widened_raises_redo():
         assert redo == 1, (t, c)
 
 
+def test_bucket_asm_inc_is_current_and_accumulates_a_bucket_on_a_simulated_lane():
+    """the hand-scheduled light-bucket accumulation of the bucket engine (tools/gen_bucket_asm.py, msm.hip: k_bucket_accumulate_asm): the
+    committed .inc files are what the generator writes; a simulated lane walks its entry list (0, 1, 2, 19, 40 entries, either sign,
+    weakly reduced rows) to the affine big-int sum in the reduction's format (X, Y, ZZ, ZZZ below 2p, limbs below 2^28, infinity as
+    literal zeros); a lane of a heavy bucket stores nothing; one row equal / opposite to the accumulator raises the redo flag"""
+    import gen_bucket_asm as Bk
+    assert open(Bk.OUT).read() == Bk.render(Bk.build())
+    assert open(Bk.OUT.replace(".inc", "_clobbers.inc")).read().split("\n", 1)[1].strip() == Bk.clobbers()
+    assert Bk.NUM_SGPRS <= 100
+    per_row = Bk.selftest(31, 19, verbose=False) / 19
+    assert per_row < 4350                                   # the direct stream's body + the entry walk + the closing products
+    for seed, n in ((32, 0), (33, 1), (34, 2), (35, 40)):
+        Bk.selftest(seed, n, verbose=False)
+    Bk.selftest(36, 9, heavy=True, verbose=False)
+    for t, neg in ((2, False), (5, True), (11, False), (17, True)):
+        assert Bk.selftest(40 + t, 18, collide_at=t, collide_neg=neg, verbose=False) == 1, (t, neg)
+
+
 def test_fold_asm_inc_is_current_and_adds_on_a_simulated_lane():
     """the hand-scheduled lane fold (tools/gen_fold_asm.py): committed .inc files are what the generator writes; one simulated
     lane adds 4 / 7 stored lane sums through the memory path (bounds as the accumulation leaves them) to the affine big-int

@@ -217,3 +217,32 @@ def test_second_pass_really_runs_when_a_row_equals_the_accumulator(K, oracle, gp
     finally:
         capi.profile_enable(False)
         K.lib().lwkzg_release_context(C.byref(s))
+
+
+def test_bucket_engine_repairs_lanes_that_meet_equal_or_opposite_points(K, oracle, gpu_setup):
+    """The hand-scheduled light-bucket accumulation (k_bucket_accumulate_asm) has no P = +-Q branches either: a lane that meets one
+    reports it through the statement's output and the C++ formulas behind the statement recompute its bucket in the same launch.
+    With every setup point equal to the generator, all entries of a bucket that come from one window ARE the same point: 128 light
+    buckets of 32 identical entries each (a doubling at the second addition), buckets that mix G and -G (infinity in the middle of
+    the walk), a heavy bucket beside them. Closed form [sum s_i] G, on the bucket engine of a hand-built KZGSettings."""
+    g_blst = C.create_string_buffer(gpu_setup.g1_values_bytes()[:144] * 4096)      # P_i = G for every i
+    s = K.KZGSettings()
+    s.fs, s.g1_values, s.g2_values = None, C.cast(g_blst, C.c_void_p), gpu_setup.s.g2_values
+    sets = [[(k % 128) + 1 for k in range(4096)],
+            [(k % 61) + 2 for k in range(4096)],
+            [((k % 40) + 1) if k % 2 else R - ((k % 40) + 1) for k in range(4096)],          # G-multiples and their negatives in the same buckets
+            [1] * 100 + [(k % 50) + 2 for k in range(3996)],                                  # a heavy bucket (100 entries) beside light ones
+            [(k % 3000) + 1 for k in range(4096)],                                             # buckets of one and of two entries
+            [((k * 2654435761) % 4093) + 1 for k in range(4096)]] * 11
+    n = len(sets)
+    blobs = b"".join(b"".join(v.to_bytes(32, "big") for v in ss) for ss in sets)
+    out = C.create_string_buffer(48 * n)
+    bad = C.c_size_t(0)
+    try:
+        assert K.lib().lwkzg_enable_direct_table(C.byref(s), 0) == K.C_KZG_OK
+        assert K.lib().lwkzg_direct_table_bits(C.byref(s)) == 0
+        assert K.lib().lwkzg_blob_to_kzg_commitment_batch(out, blobs, n, C.byref(s), C.byref(bad)) == K.C_KZG_OK
+        for i, ss in enumerate(sets):
+            assert out.raw[48 * i:48 * i + 48] == oracle.g1_generator_mul(sum(ss) % R), i
+    finally:
+        K.lib().lwkzg_release_context(C.byref(s))

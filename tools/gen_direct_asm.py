@@ -255,7 +255,7 @@ class Prog:
                 out.append("; " + args[0])
                 continue
             line = op
-            if KNOB_E64 and op in E64_OPS and not any(a[0] == "op" or (a[0] == "lit" and 64 < a[1] < 0xFFFFFFF0) for a in args):
+            if kw.get("e64") or (KNOB_E64 and op in E64_OPS and not any(a[0] == "op" or (a[0] == "lit" and 64 < a[1] < 0xFFFFFFF0) for a in args)):
                 line += "_e64"
             if args:
                 line += " " + ", ".join(fmt(a) for a in args)
@@ -391,6 +391,137 @@ KP32_1 = borrowed(32, 1)
 NX_B = WIDE_B + 8            # -X3 = PPP (wide) - R^2 - 2(-Q) + 8p
 
 
+def emit_first_row_and_negation(p):
+    """lanes still at infinity copy the row in (sVALID & sINF), the others get sACT; rows of negative digits are negated (sACT & sNEG)"""
+    e = p.emit
+    # lanes whose accumulator is still at infinity take the row as it is: -X = 4p - QX, -Y = QY (negative digit) or
+    # 4p - QY, ZZ = ZZZ = 1 (Montgomery form)
+    e("s_and_b64", sp(sTMP), sp(sVALID), sp(sINF))
+    e("s_andn2_b64", sp(sACT), sp(sVALID), sp(sINF))
+    e("s_andn2_b64", sp(sINF), sp(sINF), sp(sTMP))
+    e("s_mov_b64", EXEC, sp(sTMP))
+    e("s_cbranch_execz", ("label", "L_no_init%="))
+    for i in range(14):
+        e("v_sub_u32", v(NX[i]), lit(KP4_1[i]), v(QX[i]))
+        if i > 0:
+            e("v_add_u32", v(NX[i]), v(NX[i]), v(T1))
+        if i < 13:                                         # carried: -X keeps its limbs under 2^28
+            e("v_lshrrev_b32", v(T1), lit(W), v(NX[i]))
+            e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
+    for i in range(14):
+        e("v_sub_u32", v(NY[i]), lit(KP4_1[i]), v(QY[i]))
+        if i > 0:
+            e("v_add_u32", v(NY[i]), v(NY[i]), v(T1))
+        if i < 13:
+            e("v_lshrrev_b32", v(T1), lit(W), v(NY[i]))
+            e("v_and_b32", v(NY[i]), s(sMASK), v(NY[i]))
+    for i in range(14):
+        e("v_mov_b32", v(ZZ[i]), lit(R1[i]))
+    for i in range(14):
+        e("v_mov_b32", v(ZZZ[i]), lit(R1[i]))
+    e("s_and_b64", EXEC, sp(sTMP), sp(sNEG))
+    for i in range(14):
+        e("v_mov_b32", v(NY[i]), v(QY[i]))
+    p.label("L_no_init%=")
+    # negative digit: QY <- 4p - QY on the lanes that add
+    e("s_and_b64", EXEC, sp(sACT), sp(sNEG))
+    e("s_cbranch_execz", ("label", "L_no_neg%="))
+    for i in range(14):
+        e("v_sub_u32", v(QY[i]), lit(KP4_1[i]), v(QY[i]))
+    p.label("L_no_neg%=")
+    e("s_mov_b64", EXEC, lit(-1))
+
+
+def emit_madd_part_a(p):
+    """U2, S2, P, R and the P == 0 test, under sACT; returns the values part B needs"""
+    e = p.emit
+    # ---- the mixed addition, first part: U2 = QX ZZ1, S2 = QY ZZZ1; P = U2 + (-X1), R = S2 + (-Y1)
+    qx, qy = Val(QX, 2, 1), Val(QY, 4, 2)
+    nx, ny = Val(NX, NX_B, 1), Val(NY, WIDE_B, 1)
+    zz, zzz = Val(ZZ, WIDE_B, 1), Val(ZZZ, WIDE_B, 1)
+    e("s_mov_b64", EXEC, sp(sACT))
+    e("s_cbranch_execz", ("label", "L_skip_a%="))
+    interleave(p, chain_mul(qx, zz, U, M1, ACC1, T1, wide=True), chain_mul(qy, zzz, S, M2, ACC2, T2r, wide=True))
+    for i in range(14):
+        e("v_add_u32", v(U[i]), v(U[i]), v(NX[i]))
+        e("v_add_u32", v(S[i]), v(S[i]), v(NY[i]))
+    pp_ = Val(U, WIDE_B + nx.B, 1 + nx.L)
+    rr = Val(S, WIDE_B + ny.B, 1 + ny.L)
+    # P == 0 mod p? value = k p with k < 64 <=> (low 56 bits) p^-1 < 64 mod 2^56, tested 28 bits at a time
+    assert pp_.B <= 64
+    e("v_mul_lo_u32", v(T1), v(U[0]), s(sINVP))
+    e("v_and_b32", v(T1), s(sMASK), v(T1))
+    e("v_cmp_gt_u32", VCC, lit(64), v(T1))
+    e("s_cbranch_vccz", ("label", "L_no_cand%="))
+    # second limb of k p: ((k MOD0) >> 28) + k MOD1, against limb 1 of P plus limb 0's carry
+    e("s_mov_b64", sp(sTMP), VCC)
+    # (k MOD0 needs up to 34 bits -- k < 64, MOD0 < 2^28 --, so the carry is taken from the 64-bit product: a v_mul_lo_u32
+    # here lost it for k >= 17 and the flag stayed down, ADVICE r03; VCC, the sink of the multiply-add, was saved above)
+    assert 63 * MOD[0] >= 1 << 32 and 63 * MOD[0] < 1 << 36
+    e("v_mad_u64_u32", vp(ACC1[0]), VCC, s(sMOD[0]), v(T1), lit(0))
+    e("v_lshrrev_b64", vp(ACC1[0]), lit(W), vp(ACC1[0]))
+    e("v_mul_lo_u32", v(T3), v(T1), s(sMOD[1]))              # (only its low 28 bits are compared: exact in 32)
+    e("v_add_u32", v(T2r), v(ACC1[0]), v(T3))
+    e("v_lshrrev_b32", v(T3), lit(W), v(U[0]))
+    e("v_add_u32", v(T3), v(T3), v(U[1]))
+    e("v_xor_b32", v(T2r), v(T2r), v(T3))
+    e("v_and_b32", v(T2r), s(sMASK), v(T2r))
+    e("v_cmp_eq_u32", VCC, lit(0), v(T2r))
+    e("s_and_b64", sp(sTMP), sp(sTMP), VCC)
+    e("s_or_b64", sp(sTROUBLE), sp(sTROUBLE), sp(sTMP))
+    p.label("L_no_cand%=")
+    p.label("L_skip_a%=")
+    return pp_, rr, nx, ny, zz, zzz
+
+
+def emit_madd_part_b(p, pp_, rr, nx, ny, zz, zzz):
+    """the rest of the mixed addition under sACT (the row registers are dead: the next row is already on its way into them)"""
+    e = p.emit
+    e("s_mov_b64", EXEC, sp(sACT))
+    e("s_cbranch_execz", ("label", "L_skip_b%="))
+    # ---- second part
+    for i in range(14):
+        e("v_lshlrev_b32", v(D1[i]), lit(1), v(U[i]))
+        e("v_lshlrev_b32", v(D2[i]), lit(1), v(S[i]))
+    if KNOB_PAUSE in ("nop_groups", "nop_mid"):
+        e("s_nop", ("raw", "15"))
+    interleave(p, chain_sqr(pp_, D1, PP, M1, ACC1, T1, wide=True), chain_sqr(rr, D2, RR2, M2, ACC2, T2r))
+    pp, rr2 = Val(PP, WIDE_B, 1), Val(RR2, NARROW_B, 1)
+    if KNOB_PAUSE == "nop_groups":
+        e("s_nop", ("raw", "15"))
+    interleave(p, chain_mul(pp_, pp, D1, M1, ACC1, T1, wide=True), chain_mul(nx, pp, D2, M2, ACC2, T2r))
+    ppp, nq = Val(D1, WIDE_B, 1), Val(D2, NARROW_B, 1)          # nq = (-X1) PP = -Q
+    assert rr2.B + 2 * nq.B <= 8
+    # X3 = R^2 - PPP - 2Q  ->  -X3 = PPP - R^2 - 2(-Q) + 8p, carried: limbs < 2^28
+    for i in range(14):
+        e("v_lshl_add_u32", v(T1), v(D2[i]), lit(1), v(RR2[i]))          # 2(-Q) + R^2        < 3 2^28
+        e("v_sub_u32", v(T1), lit(KP8_4[i]), v(T1))                       # 8p (borrowed 4) - that
+        if i == 0:
+            e("v_add_u32", v(NX[i]), v(D1[i]), v(T1))
+        else:
+            e("v_add3_u32", v(NX[i]), v(D1[i]), v(T1), v(T2r))
+        if i < 13:
+            e("v_lshrrev_b32", v(T2r), lit(W), v(NX[i]))
+            e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
+    nx3 = Val(NX, ppp.B + 8, 1)
+    # t1 = (-Q) - (-X3) + 32p  [= -(Q - X3)],  t2 = 32p - PPP
+    assert nx3.B <= 32 and ppp.B <= 32
+    for i in range(14):
+        e("v_add_u32", v(D2[i]), lit(KP32_1[i]), v(D2[i]))
+        e("v_sub_u32", v(D2[i]), v(D2[i]), v(NX[i]))
+        e("v_sub_u32", v(U[i]), lit(KP32_1[i]), v(D1[i]))
+    t1 = Val(D2, nq.B + 32, 1 + 2)
+    t2 = Val(U, 32, 2)
+    # ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP, -Y3 = R t1 + (-Y1) t2   (three chains; each output overwrites an input limb by limb:
+    # output limb k - 14 is written at column k, the input limb k - 14 was last read at column k - 1)
+    if KNOB_PAUSE == "nop_groups":
+        e("s_nop", ("raw", "15"))
+    interleave(p, chain_mul(zz, pp, ZZ, M1, ACC1, T1, wide=True), chain_mul(zzz, ppp, ZZZ, M2, ACC2, T2r, wide=True),
+               chain_mul_add(rr, t1, ny, t2, NY, RR2, ACC3, T3, wide=True))
+    assert nx3.B <= nx.B and nx3.L <= nx.L
+    p.label("L_skip_b%=")
+
+
 def build():
     p = Prog()
     e = p.emit
@@ -470,42 +601,7 @@ def build():
     p.label("L_same_scalar%=")
     e("s_cmp_lt_u32", s(sQ), s(sSPL))
     e("s_cselect_b32", s(sMORE), lit(1), lit(0))
-    # lanes whose accumulator is still at infinity take the row as it is: -X = 4p - QX, -Y = QY (negative digit) or
-    # 4p - QY, ZZ = ZZZ = 1 (Montgomery form)
-    e("s_and_b64", sp(sTMP), sp(sVALID), sp(sINF))
-    e("s_andn2_b64", sp(sACT), sp(sVALID), sp(sINF))
-    e("s_andn2_b64", sp(sINF), sp(sINF), sp(sTMP))
-    e("s_mov_b64", EXEC, sp(sTMP))
-    e("s_cbranch_execz", ("label", "L_no_init%="))
-    for i in range(14):
-        e("v_sub_u32", v(NX[i]), lit(KP4_1[i]), v(QX[i]))
-        if i > 0:
-            e("v_add_u32", v(NX[i]), v(NX[i]), v(T1))
-        if i < 13:                                         # carried: -X keeps its limbs under 2^28
-            e("v_lshrrev_b32", v(T1), lit(W), v(NX[i]))
-            e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
-    for i in range(14):
-        e("v_sub_u32", v(NY[i]), lit(KP4_1[i]), v(QY[i]))
-        if i > 0:
-            e("v_add_u32", v(NY[i]), v(NY[i]), v(T1))
-        if i < 13:
-            e("v_lshrrev_b32", v(T1), lit(W), v(NY[i]))
-            e("v_and_b32", v(NY[i]), s(sMASK), v(NY[i]))
-    for i in range(14):
-        e("v_mov_b32", v(ZZ[i]), lit(R1[i]))
-    for i in range(14):
-        e("v_mov_b32", v(ZZZ[i]), lit(R1[i]))
-    e("s_and_b64", EXEC, sp(sTMP), sp(sNEG))
-    for i in range(14):
-        e("v_mov_b32", v(NY[i]), v(QY[i]))
-    p.label("L_no_init%=")
-    # negative digit: QY <- 4p - QY on the lanes that add
-    e("s_and_b64", EXEC, sp(sACT), sp(sNEG))
-    e("s_cbranch_execz", ("label", "L_no_neg%="))
-    for i in range(14):
-        e("v_sub_u32", v(QY[i]), lit(KP4_1[i]), v(QY[i]))
-    p.label("L_no_neg%=")
-    e("s_mov_b64", EXEC, lit(-1))
+    emit_first_row_and_negation(p)
     # the digit after this one (all lanes), its masks and its row address
     e("s_mov_b64", sp(sVALIDN), lit(0))
     e("s_cmp_eq_u32", s(sMORE), lit(0))
@@ -524,90 +620,13 @@ def build():
     p.label("L_no_new_scalar%=")
     digit_and_address(p)
     p.label("L_no_next%=")
-    # ---- the mixed addition, first part: U2 = QX ZZ1, S2 = QY ZZZ1; P = U2 + (-X1), R = S2 + (-Y1)
-    qx, qy = Val(QX, 2, 1), Val(QY, 4, 2)
-    nx, ny = Val(NX, NX_B, 1), Val(NY, WIDE_B, 1)
-    zz, zzz = Val(ZZ, WIDE_B, 1), Val(ZZZ, WIDE_B, 1)
-    e("s_mov_b64", EXEC, sp(sACT))
-    e("s_cbranch_execz", ("label", "L_skip_a%="))
-    interleave(p, chain_mul(qx, zz, U, M1, ACC1, T1, wide=True), chain_mul(qy, zzz, S, M2, ACC2, T2r, wide=True))
-    for i in range(14):
-        e("v_add_u32", v(U[i]), v(U[i]), v(NX[i]))
-        e("v_add_u32", v(S[i]), v(S[i]), v(NY[i]))
-    pp_ = Val(U, WIDE_B + nx.B, 1 + nx.L)
-    rr = Val(S, WIDE_B + ny.B, 1 + ny.L)
-    # P == 0 mod p? value = k p with k < 64 <=> (low 56 bits) p^-1 < 64 mod 2^56, tested 28 bits at a time
-    assert pp_.B <= 64
-    e("v_mul_lo_u32", v(T1), v(U[0]), s(sINVP))
-    e("v_and_b32", v(T1), s(sMASK), v(T1))
-    e("v_cmp_gt_u32", VCC, lit(64), v(T1))
-    e("s_cbranch_vccz", ("label", "L_no_cand%="))
-    # second limb of k p: ((k MOD0) >> 28) + k MOD1, against limb 1 of P plus limb 0's carry
-    e("s_mov_b64", sp(sTMP), VCC)
-    # (k MOD0 needs up to 34 bits -- k < 64, MOD0 < 2^28 --, so the carry is taken from the 64-bit product: a v_mul_lo_u32
-    # here lost it for k >= 17 and the flag stayed down; VCC, the sink of the multiply-add, was saved above)
-    assert 63 * MOD[0] >= 1 << 32 and 63 * MOD[0] < 1 << 36
-    e("v_mad_u64_u32", vp(ACC1[0]), VCC, s(sMOD[0]), v(T1), lit(0))
-    e("v_lshrrev_b64", vp(ACC1[0]), lit(W), vp(ACC1[0]))
-    e("v_mul_lo_u32", v(T3), v(T1), s(sMOD[1]))              # (only its low 28 bits are compared: exact in 32)
-    e("v_add_u32", v(T2r), v(ACC1[0]), v(T3))
-    e("v_lshrrev_b32", v(T3), lit(W), v(U[0]))
-    e("v_add_u32", v(T3), v(T3), v(U[1]))
-    e("v_xor_b32", v(T2r), v(T2r), v(T3))
-    e("v_and_b32", v(T2r), s(sMASK), v(T2r))
-    e("v_cmp_eq_u32", VCC, lit(0), v(T2r))
-    e("s_and_b64", sp(sTMP), sp(sTMP), VCC)
-    e("s_or_b64", sp(sTROUBLE), sp(sTROUBLE), sp(sTMP))
-    p.label("L_no_cand%=")
-    p.label("L_skip_a%=")
+    pp_, rr, nx, ny, zz, zzz = emit_madd_part_a(p)
     # ---- the row is dead: the next one is gathered into its registers
     e("s_mov_b64", EXEC, sp(sVALIDN))
     e("s_cbranch_execz", ("label", "L_no_loads%="))
     row_loads(p)
     p.label("L_no_loads%=")
-    e("s_mov_b64", EXEC, sp(sACT))
-    e("s_cbranch_execz", ("label", "L_skip_b%="))
-    # ---- second part
-    for i in range(14):
-        e("v_lshlrev_b32", v(D1[i]), lit(1), v(U[i]))
-        e("v_lshlrev_b32", v(D2[i]), lit(1), v(S[i]))
-    if KNOB_PAUSE in ("nop_groups", "nop_mid"):
-        e("s_nop", ("raw", "15"))
-    interleave(p, chain_sqr(pp_, D1, PP, M1, ACC1, T1, wide=True), chain_sqr(rr, D2, RR2, M2, ACC2, T2r))
-    pp, rr2 = Val(PP, WIDE_B, 1), Val(RR2, NARROW_B, 1)
-    if KNOB_PAUSE == "nop_groups":
-        e("s_nop", ("raw", "15"))
-    interleave(p, chain_mul(pp_, pp, D1, M1, ACC1, T1, wide=True), chain_mul(nx, pp, D2, M2, ACC2, T2r))
-    ppp, nq = Val(D1, WIDE_B, 1), Val(D2, NARROW_B, 1)          # nq = (-X1) PP = -Q
-    assert rr2.B + 2 * nq.B <= 8
-    # X3 = R^2 - PPP - 2Q  ->  -X3 = PPP - R^2 - 2(-Q) + 8p, carried: limbs < 2^28
-    for i in range(14):
-        e("v_lshl_add_u32", v(T1), v(D2[i]), lit(1), v(RR2[i]))          # 2(-Q) + R^2        < 3 2^28
-        e("v_sub_u32", v(T1), lit(KP8_4[i]), v(T1))                       # 8p (borrowed 4) - that
-        if i == 0:
-            e("v_add_u32", v(NX[i]), v(D1[i]), v(T1))
-        else:
-            e("v_add3_u32", v(NX[i]), v(D1[i]), v(T1), v(T2r))
-        if i < 13:
-            e("v_lshrrev_b32", v(T2r), lit(W), v(NX[i]))
-            e("v_and_b32", v(NX[i]), s(sMASK), v(NX[i]))
-    nx3 = Val(NX, ppp.B + 8, 1)
-    # t1 = (-Q) - (-X3) + 32p  [= -(Q - X3)],  t2 = 32p - PPP
-    assert nx3.B <= 32 and ppp.B <= 32
-    for i in range(14):
-        e("v_add_u32", v(D2[i]), lit(KP32_1[i]), v(D2[i]))
-        e("v_sub_u32", v(D2[i]), v(D2[i]), v(NX[i]))
-        e("v_sub_u32", v(U[i]), lit(KP32_1[i]), v(D1[i]))
-    t1 = Val(D2, nq.B + 32, 1 + 2)
-    t2 = Val(U, 32, 2)
-    # ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP, -Y3 = R t1 + (-Y1) t2   (three chains; each output overwrites an input limb by limb:
-    # output limb k - 14 is written at column k, the input limb k - 14 was last read at column k - 1)
-    if KNOB_PAUSE == "nop_groups":
-        e("s_nop", ("raw", "15"))
-    interleave(p, chain_mul(zz, pp, ZZ, M1, ACC1, T1, wide=True), chain_mul(zzz, ppp, ZZZ, M2, ACC2, T2r, wide=True),
-               chain_mul_add(rr, t1, ny, t2, NY, RR2, ACC3, T3, wide=True))
-    assert nx3.B <= nx.B and nx3.L <= nx.L
-    p.label("L_skip_b%=")
+    emit_madd_part_b(p, pp_, rr, nx, ny, zz, zzz)
     e("s_mov_b64", EXEC, lit(-1))
     e("s_cmp_eq_u32", s(sMORE), lit(0))
     e("s_cbranch_scc0", ("label", "L_loop%="))
@@ -781,6 +800,9 @@ class Sim:
                 self.vr[o[1]] = x
         elif o[0] == "s":
             self.sr[o[1]] = x
+        elif o[0] == "op":                   # an output operand of the statement (a VGPR: written under EXEC)
+            if self.exec & 1:
+                self.ops[o[1]] = x
         else:
             raise ValueError(o)
 
@@ -943,6 +965,12 @@ class Sim:
                     addr = self.g64(a[1]) + kw.get("offset", 0)
                     words = self.rd(addr, 4)
                     for k in range(4):
+                        self.pending.append((a[0][1] + k, words[k]))
+            elif op in ("global_load_dword", "global_load_dwordx2"):      # (the entry walk of tools/gen_bucket_asm.py)
+                if self.exec & 1:
+                    n = 1 if op.endswith("dword") else 2
+                    words = self.rd(self.g64(a[1]) + kw.get("offset", 0), n)
+                    for k in range(n):
                         self.pending.append((a[0][1] + k, words[k]))
             elif op == "global_store_dwordx4":
                 if self.exec & 1:
