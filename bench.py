@@ -231,6 +231,7 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
     One GPU only; never part of `value`. A leg that fails reports its error instead of taking the line down."""
     out = {"engine_direct_bits": direct_bits}
     stream = torch.cuda.current_stream(dev).cuda_stream
+    ckzg_outputs = []
 
     def region(step, steps, warmup):
         for _ in range(warmup):
@@ -321,13 +322,14 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         d_le = dev_bytes(B.synthetic_batch(0, n, big_endian=False))
         d_o = torch.empty(48 * n, dtype=torch.uint8, device=dev)
         d_s = torch.zeros(n, dtype=torch.int32, device=dev)
-        ts.set_mode(K.MODE_CKZG)          # this settings object only (lwkzg_settings_set_mode)
-        try:
+        K.set_mode(K.MODE_CKZG)           # the process-wide default: it never moves a table, so on a table that leaves no room for a second one
+        try:                              # (the headline's 16-bit one) this leg stays on the transform path and times k_ntt4096
             steps = 10
             el, kern = region(lambda: K.blob_to_kzg_commitment_batch_device(d_o.data_ptr(), d_le.data_ptr(), n, ts, stream, d_s.data_ptr()), steps, 3)
         finally:
-            ts.set_mode(-1)
+            K.set_mode(K.MODE_REFERENCE)
         assert int(d_s.abs().sum().item()) == 0
+        ckzg_outputs.append(bytes(d_o.cpu().numpy().tobytes()))
         ntt_ms = kern.get("k_ntt4096", {}).get("avg_ms", 0.0)
         ntt_traffic = ntt_traffic_source = None
         try:   # committed PMC passes over the all-legs run (tools/pmc_traffic_all.py): every k_ntt4096 launch there is this one
@@ -352,6 +354,26 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                                  "note": "SURVEY 8d: 262,144 algorithmic bytes per 4096-point transform; the whole blob stays in LDS for the twelve stages, "
                                          "so HBM sees each element once in and once out; the kernel is bound by its 30,720 Fr products per blob"}}
     leg("ckzg_commit_b1024_with_ntt", ckzg_commit)
+
+    def ckzg_commit_lagrange():
+        """the same c-kzg commitments with the settings object SWITCHED to c-kzg mode (lwkzg_settings_set_mode): its direct table moves to
+        the Lagrange form -- beside the monomial one if both fit, instead of it otherwise (the seconds are reported) -- and a commitment is
+        the MSM over the blob's evaluations as they stand: no k_ntt4096. Last leg: the table stays in that form."""
+        n = BLOBS_PER_GPU
+        d_le = dev_bytes(B.synthetic_batch(0, n, big_endian=False))
+        d_o = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+        d_s = torch.zeros(n, dtype=torch.int32, device=dev)
+        t0 = time.perf_counter()
+        ts.set_mode(K.MODE_CKZG)
+        t_move = time.perf_counter() - t0
+        steps = 10
+        el, kern = region(lambda: K.blob_to_kzg_commitment_batch_device(d_o.data_ptr(), d_le.data_ptr(), n, ts, stream, d_s.data_ptr()), steps, 3)
+        assert int(d_s.abs().sum().item()) == 0
+        assert not ckzg_outputs or ckzg_outputs[0] == bytes(d_o.cpu().numpy().tobytes()), "the Lagrange form and the transform path disagree"
+        return {"workload": "c-kzg-4844 semantics on the Lagrange form of the setup: batch=%d little-endian evaluation-form blobs -> commitments, no transform "
+                            "(range check + copy, then the same MSM kernel over [l_i(tau)]G)" % n,
+                "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern,
+                "table_forms": ts.direct_table_forms(), "settings_set_mode_s": t_move, "equal_to_transform_path": bool(ckzg_outputs)}
 
     def verify_batch():
         n = 4096
@@ -398,6 +420,7 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         return {"workload": "BASELINE configs[1] once more on ONE caller stream after the two-stream legs (the twin context exists and is idle)",
                 "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern}
     leg("commit_b1024_one_stream_after_twin", commit_after_two_streams)
+    leg("ckzg_commit_b1024_lagrange", ckzg_commit_lagrange)
     return out
 
 LINE_LIMIT = 8000            # bytes of the one stdout line (the driver keeps a bounded tail of stdout)

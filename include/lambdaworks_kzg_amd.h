@@ -138,7 +138,13 @@ C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48
  * lwkzg_set_mode sets the process-wide DEFAULT (initial value from the environment variable LWKZG_MODE,
  * "reference"|"ckzg"); lwkzg_settings_set_mode gives ONE settings object a mode of its own, which wins over the default
  * (mode -1 hands it back to the default), so two consumers in one process can use different semantics. Every entry
- * point resolves its mode once, when it is entered: a change does not affect calls already in flight. */
+ * point resolves its mode once, when it is entered: a change does not affect calls already in flight.
+ * Cost of lwkzg_settings_set_mode: it brings the settings' MSM tables to the new mode's form (lwkzg_direct_table_forms below). The
+ * first switch to c-kzg mode derives the Lagrange form of the setup on the device (about 50 ms) and builds a second direct table
+ * beside the first if it fits (default engine: 0.2-0.3 s and 41 GB more); at 15 / 16 bits, where only one table fits, the table is
+ * REBUILT in the new form (what lwkzg_enable_direct_table of that width costs: 0.9 s of kernels at 16 bits plus the driver's
+ * hipMalloc waits). Switching back and forth between two forms that both exist is free. lwkzg_set_mode never touches a table: a
+ * settings object that merely follows the default gets the Lagrange form on its first c-kzg call, and only if it fits beside. */
 #define LWKZG_MODE_REFERENCE 0
 #define LWKZG_MODE_CKZG 1
 int lwkzg_set_mode(int mode); /* returns the previous default, or -1 if `mode` is invalid */
@@ -207,6 +213,18 @@ C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int call
 C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits);
 int lwkzg_direct_table_bits(const KZGSettings *s);   /* 0 = bucket engine, 10..16 = direct table live, -1 = bad settings */
 int lwkzg_direct_num_windows(int window_bits);       /* additions per scalar on the direct path (0 for other widths) */
+/* The forms the live direct table(s) are in: bit 0 = monomial ([tau^i]G: reference mode, and every proof's quotient), bit 1 =
+ * Lagrange ([l_i(tau)]G in the blob's own order: a c-kzg commitment is then an MSM over the blob's evaluations as they stand, no
+ * transform -- SURVEY Appendix D; the reference left this conversion commented out, src/lib.rs:760-770, src/srs.rs:117-124).
+ * The table is built in the form of the mode the settings answer in at that moment (lwkzg_enable_direct_table, the load's own
+ * choice, lwkzg_settings_set_mode) and in the other form as well when that fits beside it with 8 GiB to spare (always up to 14 bits
+ * on an empty MI355X, never at 15 / 16); the Lagrange form only once the settings have answered in c-kzg mode. No result depends on
+ * it: without a Lagrange table a c-kzg commitment pays the inverse transform (k_ntt4096, +4 %); without a monomial table a c-kzg proof
+ * pays one forward transform of its quotient, and reference mode runs on the monomial buckets. 0 = bucket engine, -1 = bad settings. */
+int lwkzg_direct_table_forms(const KZGSettings *s);
+/* lwkzg_enable_direct_table with the forms named: 1 = monomial only, 2 = Lagrange only (a consumer that only ever speaks c-kzg and wants
+ * the widest table: 16 bits = 275 GB in ONE form), 3 = both or C_KZG_MALLOC. C_KZG_BADARGS for anything else. */
+C_KZG_RET lwkzg_enable_direct_table_forms(const KZGSettings *s, int window_bits, int forms);
 /* Bytes from one table row to the next: 128 when every row got a 128-byte line of its own (chosen whenever that table
  * leaves 8 GiB of the device free: one line per gather, +2.5 % / +5 % / +1.4 % at 13 / 15 / 16 bits), 112 when the rows are
  * packed (the sizes quoted above); 0 = bucket engine, -1 = bad settings. LWKZG_DIRECT_ROW=112|128 forces one. */

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
-    "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
+    "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_table_forms", "lwkzg_enable_direct_table_forms", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
     "lwkzg_timing_report", "lwkzg_runtime_init",
     "lwkzg_multi_load", "lwkzg_multi_load_file", "lwkzg_multi_free", "lwkzg_multi_device_count", "lwkzg_multi_device", "lwkzg_multi_settings",
@@ -104,6 +104,8 @@ def lib():
     l.lwkzg_reserve_streams.argtypes = [ps, sz, ci]
     l.lwkzg_enable_direct_table.argtypes = [ps, ci]
     l.lwkzg_direct_table_bits.argtypes = [ps]
+    l.lwkzg_direct_table_forms.argtypes = [ps]
+    l.lwkzg_enable_direct_table_forms.argtypes = [ps, ci, ci]
     l.lwkzg_direct_num_windows.argtypes = [ci]
     l.lwkzg_direct_row_bytes.argtypes = [ps]
     l.lwkzg_g1_lincomb_setup_device.argtypes = [vp, vp, sz, ps, vp]
@@ -263,6 +265,14 @@ class TrustedSetup:
 
     def direct_table_bits(self):
         return lib().lwkzg_direct_table_bits(self.ref())
+
+    def enable_direct_table_forms(self, window_bits, forms):
+        """forms: 1 = monomial only, 2 = Lagrange only, 3 = both"""
+        _check("lwkzg_enable_direct_table_forms", lib().lwkzg_enable_direct_table_forms(self.ref(), window_bits, forms))
+
+    def direct_table_forms(self):
+        """bit 0: a monomial-form direct table is live, bit 1: a Lagrange-form one (c-kzg commitments without the transform)"""
+        return lib().lwkzg_direct_table_forms(self.ref())
 
     def direct_row_bytes(self):
         """128 = table rows aligned to 128-byte lines, 112 = packed, 0 = bucket engine."""

@@ -173,6 +173,19 @@ struct SmallProofHost {
     size_t cap = 0;
 };
 
+// The Lagrange form of the setup (c-kzg mode without the transform): L_i = [l_i(tau)]G in the blob's own
+// (bit-reversed domain) order, so that a c-kzg blob's evaluations are MSM scalars as they stand. Derived on the device from the
+// monomial points (engine.hip: lagrange_prepare), lazily: a settings object that never answers in c-kzg mode never pays for it.
+struct LagrangeForm {
+    bool ready = false;                  // points + 9 MB bucket table exist (written under the context's locks, both of them)
+    G1Affine *points = nullptr;          // 4096 affine Montgomery points
+    G1Affine29 *table = nullptr;         // the bucket engine's fixed-base table over them
+    G1Affine29 *direct_table = nullptr;  // direct table over them (window 0's rows); nullptr = none
+    DirectTable direct_tab;
+    int direct_bits = 0;
+    size_t direct_row_bytes = 0;
+};
+
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
 struct Ctx {
     FFTSettings fs;
@@ -208,6 +221,9 @@ struct Ctx {
     DirectTable direct_tab;    // the windows (one allocation each) and their addresses on the device; owned by the primary context
     int direct_bits;           // 14 / 15 / 16 when direct_table is live, else 0
     size_t direct_row_bytes;   // 128 (every row in a line of its own) or 112 (packed), see kernels.h
+    LagrangeForm lag;          // owned by the primary context; a twin holds copies of the pointers (sync_twin_tables)
+    std::atomic<bool> lag_ready{false};  // == lag.ready, readable without the lock (ensure_lagrange's fast path)
+    bool lag_failed = false;   // the derivation failed once (out of memory): c-kzg mode stays on the transform path
     Fr *tw_fwd, *tw_inv;
     Fr28 *tw28_fwd, *tw28_inv;  // the same twiddles in the transform's own arithmetic (fr28.cuh)
     Workspace ws;

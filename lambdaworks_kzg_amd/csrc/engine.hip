@@ -299,6 +299,7 @@ static void ctx_destroy(Ctx *c) {
         c->table = nullptr;
         c->direct_table = nullptr;
         c->direct_tab = DirectTable();
+        c->lag = LagrangeForm();
         c->tw_fwd = c->tw_inv = nullptr;
         c->tw28_fwd = c->tw28_inv = nullptr;
     }
@@ -306,6 +307,9 @@ static void ctx_destroy(Ctx *c) {
     dev_free(c->table);
     free_direct_table(c->direct_tab);
     c->direct_table = nullptr;
+    free_direct_table(c->lag.direct_tab);
+    dev_free(c->lag.points);
+    dev_free(c->lag.table);
     dev_free(c->tw_fwd);
     dev_free(c->tw_inv);
     dev_free(c->tw28_fwd);
@@ -399,6 +403,9 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
         c->direct_tab.win_dev = twin_of->direct_tab.win_dev;  // (addresses only: the windows belong to the primary context)
         c->direct_bits = twin_of->direct_bits;
         c->direct_row_bytes = twin_of->direct_row_bytes;
+        c->lag = twin_of->lag;
+        c->lag.direct_tab = DirectTable();
+        c->lag.direct_tab.win_dev = twin_of->lag.direct_tab.win_dev;  // (addresses only)
         c->tw_fwd = twin_of->tw_fwd;
         c->tw_inv = twin_of->tw_inv;
         c->tw28_fwd = twin_of->tw28_fwd;
@@ -581,41 +588,71 @@ Ctx *ctx_of(const KZGSettings *s) {
 // work in disjoint slices of the same workspace.
 // `shared_chip`: latency-chain kernels of the same call run beside this MSM (the fused commit-and-prove's hash): finer
 // workgroups, as when the settings' other context is busy, so that the compute units they sit on do not set the launch's end
-static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0, bool shared_chip = false) {
+// `lagrange`: the scalars are evaluations on the bit-reversed domain and the MSM runs over the Lagrange form of the setup
+static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0, bool shared_chip = false,
+                                bool lagrange = false) {
     Workspace &w = c->ws;
     uint32_t *sorted = w.sorted + base * (size_t)kMaxEntries;
     uint32_t *bstart = w.bucket_start + base * (size_t)(kNumBuckets + 1);
     uint32_t *perm = w.perm + base * (size_t)(kNumBuckets + 1);
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
     G1Xyzz29 *sums = w.sums + base;
-    if (c->direct_table) {  // opt-in giant-table path: gather + add, nothing else
+    const G1Affine29 *direct = lagrange ? c->lag.direct_table : c->direct_table;
+    if (direct) {  // giant-table path: gather + add, nothing else
         // (scratch of the bucket engine, idle on this path: `buckets` holds the per-lane sums of the hand-scheduled kernel,
         // `sorted` the per-workgroup partial sums, `bstart` the redo flags)
-        launch_direct_msm(c->direct_bits, c->direct_tab.win_dev, c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
+        launch_direct_msm(lagrange ? c->lag.direct_bits : c->direct_bits, lagrange ? c->lag.direct_tab.win_dev : c->direct_tab.win_dev,
+                          lagrange ? c->lag.direct_row_bytes : c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
                           st, (shared_chip || peer_busy(c)) ? 2048 : 0);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
-    launch_bucket_accumulate(c->table, sorted, bstart, perm, buckets, n, st);
+    launch_bucket_accumulate(lagrange ? c->lag.table : c->table, sorted, bstart, perm, buckets, n, st);
     launch_bucket_reduce(buckets, sums, n, st);
     return sums;
 }
 
 static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0,
-                       bool shared_chip = false) {
-    launch_finalize_compress(msm_sums_stage(c, scalars_raw, n, st, base, shared_chip), out48, n, st);
+                       bool shared_chip = false, bool lagrange = false) {
+    launch_finalize_compress(msm_sums_stage(c, scalars_raw, n, st, base, shared_chip, lagrange), out48, n, st);
 }
 
-// blob bytes -> canonical monomial coefficients in ws.scalars (slots base .. base + n)
-static void coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st,
-                               size_t base = 0) {
+// Which form a c-kzg call's MSM runs on. A COMMITMENT's scalars can be had in either form -- the blob's evaluations as they stand,
+// or their coefficients behind the transform --, so it takes the Lagrange form whenever that form has a direct table or the monomial
+// one has none. A PROOF's quotient is computed in coefficient form (Horner / Ruffini); it moves to the Lagrange form, by one forward
+// transform, only when that is where the settings' one direct table is.
+static bool commit_on_lagrange(const Ctx *c, int mode) {
+    return mode == LWKZG_MODE_CKZG && c->lag.ready && (c->lag.direct_table || !c->direct_table);
+}
+static bool proof_on_lagrange(const Ctx *c, int mode) {
+    return mode == LWKZG_MODE_CKZG && c->lag.ready && c->lag.direct_table && !c->direct_table;
+}
+// the quotients in w.scalars2 (slots base ..) -> the form their MSM runs on; returns that form (true = Lagrange). The coefficients
+// in w.scalars (same slots) are dead by now and serve as scratch.
+static bool quotient_to_msm_form(Ctx *c, int mode, size_t n, hipStream_t st, size_t base = 0) {
+    if (!proof_on_lagrange(c, mode)) return false;
+    Workspace &w = c->ws;
+    const size_t so = base * (size_t)kBlobElems;
+    launch_coefficients_to_evaluations(w.scalars2 + so * 8, w.fr + so, (Fr *)(w.scalars + so * 8), c->tw28_fwd, n, st);
+    return true;
+}
+
+// blob bytes -> the scalars of an MSM in ws.scalars (slots base .. base + n): canonical monomial coefficients, or -- c-kzg mode,
+// `evaluations_ok` (the caller only commits) and a usable Lagrange form -- the blob's own evaluations, copied and range-checked with
+// no transform at all. Returns true in that case: the MSM must then run on the Lagrange form.
+static bool coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st,
+                               size_t base = 0, bool evaluations_ok = false) {
     Workspace &w = c->ws;
     uint32_t *scalars = w.scalars + base * (size_t)kBlobElems * 8;
     if (mode == LWKZG_MODE_REFERENCE) {
         launch_parse_be_reduce(blobs, scalars, n * kBlobElems, st);
+    } else if (evaluations_ok && commit_on_lagrange(c, mode)) {
+        launch_copy_le_check(blobs, scalars, status, n, st);
+        return true;
     } else {
         launch_blob_evaluations_to_coefficients(blobs, scalars, c->tw28_inv, status, n, st);
     }
+    return false;
 }
 
 // sub-batches per launch set. The bucket path gains from two (its sort / reduce / inversion tails hide behind the
@@ -648,10 +685,10 @@ C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         int32_t *stt = status ? status + off : c->ws.status;
         LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
-        const int ways = m >= 256 ? split_ways(c->direct_table != nullptr) : 1;
+        const int ways = m >= 256 ? split_ways((commit_on_lagrange(c, mode) ? c->lag.direct_table : c->direct_table) != nullptr) : 1;
         if (ways == 1) {
-            coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
-            msm_stages(c, c->ws.scalars, out48 + 48 * off, m, st);
+            const bool lg = coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st, 0, true);
+            msm_stages(c, c->ws.scalars, out48 + 48 * off, m, st, 0, false, lg);
             continue;
         }
         LWK_HIP(hipEventRecord(c->ev_fork, st));
@@ -659,8 +696,8 @@ C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size
             size_t lo = m * k / ways, hi = m * (k + 1) / ways;
             hipStream_t sk = c->aux[k];
             LWK_HIP(hipStreamWaitEvent(sk, c->ev_fork, 0));
-            coefficients_stage(c, blobs + (off + lo) * (size_t)kBlobBytes, hi - lo, mode, stt + lo, sk, lo);
-            msm_stages(c, c->ws.scalars + lo * (size_t)kBlobElems * 8, out48 + 48 * (off + lo), hi - lo, sk, lo);
+            const bool lg = coefficients_stage(c, blobs + (off + lo) * (size_t)kBlobBytes, hi - lo, mode, stt + lo, sk, lo, true);
+            msm_stages(c, c->ws.scalars + lo * (size_t)kBlobElems * 8, out48 + 48 * (off + lo), hi - lo, sk, lo, false, lg);
             LWK_HIP(hipEventRecord(c->ev_join[k], sk));
             LWK_HIP(hipStreamWaitEvent(st, c->ev_join[k], 0));
         }
@@ -758,7 +795,7 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt + off, st);
         launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
-        G1Xyzz29 *sums = msm_sums_stage(c, w.scalars2, m, st);
+        G1Xyzz29 *sums = msm_sums_stage(c, w.scalars2, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
         if (heavy_serial && off + kMaxChunk >= n) {  // the last accumulation is in the queue: the other context's phase may follow it
             std::lock_guard<std::mutex> hk(pr->heavy_mu);
             LWK_HIP(hipEventRecord(pr->heavy_done, st));
@@ -796,12 +833,17 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
     for (size_t off = 0; off < n; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         const uint8_t *b = blobs + off * (size_t)kBlobBytes;
-        coefficients_stage(c, b, m, mode, stt + off, st);
-        msm_stages(c, w.scalars, comm_out48 + 48 * off, m, st, 0, off == 0);  // the first one has the hash beside it
+        coefficients_stage(c, b, m, mode, stt + off, st);  // (coefficients: the quotient needs them)
+        if (proof_on_lagrange(c, mode)) {  // the only direct table is the Lagrange one: the commitment comes from the evaluations as they stand
+            launch_copy_le_check(b, (uint32_t *)w.fr, nullptr, m, st);
+            msm_stages(c, (const uint32_t *)w.fr, comm_out48 + 48 * off, m, st, 0, off == 0, true);
+        } else {
+            msm_stages(c, w.scalars, comm_out48 + 48 * off, m, st, 0, off == 0);  // the first one has the hash beside it
+        }
         if (off == 0) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge_finish(b, comm_out48 + 48 * off, mid + 8 * off, z + off, le, m, st);
         launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
-        msm_stages(c, w.scalars2, proof_out48 + 48 * off, m, st);
+        msm_stages(c, w.scalars2, proof_out48 + 48 * off, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
     }
     return C_KZG_OK;
 }
@@ -819,7 +861,7 @@ C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const
         coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
         launch_z_from_bytes(z32 + 32 * off, w.z, stt, le, m, st);
         launch_eval_quotient(w.scalars, w.z, w.scalars2, y32 + 32 * off, le, m, st);
-        msm_stages(c, w.scalars2, proof48 + 48 * off, m, st);
+        msm_stages(c, w.scalars2, proof48 + 48 * off, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
     }
     return C_KZG_OK;
 }
@@ -1260,12 +1302,21 @@ int lwkzg_get_mode(void) { return mode_now(); }
 
 // Per-settings semantics: a settings object that was given a mode of its own answers in it whatever the process-wide
 // default says (-1 gives it back to the default); every entry point resolves its mode ONCE, when it is entered.
+// An explicit mode for a settings object also brings its tables to that mode's form (settings_follow_mode below): the first switch
+// to c-kzg mode derives the Lagrange form (about 50 ms) and builds a Lagrange direct table beside the monomial one if it fits (the
+// default engine: 0.2-0.3 s, 41 GB more); when the two do not fit side by side (15 / 16 bits) the ONE table is rebuilt in the new
+// mode's form -- the cost of a lwkzg_enable_direct_table call of that width (0.9 s of kernels at 16 bits plus whatever hipMalloc
+// waits for). Nothing happens when the tables already suit the mode. The process-wide default (lwkzg_set_mode) never moves a table.
+static void settings_follow_mode(Ctx *c, int mode);
+static void ensure_lagrange(Ctx *c, int mode);
 int lwkzg_settings_set_mode(const KZGSettings *s, int mode) {
     if (mode != LWKZG_MODE_REFERENCE && mode != LWKZG_MODE_CKZG && mode != -1) return -1;
     Ctx *c = ctx_of(s);  // hand-built settings get their context here
     if (!c) return -1;
     const int prev = lwk::mode_of(s);
     c->mode_override.store(mode, std::memory_order_relaxed);
+    const int now = lwk::mode_of(s);
+    if (now != prev && gpu_available()) settings_follow_mode(c, now);
     return prev;
 }
 int lwkzg_settings_get_mode(const KZGSettings *s) { return lwk::mode_of(s); }
@@ -1647,8 +1698,8 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
                                     hipMemcpyHostToDevice, sk) == hipSuccess;
             ok = ok && hipMemsetAsync(w.status + lo, 0, n * 4, sk) == hipSuccess;
             if (ok) {
-                coefficients_stage(c, d_blobs, n, mode, w.status + lo, sk, lo);
-                msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, n, sk, lo);
+                const bool lg = coefficients_stage(c, d_blobs, n, mode, w.status + lo, sk, lo, true);
+                msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, n, sk, lo, false, lg);
                 ok = hipMemcpyAsync(cb.pinned_out[lane], w.out48 + 48 * lo, n * 48, hipMemcpyDeviceToHost, sk) == hipSuccess &&
                      hipMemcpyAsync(cb.pinned_status[lane], w.status + lo, n * 4, hipMemcpyDeviceToHost, sk) == hipSuccess;
             }
@@ -1698,6 +1749,7 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
     if (!out || !blobs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    ensure_lagrange(c, mode);
     if (n == 1) {  // the reference's symbol: merged with the other callers of the moment
         C_KZG_RET rc1;
         uint8_t tmp[48];
@@ -1755,14 +1807,14 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
     LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
     size_t k = 0;
     for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
-        cnt = slice_len(k, n - off, n, c->direct_table != nullptr);
+        cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
         const size_t lo = (k % 2) * kSlice;
         hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
         LWK_HIP(hipMemcpyAsync(d_blobs, (const uint8_t *)(blobs + off), cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
         LWK_HIP(hipMemsetAsync(d_status_all + off, 0, cnt * 4, sk));
-        coefficients_stage(c, d_blobs, cnt, mode, d_status_all + off, sk, lo);
-        msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, d_out_all + 48 * off, cnt, sk, lo);
+        const bool lg = coefficients_stage(c, d_blobs, cnt, mode, d_status_all + off, sk, lo, true);
+        msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, d_out_all + 48 * off, cnt, sk, lo, false, lg);
     }
     for (int j = 0; j < 2; j++) {
         LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
@@ -1842,7 +1894,7 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
     LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
     size_t k = 0;
     for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
-        cnt = slice_len(k, n - off, n, c->direct_table != nullptr);
+        cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
         const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
         hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
@@ -1850,7 +1902,7 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
         coefficients_stage(c, d_blobs, cnt, mode, d_status + off, sk, lo);
         launch_z_from_bytes(d_z + 32 * off, w.z + lo, d_status + off, le, cnt, sk);
         launch_eval_quotient(w.scalars + so, w.z + lo, w.scalars2 + so, d_y + 32 * off, le, cnt, sk);
-        msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo);
+        msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo, false, quotient_to_msm_form(c, mode, cnt, sk, lo));
     }
     for (int j = 0; j < 2; j++) {
         LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
@@ -1907,7 +1959,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
     bool validated = false;
     size_t k = 0;
     for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
-        cnt = slice_len(k, n - off, n, c->direct_table != nullptr);
+        cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
         const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
         hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
@@ -1936,7 +1988,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
             launch_challenge(d_blobs, d_canon + 48 * off, w.z + lo, le, cnt, sk);
         }
         launch_eval_quotient(w.scalars + so, w.z + lo, w.scalars2 + so, nullptr, le, cnt, sk);
-        msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo);
+        msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo, false, quotient_to_msm_form(c, mode, cnt, sk, lo));
     }
     for (int j = 0; j < 2; j++) {
         LWK_HIP(hipEventRecord(c->ev_join[j], c->aux[j]));
@@ -2043,6 +2095,7 @@ static C_KZG_RET blob_proof_batch_impl(KZGProof *out, const Blob *blobs, const B
     if (!out || !blobs || !commitments) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    ensure_lagrange(c, mode);
     if (n == 1) {  // the reference's symbol: merged with the other callers of the moment
         if (coalesce_singles()) {
             C_KZG_RET rc1 = combine_blob_proof(c, out, blobs, commitments, mode);
@@ -2104,7 +2157,7 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
         LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
         launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
-        msm_stages(c, w.scalars2, w.out48, m, st);
+        msm_stages(c, w.scalars2, w.out48, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
         if (!host_validate) {
             // (a device-to-host copy into pageable memory blocks this thread until the stream has reached it: the
             // canonical bytes are fetched only now that everything else has been submitted)
@@ -2117,8 +2170,9 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
             // status): redo the chunk with the hash taken over the canonical bytes on the GPU
             if (host_validate) LWK_HIP(hipMemcpyAsync(w.canon48, h_canon.data(), m * 48, hipMemcpyHostToDevice, st));
             launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
+            coefficients_stage(c, w.blobs, m, mode, w.status, st);  // (the first attempt's forward transform may have used them as scratch)
             launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
-            msm_stages(c, w.scalars2, w.out48, m, st);
+            msm_stages(c, w.scalars2, w.out48, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
         }
         std::vector<uint8_t> h_out(m * 48);
         LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
@@ -2135,6 +2189,7 @@ static C_KZG_RET point_proof_batch_impl(KZGProof *proofs_out, Bytes32 *ys_out, c
     if (!proofs_out || !ys_out || !blobs || !zs) return map_rc(C_KZG_BADARGS, mode);
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    ensure_lagrange(c, mode);
     if (n == 1 && coalesce_singles()) {  // the reference's symbol: merged with the other callers of the moment
         C_KZG_RET rc1 = combine_point_proof(c, proofs_out, ys_out, blobs, zs, mode);
         if (rc1 != C_KZG_OK) {
@@ -2247,41 +2302,61 @@ C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int call
     return ctx_reserve(t, max_batch);
 }
 
-// row_pref: 0 = rows aligned to 128-byte lines when that leaves headroom on the device, else packed; or one of the two
-static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size_t row_pref) {
-    Ctx *c = ctx_of(s);
-    if (!c) return C_KZG_ERROR;
-    std::lock_guard<std::mutex> lk(c->mu);
-    // the twin context launches against the same table under its own lock: keep it out as well (lock order: main, twin)
-    std::unique_lock<std::mutex> lk_twin;
-    Ctx *const twin = c->twin.load(std::memory_order_acquire);
-    if (twin) lk_twin = std::unique_lock<std::mutex>(twin->mu);
-    LWK_HIP(hipSetDevice(c->device));
-    LWK_HIP(hipDeviceSynchronize());  // the table may be in use on any stream, the callers' included
-    if (window_bits == c->direct_bits) return C_KZG_OK;
-    if (window_bits != 0 && direct_table_entries(window_bits) == 0) {
-        set_error("lwkzg_enable_direct_table: window_bits must be 0 or 10 .. 16 (got %d)", window_bits);
-        return C_KZG_BADARGS;
-    }
-    const int old_bits = c->direct_bits;
-    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_start = wall();
-    free_direct_table(c->direct_tab);  // (the old and the new table need not fit side by side)
-    c->direct_table = nullptr;
-    BuildTiming bt;
-    bt.free_old_ms = wall() - t_start;
-    c->direct_bits = 0;
-    if (twin) {
-        twin->direct_table = nullptr;
-        twin->direct_tab.win_dev = nullptr;
-        twin->direct_bits = 0;
-    }
-    if (window_bits == 0) return C_KZG_OK;
-    // rows aligned to 128-byte lines when that table leaves kDirectAlignedHeadroom of HBM free (workspaces, the caller's
-    // own buffers), packed otherwise; LWKZG_DIRECT_ROW=112|128 forces one (A/B runs)
-    auto build_rows = [&](int bits, size_t row) -> hipError_t {
+// ---- the two forms of the setup and their direct tables --------------------------------------------------------------------------
+//
+// A settings object has its MSM tables in up to two forms: monomial ([tau^i]G: what reference mode commits over, and what a
+// quotient in coefficient form needs) and Lagrange ([l_i(tau)]G: what a c-kzg blob's evaluations commit over with no transform).
+// The 9 MB bucket tables exist in both forms as soon as c-kzg mode is first used; the DIRECT table (7 .. 275 GB) is built
+//   * in the form of the mode the settings answer in when it is built (lwkzg_enable_direct_table, the load's own choice) or are
+//     switched to (lwkzg_settings_set_mode) -- the primary form --,
+//   * and in the other form too whenever that fits beside it with kDirectAlignedHeadroom to spare (always up to 14 bits on an empty
+//     MI355X; never at 15 / 16 bits) and is of use (the Lagrange form only once c-kzg mode has been used).
+// A call never depends on which exist: a c-kzg commitment takes the Lagrange table when there is one, else the transform and the
+// monomial table, else Lagrange buckets; a proof's quotient (coefficient form) takes the monomial table when there is one, else one
+// forward transform and the Lagrange table; reference mode on a Lagrange-only table falls back to the monomial buckets.
+
+// the twin context holds copies of every table address: refresh them (caller holds both contexts' locks)
+static void sync_twin_tables(Ctx *c) {
+    Ctx *t = c->twin.load(std::memory_order_acquire);
+    if (!t) return;
+    t->direct_table = c->direct_table;
+    t->direct_tab.win_dev = c->direct_tab.win_dev;
+    t->direct_bits = c->direct_bits;
+    t->direct_row_bytes = c->direct_row_bytes;
+    t->lag = c->lag;
+    t->lag.direct_tab = DirectTable();
+    t->lag.direct_tab.win_dev = c->lag.direct_tab.win_dev;
+    t->lag_ready.store(c->lag.ready, std::memory_order_release);
+}
+
+struct FormRef {  // one form's direct-table fields
+    const G1Affine *points;
+    DirectTable &tab;
+    G1Affine29 *&table0;
+    int &bits;
+    size_t &row;
+};
+static FormRef form_ref(Ctx *c, bool lagrange) {
+    if (lagrange) return {c->lag.points, c->lag.direct_tab, c->lag.direct_table, c->lag.direct_bits, c->lag.direct_row_bytes};
+    return {c->points, c->direct_tab, c->direct_table, c->direct_bits, c->direct_row_bytes};
+}
+static void form_drop(Ctx *c, bool lagrange) {
+    FormRef f = form_ref(c, lagrange);
+    free_direct_table(f.tab);
+    f.table0 = nullptr;
+    f.bits = 0;
+}
+
+// one form's direct table of `bits`: rows aligned to 128-byte lines when that table leaves kDirectAlignedHeadroom of HBM free
+// (workspaces, the caller's own buffers), packed otherwise; LWKZG_DIRECT_ROW=112|128 or row_pref forces one (A/B runs).
+// need_headroom: 1 = build only if even the packed table leaves the headroom (a secondary form somebody asked for must not crowd the
+// device); 2 = only if it takes at most a quarter of what is free now (the rule the load picks its own table by: a second table
+// nobody asked for -- the first c-kzg call of a settings object that follows the process default -- gets no more than the first did).
+static hipError_t form_build(Ctx *c, bool lagrange, int bits, size_t row_pref, int need_headroom, BuildTiming &bt) {
+    FormRef f = form_ref(c, lagrange);
+    auto build_rows = [&](size_t row) -> hipError_t {
         double ms[4] = {0, 0, 0, 0};
-        const hipError_t e = build_direct_table(bits, c->points, c->direct_tab, row, c->stream, ms);
+        const hipError_t e = build_direct_table(bits, f.points, f.tab, row, c->stream, ms);
         bt.scratch_malloc_ms += ms[0];
         bt.table_malloc_ms += ms[1];
         bt.kernels_ms += ms[2];
@@ -2290,79 +2365,232 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
             (void)hipGetLastError();  // an out-of-memory here is an answer, not a sticky failure
             return e;
         }
-        c->direct_table = (G1Affine29 *)c->direct_tab.win[0];
-        c->direct_bits = bits;
-        c->direct_row_bytes = row;
+        f.table0 = (G1Affine29 *)f.tab.win[0];
+        f.bits = bits;
+        f.row = row;
         bt.bits = bits;
         bt.row_bytes = row;
-        bt.table_bytes = direct_table_entries(bits) * row;
-        if (twin) {
-            twin->direct_table = c->direct_table;
-            twin->direct_tab.win_dev = c->direct_tab.win_dev;
-            twin->direct_bits = bits;
-            twin->direct_row_bytes = row;
-        }
+        bt.table_bytes += direct_table_entries(bits) * row;
         return hipSuccess;
     };
-    auto build = [&](int bits) -> hipError_t {
-        static const int forced_env = getenv("LWKZG_DIRECT_ROW") ? atoi(getenv("LWKZG_DIRECT_ROW")) : 0;
-        const int forced = forced_env ? forced_env : (int)row_pref;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
-        const bool aligned_fits = direct_table_entries(bits) * kDirectRowAligned + kDirectAlignedHeadroom <= free_b;
-        if (forced == (int)kDirectRowAligned || (forced != (int)kDirectRowPacked && aligned_fits))
-            if (build_rows(bits, kDirectRowAligned) == hipSuccess) return hipSuccess;
-        return build_rows(bits, kDirectRowPacked);
-    };
-    const hipError_t e = build(window_bits);
+    static const int forced_env = getenv("LWKZG_DIRECT_ROW") ? atoi(getenv("LWKZG_DIRECT_ROW")) : 0;
+    const int forced = forced_env ? forced_env : (int)row_pref;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
+    if (need_headroom && direct_table_entries(bits) * kDirectRowPacked + kDirectAlignedHeadroom > free_b) return hipErrorOutOfMemory;
+    if (need_headroom == 2 && direct_table_entries(bits) * kDirectRowPacked > free_b / 4) return hipErrorOutOfMemory;
+    const bool aligned_fits = direct_table_entries(bits) * kDirectRowAligned + kDirectAlignedHeadroom <= free_b;
+    if (forced == (int)kDirectRowAligned || (forced != (int)kDirectRowPacked && aligned_fits))
+        if (build_rows(kDirectRowAligned) == hipSuccess) return hipSuccess;
+    return build_rows(kDirectRowPacked);
+}
+
+// The Lagrange form of the setup, derived on the device: the 4096 rows of inverse-DFT coefficients (k_idft_columns) committed by
+// the monomial engine as it stands, the results decompressed into affine points, the bucket engine's table built over them.
+// About 50 ms on the default engine. Caller holds the primary context's lock and its twin's.
+static C_KZG_RET lagrange_prepare(Ctx *c) {
+    if (c->lag.ready) return C_KZG_OK;
+    if (c->lag_failed) return C_KZG_MALLOC;
+    LWK_HIP(hipSetDevice(c->device));
+    C_KZG_RET rc = ctx_reserve(c, kMaxChunk);
+    if (rc != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    hipStream_t st = c->stream;
+    WsUse wsu(c, st);
+    uint8_t *d_comp = nullptr;
+    int32_t *d_status = nullptr;
+    bool ok = hipMalloc((void **)&c->lag.points, (size_t)kBlobElems * sizeof(G1Affine)) == hipSuccess &&
+              hipMalloc((void **)&c->lag.table, (size_t)kTablePoints * sizeof(G1Affine29)) == hipSuccess &&
+              hipMalloc((void **)&d_comp, (size_t)kBlobElems * 48) == hipSuccess && hipMalloc((void **)&d_status, (size_t)kBlobElems * 4) == hipSuccess;
+    std::vector<int32_t> h_status(kBlobElems, 0);
+    if (ok) {
+        for (size_t off = 0; off < (size_t)kBlobElems; off += kMaxChunk) {
+            launch_idft_columns(w.scalars, c->tw_inv, (uint32_t)off, kMaxChunk, st);
+            msm_stages(c, w.scalars, d_comp + 48 * off, kMaxChunk, st);   // over the monomial form, on whatever engine it has
+        }
+        launch_g1_decompress(d_comp, c->lag.points, d_status, kBlobElems, 0, st);  // (our own sums: in the subgroup by construction)
+        launch_build_table(c->lag.points, c->lag.table, st);
+        ok = hipMemcpyAsync(h_status.data(), d_status, (size_t)kBlobElems * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (d_comp) hipFree(d_comp);
+    if (d_status) hipFree(d_status);
+    for (int i = 0; ok && i < kBlobElems; i++)
+        if (h_status[i] != 0) ok = false;  // (an l_i(tau) G at infinity: tau would have to be a root of l_i, i.e. a domain point)
+    if (!ok) {
+        (void)hipGetLastError();
+        dev_free(c->lag.points);
+        dev_free(c->lag.table);
+        c->lag_failed = true;
+        set_error("the Lagrange form of the setup could not be derived (out of device memory, or tau is a 4096th root of unity): c-kzg mode stays on the transform");
+        return C_KZG_MALLOC;
+    }
+    c->lag.ready = true;
+    c->lag_ready.store(true, std::memory_order_release);
+    return C_KZG_OK;
+}
+
+// Bring the tables to what mode `mode` wants (see the block comment above). `may_swap`: when the mode's form has no direct table,
+// the other has one and the two do not fit side by side, move the table over (explicit requests: lwkzg_settings_set_mode,
+// lwkzg_enable_direct_table); lazily (first c-kzg call of a settings object that follows the process-wide default) only the
+// free-of-charge secondary build is tried. Caller holds the primary context's lock and its twin's; the device is idle.
+static void tables_follow_mode(Ctx *c, int mode, bool may_swap) {
+    const bool want_lag = mode == LWKZG_MODE_CKZG;
+    if (want_lag && lagrange_prepare(c) != C_KZG_OK) return;
+    const int bits = c->direct_bits ? c->direct_bits : c->lag.direct_bits;
+    if (!bits) return;                                     // bucket engine: both forms have their 9 MB tables
+    FormRef mine = form_ref(c, want_lag);
+    if (mine.bits == bits) return;
+    BuildTiming bt;
+    if (form_build(c, want_lag, bits, 0, may_swap ? 1 : 2, bt) == hipSuccess) return;  // fits beside the other: both forms live
+    if (!may_swap) return;
+    form_drop(c, !want_lag);
+    if (form_build(c, want_lag, bits, 0, 0, bt) != hipSuccess) (void)form_build(c, !want_lag, bits, 0, 0, bt);  // (cannot happen: the other form's table just left)
+    c->last_build = bt;
+}
+
+// Called by every compute entry point before it takes its context: a settings object answering in c-kzg mode gets the Lagrange form
+// on first use (and a Lagrange direct table if one fits beside the monomial one). One atomic load afterwards.
+static void ensure_lagrange(Ctx *c, int mode) {
+    if (mode != LWKZG_MODE_CKZG || c->lag_ready.load(std::memory_order_acquire)) return;
+    c = c->primary;
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::unique_lock<std::mutex> lk_twin;
+    Ctx *const twin = c->twin.load(std::memory_order_acquire);
+    if (twin) lk_twin = std::unique_lock<std::mutex>(twin->mu);
+    if (c->lag.ready || c->lag_failed) return;
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return;
+    tables_follow_mode(c, mode, false);
+    hipDeviceSynchronize();
+    sync_twin_tables(c);
+}
+
+static void settings_follow_mode(Ctx *c, int mode) {
+    c = c->primary;
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::unique_lock<std::mutex> lk_twin;
+    Ctx *const twin = c->twin.load(std::memory_order_acquire);
+    if (twin) lk_twin = std::unique_lock<std::mutex>(twin->mu);
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return;
+    tables_follow_mode(c, mode, true);
+    hipDeviceSynchronize();
+    sync_twin_tables(c);
+}
+
+// row_pref: 0 = rows aligned to 128-byte lines when that leaves headroom on the device, else packed; or one of the two
+// forms: 0 = by the settings' mode (the rule above); 1 / 2 / 3 = exactly the monomial / the Lagrange / both forms (lwkzg_enable_direct_table_forms)
+static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size_t row_pref, int forms = 0) {
+    Ctx *c = ctx_of(s);
+    if (!c) return C_KZG_ERROR;
+    if (forms < 0 || forms > 3) {
+        set_error("lwkzg_enable_direct_table_forms: forms must be 1 (monomial), 2 (Lagrange) or 3 (both)");
+        return C_KZG_BADARGS;
+    }
+    const int mode = forms == 2 || forms == 3 ? LWKZG_MODE_CKZG : forms == 1 ? LWKZG_MODE_REFERENCE : mode_of(s);
+    std::lock_guard<std::mutex> lk(c->mu);
+    // the twin context launches against the same table under its own lock: keep it out as well (lock order: main, twin)
+    std::unique_lock<std::mutex> lk_twin;
+    Ctx *const twin = c->twin.load(std::memory_order_acquire);
+    if (twin) lk_twin = std::unique_lock<std::mutex>(twin->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    LWK_HIP(hipDeviceSynchronize());  // the table may be in use on any stream, the callers' included
+    const int old_bits = c->direct_bits ? c->direct_bits : c->lag.direct_bits;
+    const int old_forms = (c->direct_table ? 1 : 0) | (c->lag.direct_table ? 2 : 0);
+    if (window_bits == old_bits && (forms == 0 || forms == old_forms || window_bits == 0)) return C_KZG_OK;
+    if (window_bits != 0 && direct_table_entries(window_bits) == 0) {
+        set_error("lwkzg_enable_direct_table: window_bits must be 0 or 10 .. 16 (got %d)", window_bits);
+        return C_KZG_BADARGS;
+    }
+    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = wall();
+    // the primary form: the one the settings' mode commits over (Lagrange only if it can be had)
+    const bool primary_lag = mode == LWKZG_MODE_CKZG && lagrange_prepare(c) == C_KZG_OK;
+    if (forms >= 2 && !primary_lag) return C_KZG_MALLOC;  // (lagrange_prepare has said why)
+    form_drop(c, false);  // (the old and the new tables need not fit side by side)
+    form_drop(c, true);
+    BuildTiming bt;
+    bt.free_old_ms = wall() - t_start;
+    sync_twin_tables(c);
+    if (window_bits == 0) return C_KZG_OK;
+    hipError_t e = form_build(c, primary_lag, window_bits, row_pref, 0, bt);
+    if (e == hipSuccess && forms == 3) e = form_build(c, false, window_bits, row_pref, 0, bt);
+    if (e == hipSuccess && forms == 0 && (primary_lag || c->lag.ready)) (void)form_build(c, !primary_lag, window_bits, row_pref, 1, bt);  // the other form, if it fits beside
+    if (e != hipSuccess) {
+        form_drop(c, false);
+        form_drop(c, true);
+    }
     bt.total_ms = wall() - t_start;
     c->last_build = bt;
     if (e != hipSuccess) {
-        if (old_bits) (void)build(old_bits);  // the engine the settings had stays in place
+        if (old_bits) {  // the engine the settings had stays in place (the form it was in first)
+            BuildTiming scratch;
+            const bool first_lag = old_forms == 2 || (old_forms == 3 && primary_lag);
+            if (form_build(c, first_lag, old_bits, row_pref, 0, scratch) == hipSuccess && old_forms == 3)
+                (void)form_build(c, !first_lag, old_bits, row_pref, 1, scratch);
+        }
+        sync_twin_tables(c);
         set_error("lwkzg_enable_direct_table(%d): %zu bytes: %s", window_bits, direct_table_entries(window_bits) * kDirectRowPacked,
                   hipGetErrorString(e));
         return C_KZG_MALLOC;
     }
+    sync_twin_tables(c);
     return C_KZG_OK;
 }
 
 C_KZG_RET lwkzg_enable_direct_table(const KZGSettings *s, int window_bits) { return enable_direct_table(s, window_bits, 0); }
+C_KZG_RET lwkzg_enable_direct_table_forms(const KZGSettings *s, int window_bits, int forms) {
+    if (forms < 1 || forms > 3) {
+        set_error("lwkzg_enable_direct_table_forms: forms must be 1 (monomial), 2 (Lagrange) or 3 (both)");
+        return C_KZG_BADARGS;
+    }
+    return enable_direct_table(s, window_bits, 0, forms);
+}
 
 int lwkzg_direct_table_bits(const KZGSettings *s) {
     Ctx *c = ctx_of(s);
-    return c ? c->direct_bits : -1;
+    return !c ? -1 : c->direct_bits ? c->direct_bits : c->lag.direct_bits;
+}
+
+// bit 0: a direct table over the monomial form is live; bit 1: one over the Lagrange form (c-kzg mode without the transform)
+int lwkzg_direct_table_forms(const KZGSettings *s) {
+    Ctx *c = ctx_of(s);
+    return !c ? -1 : (c->direct_table ? 1 : 0) | (c->lag.direct_table ? 2 : 0);
 }
 
 int lwkzg_direct_num_windows(int window_bits) { return direct_num_windows(window_bits); }
 
 int lwkzg_direct_row_bytes(const KZGSettings *s) {
     Ctx *c = ctx_of(s);
-    return !c ? -1 : c->direct_table ? (int)c->direct_row_bytes : 0;
+    return !c ? -1 : c->direct_table ? (int)c->direct_row_bytes : c->lag.direct_table ? (int)c->lag.direct_row_bytes : 0;
 }
 
 C_KZG_RET lwkzg_blob_to_kzg_commitment_batch_device(void *out48_dev, const void *blobs_dev, size_t n, const KZGSettings *s,
                                                     void *stream, int32_t *status_dev) {
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    const int mode = mode_of(s);
+    ensure_lagrange(c, mode);
     c = pick_ctx(c, (hipStream_t)stream);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     WsUse wsu(c, st);
-    return commit_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, n, mode_of(s), st, status_dev);
+    return commit_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, n, mode, st, status_dev);
 }
 
 C_KZG_RET lwkzg_compute_blob_kzg_proof_batch_device(void *out48_dev, const void *blobs_dev, const void *commitments48_dev,
                                                     size_t n, const KZGSettings *s, void *stream, int32_t *status_dev) {
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
+    const int mode = mode_of(s);
+    ensure_lagrange(c, mode);
     c = pick_ctx(c, (hipStream_t)stream);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     WsUse wsu(c, st);
     return blob_proof_batch_device(c, (uint8_t *)out48_dev, (const uint8_t *)blobs_dev, (const uint8_t *)commitments48_dev,
-                                   n, mode_of(s), st, status_dev);
+                                   n, mode, st, status_dev);
 }
 
 C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *proofs48_dev, const void *blobs_dev, size_t n,
@@ -2371,13 +2599,15 @@ C_KZG_RET lwkzg_commit_and_prove_batch_device(void *commitments48_dev, void *pro
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
     if (n == 0) return C_KZG_OK;
+    const int mode = mode_of(s);
+    ensure_lagrange(c, mode);
     c = pick_ctx(c, (hipStream_t)stream);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     WsUse wsu(c, st);
     return commit_and_prove_batch_device(c, (uint8_t *)commitments48_dev, (uint8_t *)proofs48_dev, (const uint8_t *)blobs_dev, n,
-                                         mode_of(s), st, status_dev);
+                                         mode, st, status_dev);
 }
 
 // z_i = compute_challenge(blob_i, commitment_i) (src/utils.rs:120-154) for device-resident blobs, as 32 bytes in the

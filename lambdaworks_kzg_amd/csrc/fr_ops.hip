@@ -316,6 +316,100 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
                        z_mont, (uint4 *)quot_raw, y_out, le);
 }
 
+// ---- c-kzg mode without the transform: the Lagrange form of the setup ------------------------------------------
+//
+// L_i = [l_i(tau)]G, l_i the Lagrange polynomial of the domain point w_i = w^bitrev12(i), is the commitment of l_i's MONOMIAL
+// coefficients c_(i,k) = w_i^(-k) / 4096 -- a column of the inverse DFT matrix -- over the monomial setup, so the 4096 points are 4096
+// commitments of the existing engine (engine.hip: lagrange_prepare). This kernel writes those 4096 "blobs" of coefficients, in the
+// canonical raw form the MSM's digit extraction reads: row b of the output = l_(first + b). One workgroup per row, 16 consecutive
+// powers per thread (a 12-step square-and-multiply to the thread's first power, then 15 products).
+__global__ __launch_bounds__(256) void k_idft_columns(uint4 *__restrict__ coeffs_raw, const Fr *__restrict__ tw_inv, uint32_t first, Fr ninv) {
+    const uint32_t i = first + blockIdx.x, t = threadIdx.x;
+    const uint32_t e = __brev(i) >> 20;                                   // w_i = w^e
+    const Fr base = e < kBlobElems / 2 ? tw_inv[e] : neg(tw_inv[e - kBlobElems / 2]);   // w^-e  (w^(-e - 2048) = -w^-e)
+    // base^(16 t): t < 256 -> exponent bits 4 .. 11
+    Fr b16 = base;
+#pragma unroll
+    for (int k = 0; k < 4; k++) b16 = sqr(b16);
+    Fr cur = ninv, pw = b16;
+    for (uint32_t bits = t; bits; bits >>= 1) {
+        if (bits & 1u) cur = cur * pw;
+        pw = sqr(pw);
+    }
+    uint4 *out = coeffs_raw + ((size_t)blockIdx.x * kBlobElems + (size_t)t * 16) * 2;
+#pragma unroll 1
+    for (int k = 0; k < 16; k++) {
+        uint32_t raw[8];
+        fe_to_raw<FrParams>(raw, cur);
+        out[2 * k] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+        out[2 * k + 1] = make_uint4(raw[4], raw[5], raw[6], raw[7]);
+        cur = cur * base;
+    }
+}
+
+void launch_idft_columns(uint32_t *coeffs_raw, const Fr *tw_inv, uint32_t first, size_t n_rows, hipStream_t st) {
+    ProfScope p("k_idft_columns", st);
+    uint32_t n4096[8] = {4096, 0, 0, 0, 0, 0, 0, 0};
+    const Fr ninv = inv(fe_from_raw<FrParams>(n4096));                    // 1 / 4096 (Montgomery form), on the host
+    hipLaunchKernelGGL(k_idft_columns, dim3((unsigned)n_rows), dim3(256), 0, st, (uint4 *)coeffs_raw, tw_inv, first, ninv);
+}
+
+// c-kzg blobs on the Lagrange form: the canonical little-endian elements ARE the scalars the MSM reads (32-bit words, least
+// significant first), so "parsing" is a copy with the range check of the c-kzg front end (an element >= r: status[blob] = BADARGS)
+__global__ __launch_bounds__(256) void k_copy_le_check(const uint4 *__restrict__ blobs, uint4 *__restrict__ scalars_raw,
+                                                       int32_t *__restrict__ status, size_t n_elems) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elems) return;
+    const uint4 lo = blobs[2 * i], hi = blobs[2 * i + 1];
+    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (status && raw_geq<8>(s, FrParams::MOD)) status[i / kBlobElems] = kStatusBadArgs;
+    scalars_raw[2 * i] = lo;
+    scalars_raw[2 * i + 1] = hi;
+}
+
+void launch_copy_le_check(const uint8_t *blobs, uint32_t *scalars_raw, int32_t *status, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_copy_le_check", st);
+    const size_t n = n_blobs * kBlobElems;
+    hipLaunchKernelGGL(k_copy_le_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)blobs, (uint4 *)scalars_raw, status, n);
+}
+
+// Quotients of a proof call whose MSM runs on the Lagrange form while the quotient was computed in coefficient form (a Lagrange-form
+// table with no monomial table beside it): coefficients -> evaluations on the bit-reversed domain, i.e. a forward transform. Entry:
+// canonical raw coefficient k -> Montgomery form at position bitrev(k) (the transform is decimation in time); exit: Montgomery
+// evaluation at w^j -> canonical raw at position bitrev(j).
+__global__ __launch_bounds__(256) void k_raw_to_mont_bitrev(const uint4 *__restrict__ in_raw, Fr *__restrict__ out, size_t n) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t i = (uint32_t)(g & (kBlobElems - 1)), r = __brev(i) >> 20;
+    const uint4 lo = in_raw[2 * g], hi = in_raw[2 * g + 1];
+    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    out[(g - i) + r] = fe_from_raw<FrParams>(s);
+}
+__global__ __launch_bounds__(256) void k_mont_to_raw_bitrev(const Fr *__restrict__ in, uint4 *__restrict__ out_raw, size_t n) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t i = (uint32_t)(g & (kBlobElems - 1)), r = __brev(i) >> 20;
+    uint32_t s[8];
+    fe_to_raw<FrParams>(s, in[g]);
+    const size_t o = (g - i) + r;
+    out_raw[2 * o] = make_uint4(s[0], s[1], s[2], s[3]);
+    out_raw[2 * o + 1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// coeffs_raw (in place) <- evaluations on the bit-reversed domain; `scratch`, `scratch2`: n_blobs x 4096 Fr each
+void launch_coefficients_to_evaluations(uint32_t *coeffs_raw, Fr *scratch, Fr *scratch2, const Fr28 *tw28_fwd, size_t n_blobs, hipStream_t st) {
+    const size_t n = n_blobs * kBlobElems;
+    {
+        ProfScope p("k_raw_to_mont_bitrev", st);
+        hipLaunchKernelGGL(k_raw_to_mont_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)coeffs_raw, scratch, n);
+    }
+    launch_ntt4096(scratch, scratch2, tw28_fwd, 0, n_blobs, st);
+    {
+        ProfScope p("k_mont_to_raw_bitrev", st);
+        hipLaunchKernelGGL(k_mont_to_raw_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Fr *)scratch2, (uint4 *)coeffs_raw, n);
+    }
+}
+
 // Montgomery Fr -> 32 bytes in the requested byte order, one lane each (z of a batch going back to the host)
 __global__ __launch_bounds__(64) void k_fr_mont_to_bytes(const Fr *__restrict__ in, uint8_t *__restrict__ out, int le,
                                                          size_t n) {

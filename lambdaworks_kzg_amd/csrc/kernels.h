@@ -90,6 +90,12 @@ void launch_ntt4096(const Fr *in, Fr *out, const Fr28 *tw28, int inverse_scale_t
 void launch_blob_evaluations_to_coefficients(const uint8_t *blobs, uint32_t *coeffs_raw, const Fr28 *tw28_inv, int32_t *status,
                                              size_t n_blobs, hipStream_t st);
 void launch_bitrev_permute(const Fr *in, Fr *out, size_t n_blobs, hipStream_t st);
+// c-kzg mode on the Lagrange form of the setup (fr_ops.hip): the 4096 rows of inverse-DFT coefficients whose
+// commitments are the Lagrange points; the copy + range check that replaces the transform in front of a commitment; and the forward
+// transform of a proof's quotient when only the Lagrange-form table exists
+void launch_idft_columns(uint32_t *coeffs_raw, const Fr *tw_inv, uint32_t first, size_t n_rows, hipStream_t st);
+void launch_copy_le_check(const uint8_t *blobs, uint32_t *scalars_raw, int32_t *status, size_t n_blobs, hipStream_t st);
+void launch_coefficients_to_evaluations(uint32_t *coeffs_raw, Fr *scratch, Fr *scratch2, const Fr28 *tw28_fwd, size_t n_blobs, hipStream_t st);
 void launch_fr_be_to_mont(const uint8_t *in_be, Fr *out, size_t n_elems, hipStream_t st);
 void launch_fr_mont_to_be(const Fr *in, uint8_t *out_be, size_t n_elems, hipStream_t st);
 void launch_raw_to_be(const uint32_t *raw, uint8_t *out_be, size_t n_elems, hipStream_t st);
