@@ -333,9 +333,11 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         ntt_ms = kern.get("k_ntt4096", {}).get("avg_ms", 0.0)
         ntt_traffic = ntt_traffic_source = None
         try:   # committed PMC passes over the all-legs run (tools/pmc_traffic_all.py): every k_ntt4096 launch there is this one
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_all_legs.json")))
+            import glob
+            src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic_all_legs.json")))[-1]     # the latest round's
+            pmc = json.load(open(src))
             ntt_traffic = pmc["kernels"]["k_ntt4096"]["largest_launch_traffic_bytes"]
-            ntt_traffic_source = "profiles/r03_pmc_traffic_all_legs.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in this run"
+            ntt_traffic_source = "profiles/%s: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, NOT measured in this run" % os.path.basename(src)
         except Exception:
             pass
         launches_per_step = max(1, round(kern.get("k_ntt4096", {}).get("launches", steps) / steps))

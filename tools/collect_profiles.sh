@@ -6,20 +6,24 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
-python bench.py > $O/bench_line.json 2> $O/bench_err.txt
-python bench.py --force-dist --steps 10 --no-cpu-baseline --no-extra-legs > $O/bench_line_force_dist.json 2>> $O/bench_err.txt
-LWKZG_DIRECT_ASM=0 python bench.py --no-cpu-baseline --no-config-legs > $O/bench_line_compiler_scheduled_arm.json 2>> $O/bench_err.txt
-python bench.py --scalars full --no-cpu-baseline --no-extra-legs > $O/bench_line_full_range_scalars.json 2>> $O/bench_err.txt
-python bench.py --mode ckzg --no-cpu-baseline --no-extra-legs > $O/bench_line_ckzg_mode.json 2>> $O/bench_err.txt
-python bench.py --op blob_proof --batch 256 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
-python bench.py --op blob_proof --batch 1024 --no-cpu-baseline > $O/bench_line_blob_proof_b1024.json 2>> $O/bench_err.txt
-python bench.py --op blob_proof --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_blob_proof_b4096.json 2>> $O/bench_err.txt
-python bench.py --op blob_proof --batch 256 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b256_two_streams.json 2>> $O/bench_err.txt
-python bench.py --op blob_proof --batch 1024 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b1024_two_streams.json 2>> $O/bench_err.txt
-python bench.py --op commit_prove --batch 256 --no-cpu-baseline > $O/bench_line_commit_prove_b256.json 2>> $O/bench_err.txt
-python bench.py --op commit_prove --batch 1024 --no-cpu-baseline > $O/bench_line_commit_prove_b1024.json 2>> $O/bench_err.txt
-python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_verify_batch_b4096.json 2>> $O/bench_err.txt
-python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail.json python bench.py > $O/bench_line.json 2> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_force_dist.json python bench.py --force-dist --steps 10 --no-cpu-baseline --no-extra-legs > $O/bench_line_force_dist.json 2>> $O/bench_err.txt
+LWKZG_DIRECT_ASM=0 LWKZG_BENCH_DETAIL=$O/bench_detail_compiler_scheduled_arm.json python bench.py --no-cpu-baseline --no-config-legs > $O/bench_line_compiler_scheduled_arm.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_full_range_scalars.json python bench.py --scalars full --no-cpu-baseline --no-extra-legs > $O/bench_line_full_range_scalars.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_ckzg_mode.json python bench.py --mode ckzg --no-cpu-baseline --no-extra-legs > $O/bench_line_ckzg_mode.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256.json python bench.py --op blob_proof --batch 256 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b1024.json python bench.py --op blob_proof --batch 1024 --no-cpu-baseline > $O/bench_line_blob_proof_b1024.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b4096.json python bench.py --op blob_proof --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_blob_proof_b4096.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256_two_streams.json python bench.py --op blob_proof --batch 256 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b256_two_streams.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b1024_two_streams.json python bench.py --op blob_proof --batch 1024 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b1024_two_streams.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_commit_prove_b256.json python bench.py --op commit_prove --batch 256 --no-cpu-baseline > $O/bench_line_commit_prove_b256.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_commit_prove_b1024.json python bench.py --op commit_prove --batch 1024 --no-cpu-baseline > $O/bench_line_commit_prove_b1024.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_verify_batch_b4096.json python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_verify_batch_b4096.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_tiled_msm.json python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_bucket_compiler_arm.json LWKZG_BUCKET_ASM=0 python bench.py --direct-bits 0 --no-cpu-baseline --no-config-legs > $O/bench_line_bucket_compiler_arm.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_bucket.json python bench.py --direct-bits 0 --no-cpu-baseline --no-config-legs > $O/bench_line_bucket.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_default_engine.json python bench.py --direct-bits default --no-cpu-baseline --no-config-legs > $O/bench_line_default_engine.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_gpus2_gloo.json python bench.py --gpus 2 --backend gloo --steps 5 --no-cpu-baseline --no-extra-legs --direct-bits 13 > $O/bench_line_gpus2_gloo_one_device.json 2>> $O/bench_err.txt
 # per-kernel time of the headline command, of the default engine and of the bucket engine
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_line.json 2> $O/kt_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_all -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_all_line.json 2> $O/kt_all_err.txt
@@ -54,6 +58,7 @@ unset LWKZG_DIRECT_ASM
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_bucket -o sq -- $P --direct-bits 0 > $O/pmc_sq_bucket_line.json 2> $O/pmc_sq_bucket_err.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm_bucket -o grbm -- $P --direct-bits 0 > $O/pmc_grbm_bucket_line.json 2> $O/pmc_grbm_bucket_err.txt
 python tools/host_api_timing.py > $O/host_api_timing.txt 2>&1
+python tools/single_blob_timing.py > $O/single_blob_timing.txt 2>&1
 python tools/config_sweep.py --direct-bits 16 > $O/config_sweep_direct16.json 2> $O/sweep_err.txt
 python tools/config_sweep.py --direct-bits default > $O/config_sweep_default.json 2>> $O/sweep_err.txt
 python tools/config_sweep.py --direct-bits 0 --max-verify 1024 > $O/config_sweep_bucket.json 2>> $O/sweep_err.txt

@@ -2,11 +2,17 @@
 # Copies what tools/collect_profiles.sh left under gpurun_out/final into profiles/ (tracked), keeping only our kernels' rows.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/final; P=profiles; TAG=${1:-r03}
+O=gpurun_out/final; P=profiles; TAG=${1:-r04}
 for f in bench_line bench_line_force_dist bench_line_compiler_scheduled_arm bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
-         bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm; do
+         bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm \
+         bench_line_bucket bench_line_bucket_compiler_arm bench_line_default_engine bench_line_gpus2_gloo_one_device; do
   [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${TAG}_$f.json
 done
+# the detail files (every note, breakdown and per-kernel table of the runs above)
+for f in bench_detail bench_detail_compiler_scheduled_arm bench_detail_bucket bench_detail_bucket_compiler_arm bench_detail_default_engine bench_detail_ckzg_mode; do
+  [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json
+done
+[ -s $O/single_blob_timing.txt ] && grep -v "amdgpu.ids" $O/single_blob_timing.txt > $P/${TAG}_single_blob_timing.txt
 [ -s $O/kt_line.json ] && tail -1 $O/kt_line.json > $P/${TAG}_bench_kernel_stats_run_line.json   # the line the profiled run itself printed
 for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
 grep -v "amdgpu.ids" $O/host_api_timing.txt > $P/${TAG}_host_api_timing.txt || true
@@ -47,7 +53,7 @@ python3 tools/pmc_summary.py $O/fetch/fetch_counter_collection.csv $O/write/writ
 python3 tools/pmc_issue_summary.py k_direct_accumulate $P/${TAG}_issue_summary_compiler_scheduled_arm.json $O/pmc_cpp_sq1/sq_counter_collection.csv $O/pmc_cpp_sq2/sq_counter_collection.csv $O/pmc_cpp_grbm/grbm_counter_collection.csv > /dev/null
 python3 tools/pmc_traffic_all.py $O/fetch_all/fetch_counter_collection.csv $O/write_all/write_counter_collection.csv $TAG > /dev/null
 python3 tools/pmc_issue_summary.py k_direct_accumulate_asm $P/${TAG}_issue_summary.json $O/pmc_sq1/sq_counter_collection.csv $O/pmc_sq2/sq_counter_collection.csv $O/pmc_sq3/sq_counter_collection.csv $O/pmc_grbm/grbm_counter_collection.csv > /dev/null
-python3 tools/pmc_issue_summary.py k_bucket_accumulate $P/${TAG}_issue_summary_bucket.json $O/pmc_sq_bucket/sq_counter_collection.csv $O/pmc_grbm_bucket/grbm_counter_collection.csv > /dev/null
+python3 tools/pmc_issue_summary.py k_bucket_accumulate_asm $P/${TAG}_issue_summary_bucket.json $O/pmc_sq_bucket/sq_counter_collection.csv $O/pmc_grbm_bucket/grbm_counter_collection.csv > /dev/null
 ls $P | grep $TAG | wc -l
 [ -s $O/kt_two_streams/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_timeline.txt
 [ -s $O/kt_two_streams_untuned/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams_untuned/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_untuned_timeline.txt
