@@ -554,6 +554,16 @@ def test_adversarial_blobs_closed_form(K, engine_setup, oracle):
             [boundary1 % R] * 4096,
             [(1 << 247) | 1] * 4096,
             list(range(1, 4097))]
+    # heavy buckets (more than 64 entries) BETWEEN light ones, at every position of the entry array: the digit sort's staged copy-out must
+    # step over the slots heavy buckets wrote directly (round 4: it once overwrote them -- the rows of the inverse DFT that
+    # lagrange_prepare commits look like this: powers of a root of small order are a few distinct values repeated)
+    rnd = random.Random(77)
+    few = [rnd.randrange(R) for _ in range(70)]
+    sets += [[few[k % 4] for k in range(4096)],                              # 4 distinct values: 80 buckets of 1024 entries
+             [few[k % 63] for k in range(4096)],                             # 63 values: buckets of 65-66 entries (just heavy)
+             [few[k % 64] for k in range(4096)],                             # 64 values: buckets of exactly 64 (the last light size)
+             [few[k % 70] if k % 3 else rnd.randrange(R) for k in range(4096)],   # heavy and light side by side
+             [pow(few[0], k, R) if k % 2 else few[1] for k in range(4096)]]  # one value 2048 times + 2048 different ones
     blobs = [b"".join(s.to_bytes(32, "big") for s in ss) for ss in sets]
     got = K.blob_to_kzg_commitment_batch(b"".join(blobs), gpu_setup)
     for ss, g in zip(sets, got):
