@@ -105,6 +105,7 @@ constexpr int kStageEntries = 16384;                                // slots per
 static_assert(kNumBuckets % kSortThreads == 0 && kBlobElems % kSortThreads == 0, "sort tiling");
 
 // one workgroup (16 waves) per blob
+template <bool staged>
 __global__ __launch_bounds__(kSortThreads) void k_digit_sort(const uint4 *__restrict__ scalars,
                                                              uint32_t *__restrict__ sorted,
                                                              uint32_t *__restrict__ bucket_start,
@@ -204,6 +205,18 @@ __global__ __launch_bounds__(kSortThreads) void k_digit_sort(const uint4 *__rest
     // between the passes: every pass walks the digits again (the scalars come out of the L2).
     const uint32_t total = bst[kNumBuckets];
     uint32_t *out = sorted + blob * (size_t)kMaxEntries;
+    if constexpr (!staged) {   // LWKZG_SORT_STAGE=0, the A/B arm: every entry straight to its slot (round 3's scatter)
+#pragma unroll
+        for (int q = 0; q < kScalarsPerSortThread; q++) {
+            uint32_t s[8];
+            load_scalar(q, s);
+            const uint32_t e = (uint32_t)(q * kSortThreads + tid);
+            for_each_digit<0>(s, 0u, [&](int j, uint32_t b, uint32_t neg) {
+                out[atomicAdd(&cnt[b], 1u)] = ((uint32_t)j * kBlobElems + e) | (neg ? kEntryNegBit : 0u);
+            });
+        }
+        return;
+    }
     constexpr uint32_t kEmpty = 0xffffffffu;   // never an entry (window < 20)
     for (uint32_t p = 0; p * kStageEntries < total; p++) {
         __syncthreads();   // the previous pass's copy-out has read the buffer
@@ -239,8 +252,11 @@ __global__ __launch_bounds__(kSortThreads) void k_digit_sort(const uint4 *__rest
 void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *bucket_start, uint32_t *perm,
                        size_t n_blobs, hipStream_t st) {
     ProfScope p("k_digit_sort", st);
-    hipLaunchKernelGGL(k_digit_sort, dim3((unsigned)n_blobs), dim3(kSortThreads), 0, st, (const uint4 *)scalars_raw,
-                       sorted, bucket_start, perm);
+    static const int staged = !(getenv("LWKZG_SORT_STAGE") && atoi(getenv("LWKZG_SORT_STAGE")) == 0);
+    if (staged)
+        hipLaunchKernelGGL(k_digit_sort<true>, dim3((unsigned)n_blobs), dim3(kSortThreads), 0, st, (const uint4 *)scalars_raw, sorted, bucket_start, perm);
+    else
+        hipLaunchKernelGGL(k_digit_sort<false>, dim3((unsigned)n_blobs), dim3(kSortThreads), 0, st, (const uint4 *)scalars_raw, sorted, bucket_start, perm);
 }
 
 // ------------------------------------------------------------------------------------------------
