@@ -172,7 +172,10 @@ C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, c
  * hipStream_t (NULL = the engine's own stream). Asynchronous: kernels are enqueued and the call
  * returns; per-blob status words (0 = ok, C_KZG_RET otherwise) are written to status_dev (n x int32,
  * may be NULL). No allocation happens here once lwkzg_reserve() has been called for >= n (proof calls of more than
- * 1024 blobs allocate n x 84 bytes once). Calls on one settings object share its workspace: whatever `stream` each is
+ * 1024 blobs allocate n x 84 bytes once; the first blob-proof call of up to LWKZG_SMALL_PROOF_HOST = 128 blobs allocates its
+ * pinned staging, 128 KiB per blob, and synchronises the device once -- such a call takes its Fiat-Shamir challenges and its
+ * commitment validation from the host threads, in stream order through a host function, because the GPU's two latency
+ * chains cost 3.6 ms however few the blobs are; the call still returns without waiting). Calls on one settings object share its workspace: whatever `stream` each is
  * given, the library orders their GPU work one after the other (event dependencies, no host blocking), so two calls
  * in flight on two streams are safe and serial. A proof call hashes and validates ALL its blobs up front (two latency
  * chains of ~3 ms whose duration does not depend on n), then runs the MSMs chunk by chunk: one call of 4096 blobs
@@ -218,7 +221,9 @@ int lwkzg_direct_num_windows(int window_bits);       /* additions per scalar on 
  * transform -- SURVEY Appendix D; the reference left this conversion commented out, src/lib.rs:760-770, src/srs.rs:117-124).
  * The table is built in the form of the mode the settings answer in at that moment (lwkzg_enable_direct_table, the load's own
  * choice, lwkzg_settings_set_mode) and in the other form as well when that fits beside it with 8 GiB to spare (always up to 14 bits
- * on an empty MI355X, never at 15 / 16); the Lagrange form only once the settings have answered in c-kzg mode. No result depends on
+ * on an empty MI355X, never at 15 / 16); the Lagrange form only once the settings have answered in c-kzg mode (a settings object that
+ * merely follows the process default gets it at its first c-kzg call, and the second table then only within a quarter of the free
+ * memory, the rule the load picks its own table by). No result depends on
  * it: without a Lagrange table a c-kzg commitment pays the inverse transform (k_ntt4096, +4 %); without a monomial table a c-kzg proof
  * pays one forward transform of its quotient, and reference mode runs on the monomial buckets. 0 = bucket engine, -1 = bad settings. */
 int lwkzg_direct_table_forms(const KZGSettings *s);

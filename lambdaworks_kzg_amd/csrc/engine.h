@@ -171,6 +171,8 @@ struct SmallProofHost {
     uint8_t *blobs = nullptr, *comm = nullptr, *canon = nullptr, *dig = nullptr;  // cap x 131072 / 48 / 48 / 32, hipHostMalloc
     int32_t *code = nullptr;                                                      // cap status words (0 or the mode's rejection code)
     size_t cap = 0;
+    static constexpr int kChunks = 16;                                            // mid-size calls: the blobs leave in chunks, hashed as they land
+    hipEvent_t chunk_done[kChunks] = {};
 };
 
 // The Lagrange form of the setup (c-kzg mode without the transform): L_i = [l_i(tau)]G in the blob's own

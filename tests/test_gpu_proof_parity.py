@@ -452,15 +452,16 @@ def test_small_device_resident_blob_proofs_vs_oracle(K, engine_setup, oracle, n,
         assert proofs[48 * i:48 * i + 48] == want_p[i], ("proof", i)
 
 
+@pytest.mark.parametrize("n", [12, 200], ids=["small_12", "mid_200"])
 @pytest.mark.parametrize("mode_c", [False, True], ids=["reference", "ckzg"])
-def test_small_device_resident_call_rejects_only_the_bad_commitment_and_rehashes_odd_encodings(K, gpu_setup, oracle, oracle_setup, mode_c):
+def test_small_device_resident_call_rejects_only_the_bad_commitment_and_rehashes_odd_encodings(K, gpu_setup, oracle, oracle_setup, mode_c, n):
     """one commitment that is not on the curve, one in the wrong subgroup, one infinity with stray flag bits (valid, non-canonical: the
     challenge must be taken over the canonical c0 00.. bytes): per-blob status, the other lanes unharmed, and the same answers as the
-    host-pointer ABI gives blob by blob; back-to-back small calls on one stream keep their own arguments"""
+    host-pointer ABI gives blob by blob; back-to-back small calls on one stream keep their own arguments. n = 200 takes the mid-size path
+    (host hashing in chunks beside the copy out, validation on the GPU)."""
     import torch
     mode = K.MODE_CKZG if mode_c else K.MODE_REFERENCE
     K.set_mode(mode)
-    n = 12
     data = bytearray(B.synthetic_batch(33000, n, big_endian=not mode_c))
     data[5 * B.BYTES_PER_BLOB:6 * B.BYTES_PER_BLOB] = bytes(B.BYTES_PER_BLOB)           # the zero polynomial: commitment = infinity
     data = bytes(data)
