@@ -175,7 +175,9 @@ C_KZG_RET lwkzg_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_out, c
  * 1024 blobs allocate n x 84 bytes once; the first blob-proof call of up to LWKZG_SMALL_PROOF_HOST = 128 blobs allocates its
  * pinned staging, 128 KiB per blob, and synchronises the device once -- such a call takes its Fiat-Shamir challenges and its
  * commitment validation from the host threads, in stream order through a host function, because the GPU's two latency
- * chains cost 3.6 ms however few the blobs are; the call still returns without waiting). Calls on one settings object share its workspace: whatever `stream` each is
+ * chains cost 3.6 ms however few the blobs are; the call still returns without waiting. Calls of up to LWKZG_MID_PROOF_HOST = 384
+ * blobs on a settings object whose other caller stream is idle hash on the host too, in chunks beside the copy out, while the GPU
+ * validates: 4.9 instead of 6.1 ms at 256 blobs). Calls on one settings object share its workspace: whatever `stream` each is
  * given, the library orders their GPU work one after the other (event dependencies, no host blocking), so two calls
  * in flight on two streams are safe and serial. A proof call hashes and validates ALL its blobs up front (two latency
  * chains of ~3 ms whose duration does not depend on n), then runs the MSMs chunk by chunk: one call of 4096 blobs

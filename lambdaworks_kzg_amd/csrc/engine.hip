@@ -803,8 +803,10 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         LWK_HIP(hipMemcpyAsync(canon, h.canon, n * 48, hipMemcpyHostToDevice, st));
         launch_z_from_bytes(w.zbytes, z, nullptr, le, n, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_challenge(blobs, canon, z, le, n, st, comm48);
-    } else if (n <= mid_proof_host_limit() && sph_reserve(c, n)) {
-        // mid-size call: the validation on the GPU's side stream as in the large path; the hashing on the host threads, chunk by chunk
+    } else if (n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n)) {
+        // mid-size call on a settings object whose other context is idle (a producer that alternates two caller streams hides the GPU's hash
+        // behind the other call's MSM at no cost, and two calls' host hashing would queue for the same host threads: 70.9k against 49.7k
+        // proofs/s at 256 blobs on two streams -- there the hash kernel stays): the validation on the GPU's side stream as in the large path; the hashing on the host threads, chunk by chunk
         // while the next chunk is still being copied out (side stream c->aux[0], one event per chunk)
         SmallProofHost &h = c->sph;
         hipStream_t sc = c->aux[0];
