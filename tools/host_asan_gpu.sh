@@ -13,7 +13,11 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:protect_shadow_gap=0:handle_
 export UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 export LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:$LD_LIBRARY_PATH   # (torch dlopens its own libraries by name: under the sanitizer's dlopen interceptor the RUNPATH of the caller is not consulted)
 # the whole GPU suite ($1 = extra pytest arguments, e.g. -k "threads or everything_at_once" for the concurrency tests only)
-LD_PRELOAD=$ASAN timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider $1 > $O/log.txt 2>&1
+# (round 4: the three tests that start FRESH python processes whose first HIP call is torch.cuda's own initialisation die inside
+# torch's libamdhip64 under the sanitizer's preload -- with the plain library just the same, tools/experiments/r04_gpu18.sh -- and are
+# left out here; they run in the plain suite)
+SKIP="--deselect tests/test_gpu_dist.py::test_two_process_rehearsal_of_a_multi_gpu_job --deselect tests/test_gpu_dist.py::test_rccl_path_at_world_size_1 --deselect tests/test_gpu_dist.py::test_bench_gpus_2_without_a_launcher"
+LD_PRELOAD=$ASAN timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider $SKIP $1 > $O/log.txt 2>&1
 echo "pytest rc=$?" >> $O/log.txt
 tail -6 $O/log.txt
 grep -c "AddressSanitizer\|runtime error" $O/log.txt
