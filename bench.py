@@ -278,11 +278,11 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                 K.compute_blob_kzg_proof_batch_device(outs[i].data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), nb, ts,
                                                       streams[i].cuda_stream if streams else stream, stats[i].data_ptr())
             steps = 20
-            el, kern = region(step, steps, 4)
+            el, kern = region(step, steps, 10)   # (ten untimed calls: the host-assisted challenge of a 256-blob call needs the host threads awake, profiles/r04_experiments.md section 3)
             assert all(int(x.abs().sum().item()) == 0 for x in stats) and all(torch.equal(o, outs[0]) for o in outs)
             return {"workload": "BASELINE configs[2]: compute_blob_kzg_proof, batch=%d device-resident blobs per call, %d caller stream%s"
                                 % (nb, max(1, n_streams), "s (consecutive calls alternate; the library overlaps one call's hash with the other's MSM)" if n_streams > 1 else ""),
-                    "value": nb * steps / el, "unit": "proofs/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
+                    "value": nb * steps / el, "unit": "proofs/s", "steps": steps, "warmup": 10, "ms_per_step": el / steps * 1e3, "kernels": kern}
         return run
     def commit_two_streams():
         n = BLOBS_PER_GPU
@@ -311,10 +311,10 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         d_c2 = torch.empty(48 * nb, dtype=torch.uint8, device=dev)
         d_p2 = torch.empty(48 * nb, dtype=torch.uint8, device=dev)
         steps = 20
-        el, kern = region(lambda: K.commit_and_prove_batch_device(d_c2.data_ptr(), d_p2.data_ptr(), d_blobs.data_ptr(), nb, ts, stream, d_st.data_ptr()), steps, 4)
+        el, kern = region(lambda: K.commit_and_prove_batch_device(d_c2.data_ptr(), d_p2.data_ptr(), d_blobs.data_ptr(), nb, ts, stream, d_st.data_ptr()), steps, 10)
         assert int(d_st.abs().sum().item()) == 0 and torch.equal(d_c2, d_comm)
         return {"workload": "commitment AND blob proof of batch=%d device-resident blobs in one pass (configs[1] then configs[2] on its output)" % nb,
-                "value": nb * steps / el, "unit": "pairs/s", "steps": steps, "warmup": 4, "ms_per_step": el / steps * 1e3, "kernels": kern}
+                "value": nb * steps / el, "unit": "pairs/s", "steps": steps, "warmup": 10, "ms_per_step": el / steps * 1e3, "kernels": kern}
     leg("commit_prove_b256", commit_prove)
 
     def ckzg_commit():

@@ -269,6 +269,14 @@ static bool sph_reserve(Ctx *c, size_t n) {
 // on the host threads too, but PIPELINED -- the blobs leave in chunks on a side stream and every chunk is hashed while the next one is
 // on its way -- and beside the GPU's commitment validation (which stays on the GPU: 2 ms whatever the batch, where the host would need
 // 0.2 ms per point per thread). 256 blobs: the challenges in ~1.6 ms instead of the hash kernel's flat 3.2.
+static size_t mid_proof_chunks() {   // experiment knob: host functions (= chunks) per mid-size call, 1 .. SmallProofHost::kChunks
+    static const size_t v = [] {
+        const char *e = getenv("LWKZG_MID_PROOF_CHUNKS");
+        long x = e ? atol(e) : 4;
+        return (size_t)(x < 1 ? 1 : x > SmallProofHost::kChunks ? SmallProofHost::kChunks : x);
+    }();
+    return v;
+}
 static size_t mid_proof_host_limit() {
     static const size_t v = [] {
         const char *e = getenv("LWKZG_MID_PROOF_HOST");
@@ -282,6 +290,16 @@ struct ChunkHashArgs {
     SmallProofHost *h;
     size_t first, count;
 };
+static void chunk_midstate_host_fn(void *p) {   // the one-pass commit-and-prove: the commitment-free 2048 blocks of a chunk's hashes
+    ChunkHashArgs *a = (ChunkHashArgs *)p;
+    SmallProofHost &h = *a->h;
+    try {
+        challenge_midstates_host((uint32_t *)(h.dig + 32 * a->first), h.blobs + a->first * (size_t)kBlobBytes, a->count);
+    } catch (...) {
+        memset(h.dig + 32 * a->first, 0, 32 * a->count);
+    }
+    delete a;
+}
 static void chunk_hash_host_fn(void *p) {
     ChunkHashArgs *a = (ChunkHashArgs *)p;
     SmallProofHost &h = *a->h;
@@ -816,7 +834,7 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
         LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         LWK_HIP(hipMemcpyAsync(h.comm, comm48, n * 48, hipMemcpyDeviceToHost, sc));
-        const size_t per = (n + SmallProofHost::kChunks - 1) / SmallProofHost::kChunks;
+        const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
         int k = 0;
         for (size_t first = 0; first < n; first += per, k++) {
             const size_t cnt = n - first < per ? n - first : per;
@@ -894,7 +912,34 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
     LWK_HIP(hipMemsetAsync(stt, 0, n * 4, st));
     LWK_HIP(hipEventRecord(c->ev_fork, st));
     LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
-    launch_challenge_midstate(blobs, mid, n, c->vstream);  // ALL blobs of the call: a latency chain, as long for 64 blobs as for 16k
+    // mid-size calls on a settings object whose other context is idle: the commitment-free part of the hashes on the host threads,
+    // chunk by chunk beside the copy out (as blob_proof_batch_device does for whole hashes), instead of the 3.2 ms kernel beside the MSM
+    const bool host_mid = n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n);
+    if (host_mid) {
+        SmallProofHost &h = c->sph;
+        hipStream_t sc = c->aux[0];
+        LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
+        const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
+        int k = 0;
+        for (size_t first = 0; first < n; first += per, k++) {
+            const size_t cnt = n - first < per ? n - first : per;
+            LWK_HIP(hipMemcpyAsync(h.blobs + first * (size_t)kBlobBytes, blobs + first * (size_t)kBlobBytes, cnt * (size_t)kBlobBytes, hipMemcpyDeviceToHost, sc));
+            LWK_HIP(hipEventRecord(h.chunk_done[k], sc));
+            LWK_HIP(hipStreamWaitEvent(c->vstream, h.chunk_done[k], 0));
+            ChunkHashArgs *a = new (std::nothrow) ChunkHashArgs{&h, first, cnt};
+            if (!a) return C_KZG_MALLOC;
+            ProfScope p("host_midstate_chunk", c->vstream);
+            const hipError_t e = hipLaunchHostFunc(c->vstream, chunk_midstate_host_fn, a);
+            if (e != hipSuccess) {
+                delete a;
+                set_error("hipLaunchHostFunc failed: %s", hipGetErrorString(e));
+                return C_KZG_ERROR;
+            }
+        }
+        LWK_HIP(hipMemcpyAsync(mid, h.dig, n * 32, hipMemcpyHostToDevice, c->vstream));
+    } else {
+        launch_challenge_midstate(blobs, mid, n, c->vstream);  // ALL blobs of the call: a latency chain, as long for 64 blobs as for 16k
+    }
     LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
     for (size_t off = 0; off < n; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
@@ -902,9 +947,9 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
         coefficients_stage(c, b, m, mode, stt + off, st);  // (coefficients: the quotient needs them)
         if (proof_on_lagrange(c, mode)) {  // the only direct table is the Lagrange one: the commitment comes from the evaluations as they stand
             launch_copy_le_check(b, (uint32_t *)w.fr, nullptr, m, st);
-            msm_stages(c, (const uint32_t *)w.fr, comm_out48 + 48 * off, m, st, 0, off == 0, true);
+            msm_stages(c, (const uint32_t *)w.fr, comm_out48 + 48 * off, m, st, 0, off == 0 && !host_mid, true);
         } else {
-            msm_stages(c, w.scalars, comm_out48 + 48 * off, m, st, 0, off == 0);  // the first one has the hash beside it
+            msm_stages(c, w.scalars, comm_out48 + 48 * off, m, st, 0, off == 0 && !host_mid);  // the first one has the hash kernel beside it
         }
         if (off == 0) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge_finish(b, comm_out48 + 48 * off, mid + 8 * off, z + off, le, m, st);

@@ -466,6 +466,10 @@ static void sha256_block_host(uint32_t h[8], const uint8_t *b) {
     h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+void sha256_blocks_portable(uint32_t h[8], const uint8_t *blocks, size_t n_blocks) {
+    for (size_t k = 0; k < n_blocks; k++) sha256_block_host(h, blocks + 64 * k);
+}
+
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len) {
     uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
     size_t i = 0;

@@ -23,6 +23,7 @@
 namespace lwk {
 
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);  // portable, sha256.hip
+void sha256_blocks_portable(uint32_t h[8], const uint8_t *blocks, size_t n_blocks);  // portable compression of whole blocks, sha256.hip
 
 namespace {
 
@@ -278,6 +279,29 @@ void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) {
         p = pool;
     }
     p->run(n, fn);
+}
+
+// mid[8 i .. 8 i + 7] = the SHA-256 chaining value after the 2048 blocks of the compute_challenge message that do not contain a byte of
+// the commitment (header | blob without its last 32 bytes): what k_challenge_pairs<true> leaves for k_challenge_finish (sha256.hip), computed
+// on the host threads for the one-pass commit-and-prove of mid-size batches (engine.hip)
+void challenge_midstates_host(uint32_t *mid, const uint8_t *blobs, size_t n) {
+    static const uint8_t header[32] = {'F', 'S', 'B', 'L', 'O', 'B', 'V', 'E', 'R', 'I', 'F', 'Y', '_', 'V', '1', '_',
+                                       0x00, 0x10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    host_parallel_for(n, [=](size_t i) {
+        const uint8_t *blob = blobs + (size_t)kBlobBytes * i;
+        uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+        uint8_t blk[64];
+        memcpy(blk, header, 32);
+        memcpy(blk + 32, blob, 32);
+        if (have_shani()) {
+            compress_shani(h, blk, 1);
+            compress_shani(h, blob + 32, (kBlobBytes - 64) / 64);   // 2047 whole blocks straight from the blob
+        } else {
+            sha256_blocks_portable(h, blk, 1);
+            sha256_blocks_portable(h, blob + 32, (kBlobBytes - 64) / 64);
+        }
+        for (int k = 0; k < 8; k++) mid[8 * i + k] = h[k];
+    });
 }
 
 // digests[i] = SHA-256(header | blobs[i] | comms[i]) for i < n, spread over the host threads
