@@ -146,7 +146,7 @@ INT_MAD_PEAK_THEORETICAL = 256 * 4 * 64 / 4 * 2.4e9   # 256 CUs x 4 SIMDs x 64 l
 # shift, a mask and a 32-bit multiply per 16), +2.4 % with one random table row per 4096 instructions per lane out of HBM -- on the box where the kernel itself ran
 # 1.93-1.96 ns per instruction; another box gave 2.04-2.09 ns for the random stream. Field elements ARE random limbs, so this is the kernel's ceiling.
 INT_MAD_NS_RANDOM = 1.832e-9
-VALU_PER_MIXED_ADD = {"k_direct_accumulate_asm": 4256, "k_direct_accumulate": 4814}   # tools/gen_direct_asm.py --mix; SQ_INSTS_VALU of the compiler's schedule
+VALU_PER_MIXED_ADD = {"k_direct_accumulate_asm": 4256, "k_direct_accumulate": 4814, "k_bucket_accumulate_asm": 4249}   # tools/gen_direct_asm.py --mix; SQ_INSTS_VALU of the compiler's schedule
 GATHER_PEAK_ROWS = 1.31e10                       # tools/gather_bench.hip on MI355X: random 112-byte rows/s out of a 128-200 GiB table
 
 
@@ -155,7 +155,8 @@ def engine_picture(K, capi, direct_bits, prof, elapsed, steps, n, msms_per_launc
     `achieved` = algorithmic bytes per launch / average launch duration (524,336 B per 4096-term MSM)."""
     # the direct engine's accumulation runs as the hand-scheduled kernel (k_direct_accumulate_asm, tools/gen_direct_asm.py) unless
     # LWKZG_DIRECT_ASM=0 or a handful of blobs put it on the compiler-scheduled one
-    dom = ("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in prof else "k_direct_accumulate") if direct_bits else "k_bucket_accumulate"
+    dom = ("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in prof else "k_direct_accumulate") if direct_bits else \
+          ("k_bucket_accumulate_asm" if "k_bucket_accumulate_asm" in prof else "k_bucket_accumulate")    # (LWKZG_BUCKET_ASM=0: the compiler-scheduled arm)
     k = prof.get(dom, {"launches": 0, "total_ms": 0.0})
     avg_ms = k["total_ms"] / max(1, k["launches"])
     # a step may cut its batch into sub-batches on concurrent streams (engine.hip: commit_batch_device), so
@@ -397,7 +398,8 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
         d_t = dev_bytes(B.synthetic_batch(5000, tiles))
         steps = 10
         el, kern = region(lambda: D.msm_tiled_sharded(d_t, tiles * 4096, ts, dev), steps, 3)
-        dom = ("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in kern else "k_direct_accumulate") if direct_bits else "k_bucket_accumulate"
+        dom = ("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in kern else "k_direct_accumulate") if direct_bits else \
+              ("k_bucket_accumulate_asm" if "k_bucket_accumulate_asm" in kern else "k_bucket_accumulate")
         ms = kern.get(dom, {}).get("avg_ms", 0.0)
         lps = max(1, round(kern.get(dom, {}).get("launches", steps) / steps))
         algo = (tiles * 4096 * 128 + 48) / lps  # 2^20 x (32 B scalar + 96 B affine point) + 48 B, per launch
@@ -830,7 +832,8 @@ def main():
             value = tiles_total * 4096 * args.steps / elapsed      # terms per second, whole job
         override = None
         if args.op == "tiled_msm":    # a tile is one 4096-term MSM; rank 0's share of the tiles per launch
-            k0 = prof.get(("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in prof else "k_direct_accumulate") if direct_bits else "k_bucket_accumulate", {"launches": 0})
+            k0 = prof.get(("k_direct_accumulate_asm" if "k_direct_accumulate_asm" in prof else "k_direct_accumulate") if direct_bits else
+                          ("k_bucket_accumulate_asm" if "k_bucket_accumulate_asm" in prof else "k_bucket_accumulate"), {"launches": 0})
             override = D.shard_range(tiles_total, world, 0)[1] / max(1, round(k0["launches"] / max(1, args.steps)))
         roofline, nwin = engine_picture(K, capi, direct_bits, prof, elapsed, args.steps, n, override)
         dom = roofline["kernel"]

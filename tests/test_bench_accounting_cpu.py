@@ -67,6 +67,9 @@ def test_compiler_arm_and_bucket_engine_pick_their_own_kernel():
     assert r["kernel"] == "k_bucket_accumulate" and nwin == 20 and r["launches_per_step"] == 2 and r["gather"] is None
     assert r["algorithmic_bytes_per_launch"] == 512 * 524336
     assert "valu_instructions_per_mixed_addition" not in r["int_mad"]
+    prof = {"k_bucket_accumulate_asm": {"launches": 10, "total_ms": 54.0}, "k_digit_sort": {"launches": 10, "total_ms": 3.4}}   # the hand-scheduled accumulation (round 4)
+    r, _ = b.engine_picture(_K(), None, 0, prof, elapsed=0.075, steps=5, n=1024)
+    assert r["kernel"] == "k_bucket_accumulate_asm" and abs(r["avg_launch_ms"] - 5.4) < 1e-9 and r["int_mad"]["frac_of_theoretical"] > 0.3
 
 
 # ---- the ONE stdout line (a 21 KB line lost its head in the driver's bounded tail of stdout) ------------------------------

@@ -11,12 +11,12 @@ LWKZG_BENCH_DETAIL=$O/bench_detail_force_dist.json python bench.py --force-dist 
 LWKZG_DIRECT_ASM=0 LWKZG_BENCH_DETAIL=$O/bench_detail_compiler_scheduled_arm.json python bench.py --no-cpu-baseline --no-config-legs > $O/bench_line_compiler_scheduled_arm.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_full_range_scalars.json python bench.py --scalars full --no-cpu-baseline --no-extra-legs > $O/bench_line_full_range_scalars.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_ckzg_mode.json python bench.py --mode ckzg --no-cpu-baseline --no-extra-legs > $O/bench_line_ckzg_mode.json 2>> $O/bench_err.txt
-LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256.json python bench.py --op blob_proof --batch 256 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256.json python bench.py --op blob_proof --batch 256 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_line_blob_proof_b256.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b1024.json python bench.py --op blob_proof --batch 1024 --no-cpu-baseline > $O/bench_line_blob_proof_b1024.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b4096.json python bench.py --op blob_proof --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_blob_proof_b4096.json 2>> $O/bench_err.txt
-LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256_two_streams.json python bench.py --op blob_proof --batch 256 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b256_two_streams.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256_two_streams.json python bench.py --op blob_proof --batch 256 --caller-streams 2 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_line_blob_proof_b256_two_streams.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b1024_two_streams.json python bench.py --op blob_proof --batch 1024 --caller-streams 2 --no-cpu-baseline > $O/bench_line_blob_proof_b1024_two_streams.json 2>> $O/bench_err.txt
-LWKZG_BENCH_DETAIL=$O/bench_detail_commit_prove_b256.json python bench.py --op commit_prove --batch 256 --no-cpu-baseline > $O/bench_line_commit_prove_b256.json 2>> $O/bench_err.txt
+LWKZG_BENCH_DETAIL=$O/bench_detail_commit_prove_b256.json python bench.py --op commit_prove --batch 256 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_line_commit_prove_b256.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_commit_prove_b1024.json python bench.py --op commit_prove --batch 1024 --no-cpu-baseline > $O/bench_line_commit_prove_b1024.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_verify_batch_b4096.json python bench.py --op verify_batch --batch 4096 --steps 5 --no-cpu-baseline > $O/bench_line_verify_batch_b4096.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_tiled_msm.json python bench.py --op tiled_msm --no-cpu-baseline > $O/bench_line_tiled_msm.json 2>> $O/bench_err.txt
