@@ -76,3 +76,34 @@ def test_packed_and_aligned_table_rows_agree(K, gpu_setup):
     for row in ("112", "128"):
         out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, LWKZG_DIRECT_ROW=row)).decode().split()
         assert out[-3:] == [row] + want, (row, out[-3:])
+
+
+def test_ckzg_mode_from_the_environment_loads_the_lagrange_form(K, oracle, oracle_setup):
+    """LWKZG_MODE=ckzg in a fresh process: what a c-kzg consumer of the nine symbols sets. The load then builds its table in the Lagrange
+    form first (and the monomial one beside it when that fits), a commitment needs no transform, and every answer is the oracle's; the
+    bucket engine (LWKZG_DIRECT_BITS=0) runs c-kzg commitments on the Lagrange buckets; the A/B arms of round 4's kernels
+    (LWKZG_BUCKET_ASM=0, LWKZG_SORT_STAGE=0) give the same bytes."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    blob = B.synthetic_blob(4444, big_endian=False)
+    rc, want_c = oracle.blob_to_kzg_commitment(blob, oracle_setup, oracle.MODE_C)
+    assert rc == 0
+    rc, want_p = oracle.compute_blob_kzg_proof(blob, want_c, oracle_setup, oracle.MODE_C)
+    assert rc == 0
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import blobs as B; import lambdaworks_kzg_amd as K; "
+            "ts = K.TrustedSetup.from_file(%r); b = B.synthetic_blob(4444, big_endian=False); f0 = ts.direct_table_forms(); c = K.blob_to_kzg_commitment(b, ts); "
+            "print(K.get_mode(), ts.direct_table_bits(), f0, ts.direct_table_forms(), c.hex(), K.compute_blob_kzg_proof(b, c, ts).hex())"
+            % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH))
+    for extra, bits in (({"LWKZG_DIRECT_BITS": "12"}, "12"), ({"LWKZG_DIRECT_BITS": "0"}, "0"),
+                        ({"LWKZG_DIRECT_BITS": "0", "LWKZG_BUCKET_ASM": "0", "LWKZG_SORT_STAGE": "0"}, "0")):
+        env = dict(os.environ, LWKZG_MODE="ckzg", **extra)
+        out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
+        mode, got_bits, forms_at_load, forms_after, c_hex, p_hex = out[-6:]
+        assert mode == "1" and got_bits == bits, out[-6:]
+        if bits != "0":
+            assert int(forms_at_load) & 2, "the load did not build the Lagrange-form table"     # c-kzg mode was in force when the table was built
+        else:
+            assert forms_at_load == "0" and forms_after == "0"
+        assert c_hex == want_c.hex() and p_hex == want_p.hex(), (extra, out[-6:])
