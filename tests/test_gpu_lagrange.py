@@ -237,3 +237,51 @@ def test_settings_mode_moves_the_tables_and_the_default_mode_does_not(K, oracle,
     finally:
         ts.free()
         K.set_mode(K.MODE_REFERENCE)
+
+
+def test_hand_built_settings_and_two_caller_streams_on_the_lagrange_form(K, mono, oracle, oracle_setup):
+    """the Lagrange form behind a KZGSettings filled in by hand (fs == NULL: the context lives in the library's registry) and behind the
+    settings' SECOND context (two caller streams: the twin holds copies of every table address, refreshed when the tables move)"""
+    import torch
+    ts0 = K.TrustedSetup.from_file(SETUP_PATH)
+    g1 = C.create_string_buffer(ts0.g1_values_bytes())
+    hand = K.KZGSettings()
+    hand.fs, hand.g1_values, hand.g2_values = None, C.cast(g1, C.c_void_p), ts0.s.g2_values
+    n = 40
+    data = B.synthetic_batch(95000, n, big_endian=False)
+    want = K.blob_to_kzg_commitment_batch(data, mono)
+    try:
+        out = C.create_string_buffer(48 * n)
+        bad = C.c_size_t(0)
+        assert K.lib().lwkzg_blob_to_kzg_commitment_batch(out, data, n, C.byref(hand), C.byref(bad)) == K.C_KZG_OK
+        assert [out.raw[48 * i:48 * i + 48] for i in range(n)] == want
+        assert K.lib().lwkzg_direct_table_forms(C.byref(hand)) & LAG or torch.cuda.mem_get_info()[0] // 4 < 36 << 30
+        assert K.lib().lwkzg_enable_direct_table_forms(C.byref(hand), 10, LAG) == K.C_KZG_OK
+        assert K.lib().lwkzg_blob_to_kzg_commitment_batch(out, data, n, C.byref(hand), C.byref(bad)) == K.C_KZG_OK
+        assert [out.raw[48 * i:48 * i + 48] for i in range(n)] == want
+    finally:
+        K.lib().lwkzg_release_context(C.byref(hand))
+    # two caller streams on a Lagrange-only table: the second stream's calls run on the twin context
+    ts0.enable_direct_table_forms(10, LAG)
+    ts0.reserve(n, caller_streams=2)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    d_cm = torch.frombuffer(bytearray(b"".join(want)), dtype=torch.uint8).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.empty(48 * n, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    prf = [torch.empty(48 * n, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for k in range(6):
+        K.blob_to_kzg_commitment_batch_device(outs[k].data_ptr(), d_in.data_ptr(), n, ts0, (s1 if k % 2 == 0 else s2).cuda_stream, None)
+    K.compute_blob_kzg_proof_batch_device(prf[0].data_ptr(), d_in.data_ptr(), d_cm.data_ptr(), n, ts0, s1.cuda_stream, None)
+    K.compute_blob_kzg_proof_batch_device(prf[1].data_ptr(), d_in.data_ptr(), d_cm.data_ptr(), n, ts0, s2.cuda_stream, None)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert bytes(o.cpu().numpy().tobytes()) == b"".join(want)
+    want_p = b"".join(K.compute_blob_kzg_proof_batch(data, b"".join(want), mono))
+    assert bytes(prf[0].cpu().numpy().tobytes()) == want_p and bytes(prf[1].cpu().numpy().tobytes()) == want_p
+    ts0.enable_direct_table_forms(11, BOTH)                               # the tables move under an existing twin
+    K.blob_to_kzg_commitment_batch_device(outs[0].data_ptr(), d_in.data_ptr(), n, ts0, s1.cuda_stream, None)
+    K.blob_to_kzg_commitment_batch_device(outs[1].data_ptr(), d_in.data_ptr(), n, ts0, s2.cuda_stream, None)
+    torch.cuda.synchronize()
+    assert bytes(outs[0].cpu().numpy().tobytes()) == b"".join(want) == bytes(outs[1].cpu().numpy().tobytes())
+    ts0.free()
