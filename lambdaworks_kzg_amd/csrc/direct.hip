@@ -490,6 +490,77 @@ __global__ __launch_bounds__(64) void k_direct_fold(const G1Xyzz29 *__restrict__
     if (lane == 0) sums[b] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// A handful of blobs: the cooperative kernel (tools/gen_coop_asm.py writes coop_asm.inc and explains the design; DESIGN.md
+// section 4d). One blob is a reduction tree of 16 levels on a chip of 1024 SIMDs, and a lone wave issues one instruction per four
+// cycles whatever it depends on, so the way to a short call is more LANES per addition: a quad of lanes owns a point (lane c =
+// coordinate c of X, Y, ZZ, ZZZ) and the addition's products run four at a time. Workgroups are single waves of 16 quads; a quad
+// adds `rpq` rows of one scalar, the wave folds its quads by ds_bpermute, and waves hand their sums on through memory, sixteen to
+// one, the last arrival of a group carrying on (no wave ever waits). The blob's sum lands in sums[blob] in the library's layout;
+// a P = +-Q inside the formulas raises redo[blob] and the complete-branches kernel above recomputes that blob.
+struct CoopParams {
+    uint32_t k[8];        // the recoding constant: digit_j = window_j(scalar + K) - (H - 1)
+    uint32_t pack;        // c | nw << 8 | rows per quad << 16 | log2(points) << 24
+    uint32_t wtop, row_bytes, n0;
+    uint32_t part_words, ctr_words;   // this blob's slice of the hand-off memory
+};
+
+constexpr uint32_t kCoopUnitWords = 56;   // a partial sum: 224 bytes
+
+// waves of one blob at stage 0, the partial sums and counters all its stages need
+static void coop_geometry(const DirectPlanRt &P, int rpq, uint32_t &n0, uint32_t &units, uint32_t &counters) {
+    const uint32_t groups = (uint32_t)((P.nw + rpq - 1) / rpq);
+    n0 = kBlobElems * groups / 16;
+    units = 0;
+    counters = 0;
+    for (uint32_t n = n0; n > 1; n = (n + 15) / 16) {
+        units += n;
+        counters += (n + 15) / 16;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_coop_msm_asm(const uint64_t *__restrict__ win_dev, const uint4 *__restrict__ scalars,
+                                                     uint32_t *__restrict__ partials, uint32_t *__restrict__ counters,
+                                                     G1Xyzz29 *__restrict__ sums, uint32_t *__restrict__ redo, CoopParams prm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t blob = blockIdx.y, unit = blockIdx.x, lane = threadIdx.x;
+    const uint4 *sc = scalars + (size_t)blob * kBlobElems * 2;
+    uint32_t *part = partials + (size_t)blob * prm.part_words;
+    uint32_t *ctr = counters + (size_t)blob * prm.ctr_words;
+    G1Xyzz29 *out = sums + blob;
+    uint32_t *flag = redo + blob;
+    asm volatile(
+#include "coop_asm.inc"
+        :
+        : "s"(win_dev), "s"(sc), "s"(part), "s"(ctr), "s"(out), "s"(flag), "s"(prm.k[0]), "s"(prm.k[1]), "s"(prm.k[2]), "s"(prm.k[3]),
+          "s"(prm.k[4]), "s"(prm.k[5]), "s"(prm.k[6]), "s"(prm.k[7]), "s"(prm.pack), "s"(prm.wtop), "s"(prm.row_bytes), "s"(prm.n0), "s"(unit),
+          "v"(lane)
+        :
+#include "coop_asm_clobbers.inc"
+    );
+#endif
+}
+
+// LWKZG_COOP=0 switches the cooperative kernel off; LWKZG_COOP_MAX = the largest batch it takes (default 8);
+// LWKZG_COOP_RPQ = table rows a quad adds before the tree (default 4: one wave per SIMD for one blob)
+static int coop_max_blobs() {
+    static const int v = [] {
+        const char *e = getenv("LWKZG_COOP");
+        if (e && atoi(e) == 0) return 0;
+        const char *m = getenv("LWKZG_COOP_MAX");
+        return m ? atoi(m) : 8;
+    }();
+    return v;
+}
+static int coop_rows_per_quad() {
+    static const int v = [] {
+        const char *e = getenv("LWKZG_COOP_RPQ");
+        const int r = e ? atoi(e) : 4;
+        return r < 1 ? 1 : r > 16 ? 16 : r;
+    }();
+    return v;
+}
+
 // LWKZG_DIRECT_ASM=0 keeps every launch on the compiler-scheduled kernel (the A/B arm)
 static bool direct_asm_enabled() {
     static const bool on = [] {
@@ -510,6 +581,43 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
     // tail short although another call's waves take compute-unit slots away (60k instead of 53k proofs/s at 256 blobs)
     static const int kFillEnv = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 0;
     const int kFill = kFillEnv ? kFillEnv : fill ? fill : 512;
+    if ((int)n_blobs <= coop_max_blobs() && !fill) {
+        // the cooperative kernel; `lane_scratch` takes the hand-off sums, the words behind the redo flags the hand-off counters
+        CoopParams prm{};
+        const int rpq = coop_rows_per_quad();
+        uint32_t units, counters;
+        coop_geometry(plan, rpq, prm.n0, units, counters);
+        // K = (H - 1) * sum of 2^(C j) over the signed windows (all but the top one)
+        for (int j = 0; j + 1 < plan.nw; j++) {
+            const int bit = plan.c * j;
+            const uint64_t v = (uint64_t)(plan.h - 1) << (bit & 31);
+            uint64_t carry = v;
+            for (int w = bit >> 5; w < 8 && carry; w++) {
+                carry += prm.k[w];
+                prm.k[w] = (uint32_t)carry;
+                carry >>= 32;
+            }
+        }
+        prm.pack = (uint32_t)plan.c | ((uint32_t)plan.nw << 8) | ((uint32_t)rpq << 16) | (12u << 24);
+        prm.wtop = (uint32_t)plan.wtop;
+        prm.row_bytes = (uint32_t)row_bytes;
+        prm.part_words = units * kCoopUnitWords;
+        prm.ctr_words = counters;
+        uint32_t *ctr = redo + n_blobs;
+        hipMemsetAsync(redo, 0, n_blobs * (1 + (size_t)counters) * sizeof(uint32_t), st);
+        {
+            ProfScope p("k_coop_msm_asm", st);
+            hipLaunchKernelGGL(k_coop_msm_asm, dim3(prm.n0, (unsigned)n_blobs), dim3(64), 0, st, table, (const uint4 *)scalars_raw,
+                               (uint32_t *)lane_scratch, ctr, sums, redo, prm);
+        }
+        {
+            // (one workgroup per flagged blob: slow and complete; none on honest data)
+            ProfScope p("k_direct_redo", st);
+            hipLaunchKernelGGL(k_direct_accumulate<CT>, dim3(1, (unsigned)n_blobs, 1), dim3(kDirThreads), 0, st, table,
+                               (const uint4 *)scalars_raw, sums, kBlobElems / kDirThreads, plan, (uint32_t)row_bytes, (const uint32_t *)redo);
+        }
+        return;
+    }
     int blocks_per_blob = 1, wsplit = 1;
     while (blocks_per_blob < 16 && n_blobs * blocks_per_blob < (size_t)kFill) blocks_per_blob <<= 1;
     while (wsplit < 4 && n_blobs * blocks_per_blob * wsplit * 8 <= (size_t)kFill) wsplit <<= 1;  // only for a handful of blobs
