@@ -519,11 +519,15 @@ static void coop_geometry(const DirectPlanRt &P, int rpq, uint32_t &n0, uint32_t
     }
 }
 
-__global__ __launch_bounds__(64) void k_coop_msm_asm(const uint64_t *__restrict__ win_dev, const uint4 *__restrict__ scalars,
+// (workgroups of four waves that have nothing to do with each other: the dispatcher spreads a workgroup's waves over the four SIMDs
+// of its compute unit, so 256 workgroups per blob are exactly one wave per SIMD, where single-wave workgroups pile up two and three
+// to a SIMD and leave others empty)
+__global__ __launch_bounds__(256) void k_coop_msm_asm(const uint64_t *__restrict__ win_dev, const uint4 *__restrict__ scalars,
                                                      uint32_t *__restrict__ partials, uint32_t *__restrict__ counters,
                                                      G1Xyzz29 *__restrict__ sums, uint32_t *__restrict__ redo, CoopParams prm) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t blob = blockIdx.y, unit = blockIdx.x, lane = threadIdx.x;
+    const uint32_t blob = blockIdx.y, lane = threadIdx.x & 63;
+    const uint32_t unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint4 *sc = scalars + (size_t)blob * kBlobElems * 2;
     uint32_t *part = partials + (size_t)blob * prm.part_words;
     uint32_t *ctr = counters + (size_t)blob * prm.ctr_words;
@@ -542,7 +546,6 @@ __global__ __launch_bounds__(64) void k_coop_msm_asm(const uint64_t *__restrict_
 }
 
 // LWKZG_COOP=0 switches the cooperative kernel off; LWKZG_COOP_MAX = the largest batch it takes (default 8);
-// LWKZG_COOP_RPQ = table rows a quad adds before the tree (default 4: one wave per SIMD for one blob)
 static int coop_max_blobs() {
     static const int v = [] {
         const char *e = getenv("LWKZG_COOP");
@@ -552,13 +555,18 @@ static int coop_max_blobs() {
     }();
     return v;
 }
-static int coop_rows_per_quad() {
-    static const int v = [] {
+// rows a quad adds before the tree. A blob is 256 waves per group of `rpq` windows; the chip has 1024 SIMDs and a wave that shares
+// its SIMD takes twice as long, so the launch aims at 1024 waves in all: four window groups for one blob (16 windows: 4 rows per
+// quad, 20: 5), two for two blobs, one from four blobs on. LWKZG_COOP_RPQ overrides (experiments).
+static int coop_rows_per_quad(int nw, size_t n_blobs) {
+    static const int env = [] {
         const char *e = getenv("LWKZG_COOP_RPQ");
-        const int r = e ? atoi(e) : 4;
-        return r < 1 ? 1 : r > 16 ? 16 : r;
+        const int r = e ? atoi(e) : 0;
+        return r < 0 ? 0 : r > 32 ? 32 : r;
     }();
-    return v;
+    if (env) return env;
+    const int groups = n_blobs >= 4 ? 1 : (int)(4 / n_blobs);
+    return (nw + groups - 1) / groups;
 }
 
 // LWKZG_DIRECT_ASM=0 keeps every launch on the compiler-scheduled kernel (the A/B arm)
@@ -584,7 +592,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
     if ((int)n_blobs <= coop_max_blobs() && !fill) {
         // the cooperative kernel; `lane_scratch` takes the hand-off sums, the words behind the redo flags the hand-off counters
         CoopParams prm{};
-        const int rpq = coop_rows_per_quad();
+        const int rpq = coop_rows_per_quad(plan.nw, n_blobs);
         uint32_t units, counters;
         coop_geometry(plan, rpq, prm.n0, units, counters);
         // K = (H - 1) * sum of 2^(C j) over the signed windows (all but the top one)
@@ -607,7 +615,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
         hipMemsetAsync(redo, 0, n_blobs * (1 + (size_t)counters) * sizeof(uint32_t), st);
         {
             ProfScope p("k_coop_msm_asm", st);
-            hipLaunchKernelGGL(k_coop_msm_asm, dim3(prm.n0, (unsigned)n_blobs), dim3(64), 0, st, table, (const uint4 *)scalars_raw,
+            hipLaunchKernelGGL(k_coop_msm_asm, dim3(prm.n0 / 4, (unsigned)n_blobs), dim3(256), 0, st, table, (const uint4 *)scalars_raw,
                                (uint32_t *)lane_scratch, ctr, sums, redo, prm);
         }
         {

@@ -130,7 +130,7 @@ struct Combiner {
     LaneFront<CombineReq, kCombineLanes> front;
     std::mutex init_m;
     uint8_t *pinned_blobs = nullptr;                  // kCombineSlots x 131072, hipHostMalloc
-    uint8_t *pinned_out[kCombineLanes] = {nullptr, nullptr};     // kCombineMaxBatch x 48
+    uint8_t *pinned_out[kCombineLanes] = {nullptr, nullptr};     // kCombineMaxBatch x 224: compressed results, or the XYZZ sums of a small batch (finished on the host)
     int32_t *pinned_status[kCombineLanes] = {nullptr, nullptr};  // kCombineMaxBatch
     bool ready = false, failed = false;
 };

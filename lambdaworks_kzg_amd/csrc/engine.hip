@@ -4,6 +4,7 @@
 // trusted setup owns: the affine SRS points, the 20-window fixed-base table, the NTT twiddles, a
 // stream, and a grow-only workspace sized for up to kMaxChunk blobs per launch set.
 #include "engine.h"
+#include "hostfp.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -665,6 +666,68 @@ static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, h
 static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size_t n, hipStream_t st, size_t base = 0,
                        bool shared_chip = false, bool lagrange = false) {
     launch_finalize_compress(msm_sums_stage(c, scalars_raw, n, st, base, shared_chip, lagrange), out48, n, st);
+}
+
+// ---- the last step of a SMALL host-pointer call on the host -------------------------------------------------------
+// One inversion and the compression per result are a dependent chain of ~20k instructions: 0.09-0.1 ms on a lone GPU lane
+// (k_finalize_compress) whatever the batch, a few microseconds on a host core -- and the result of a host-pointer call has to
+// cross to the host anyway. Calls of up to LWKZG_HOST_FINISH results (default 8, 0 = never) therefore copy the XYZZ sums
+// (224 bytes each) instead of the 48 compressed bytes and finish here. Same bytes: x = X / ZZ, y = Y / ZZZ, compress_g1_point
+// (/root/reference/src/compression.rs:33-60) through g1.cuh's g1_compress_affine.
+static size_t host_finish_limit() {
+    static const size_t v = [] {
+        const char *e = getenv("LWKZG_HOST_FINISH");
+        const long x = e ? atol(e) : 8;
+        return (size_t)(x < 0 ? 0 : x > (long)kCombineMaxBatch ? (long)kCombineMaxBatch : x);
+    }();
+    return v;
+}
+
+// the integer of a hot-loop field value (14 limbs of 28 bits, value < 16p) reduced into [0, p)
+static HFp hfp_from_limbs28(const uint32_t *l) {
+    uint64_t w[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 14; i++) {
+        const int bit = P29::W * i, k = bit >> 6, sh = bit & 63;
+        unsigned __int128 v = (unsigned __int128)l[i] << sh;
+        for (int j = k; j < 7 && v; j++) {
+            v += w[j];
+            w[j] = (uint64_t)v;
+            v >>= 64;
+        }
+    }
+    for (int shift = 3; shift >= 0; shift--) {  // minus 8p, 4p, 2p, p where that leaves it non-negative
+        uint64_t kp[7], d[7];
+        for (int j = 0; j < 7; j++) {
+            const uint64_t lo = j < 6 ? HFpPar::P[j] : 0, below = j > 0 ? HFpPar::P[j - 1] : 0;
+            kp[j] = shift ? (lo << shift) | (below >> (64 - shift)) : lo;
+        }
+        unsigned __int128 br = 0;
+        for (int j = 0; j < 7; j++) {
+            const unsigned __int128 v = (unsigned __int128)w[j] - kp[j] - (uint64_t)br;
+            d[j] = (uint64_t)v;
+            br = (v >> 64) & 1;
+        }
+        if (!br)
+            for (int j = 0; j < 7; j++) w[j] = d[j];
+    }
+    HFp r;
+    for (int j = 0; j < 6; j++) r.l[j] = w[j];
+    return r;
+}
+
+static void host_finish_compress(uint8_t out[48], const G1Xyzz29 &sum) {
+    if (sum.is_inf()) {
+        memset(out, 0, 48);
+        out[0] = 0xc0;
+        return;
+    }
+    // the four limb vectors read as residues all carry the same Montgomery factor, which the two quotients cancel
+    const HFp X = hfp_from_limbs28(sum.x.l), Y = hfp_from_limbs28(sum.y.l), ZZ = hfp_from_limbs28(sum.zz.l), ZZZ = hfp_from_limbs28(sum.zzz.l);
+    const HFp i = inv(ZZ * ZZZ);
+    G1Affine a;
+    a.x = (X * (i * ZZZ)).to_fe();
+    a.y = (Y * (i * ZZ)).to_fe();
+    g1_compress_affine(out, a);
 }
 
 // Which form a c-kzg call's MSM runs on. A COMMITMENT's scalars can be had in either form -- the blob's evaluations as they stand,
@@ -1770,7 +1833,7 @@ static bool combiner_init(Ctx *c) {
     hipSetDevice(c->device);
     bool ok = hipHostMalloc((void **)&cb.pinned_blobs, kCombineSlots * (size_t)kBlobBytes, hipHostMallocDefault) == hipSuccess;
     for (int k = 0; k < kCombineLanes && ok; k++)
-        ok = hipHostMalloc((void **)&cb.pinned_out[k], kCombineMaxBatch * 48, hipHostMallocDefault) == hipSuccess &&
+        ok = hipHostMalloc((void **)&cb.pinned_out[k], kCombineMaxBatch * sizeof(G1Xyzz29), hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void **)&cb.pinned_status[k], kCombineMaxBatch * 4, hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
@@ -1792,6 +1855,7 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
     const int mode = batch[0]->mode;
     const size_t lo = (size_t)lane * kCombineMaxBatch;  // this lane's slice of the workspace
     hipStream_t sk = c->aux[lane];
+    const bool host_finish = n <= host_finish_limit();
     C_KZG_RET rc = C_KZG_OK;
     {
         std::lock_guard<std::mutex> lk(c->mu);  // enqueue only: the wait below happens outside
@@ -1810,9 +1874,14 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
             ok = ok && hipMemsetAsync(w.status + lo, 0, n * 4, sk) == hipSuccess;
             if (ok) {
                 const bool lg = coefficients_stage(c, d_blobs, n, mode, w.status + lo, sk, lo, true);
-                msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, n, sk, lo, false, lg);
-                ok = hipMemcpyAsync(cb.pinned_out[lane], w.out48 + 48 * lo, n * 48, hipMemcpyDeviceToHost, sk) == hipSuccess &&
-                     hipMemcpyAsync(cb.pinned_status[lane], w.status + lo, n * 4, hipMemcpyDeviceToHost, sk) == hipSuccess;
+                if (host_finish) {  // the sums come back as they are; inversion and compression below, on this thread
+                    const G1Xyzz29 *sums = msm_sums_stage(c, w.scalars + lo * (size_t)kBlobElems * 8, n, sk, lo, false, lg);
+                    ok = hipMemcpyAsync(cb.pinned_out[lane], sums, n * sizeof(G1Xyzz29), hipMemcpyDeviceToHost, sk) == hipSuccess;
+                } else {
+                    msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, n, sk, lo, false, lg);
+                    ok = hipMemcpyAsync(cb.pinned_out[lane], w.out48 + 48 * lo, n * 48, hipMemcpyDeviceToHost, sk) == hipSuccess;
+                }
+                ok = ok && hipMemcpyAsync(cb.pinned_status[lane], w.status + lo, n * 4, hipMemcpyDeviceToHost, sk) == hipSuccess;
             }
         }
         if (!ok && rc == C_KZG_OK) {
@@ -1831,7 +1900,8 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
         } else if (cb.pinned_status[lane][i] != 0) {
             r->rc = (int)map_rc((C_KZG_RET)cb.pinned_status[lane][i], mode);
         } else {
-            memcpy(r->out48, cb.pinned_out[lane] + 48 * i, 48);
+            if (host_finish) host_finish_compress(r->out48, ((const G1Xyzz29 *)cb.pinned_out[lane])[i]);
+            else memcpy(r->out48, cb.pinned_out[lane] + 48 * i, 48);
             r->rc = C_KZG_OK;
         }
     }

@@ -68,9 +68,10 @@ ACC1 = vregs(2, 2)
 T1, T2, T3 = vregs(1)[0], vregs(1)[0], vregs(1)[0]
 SC = vregs(8, 2)            # the quad's scalar + K, shifted down window by window
 ADDR = vregs(2, 2)
-LANE, QC, QUAD, POINT, MAG, BPADDR, VRB = (vregs(1)[0] for _ in range(7))
+LANE, QC, QUAD, POINT, MAG, BPADDR, VRB, SIGN = (vregs(1)[0] for _ in range(8))
+HN = vregs(14, 2)           # the NEXT table row of this quad, gathered while the current addition runs
 NUM_VGPRS = _n[0]
-assert NUM_VGPRS <= 128, NUM_VGPRS       # four waves per SIMD
+assert NUM_VGPRS <= 168, NUM_VGPRS       # three waves per SIMD
 
 sINV, sMASK, sINVP, sMOD = G.sINV, G.sMASK, G.sINVP, G.sMOD
 SBASE = G.SBASE
@@ -292,6 +293,38 @@ def lane_stores(p, src):
         e("global_store_dwordx4", vp(ADDR[0]), ("v4", src[2 + 4 * k]), ("off",), offset=64 + 16 * k, mod="sc1")
 
 
+def row_issue(p):
+    """window sJ of the scalar in SC (all lanes): MAG, SIGN, the row's address, its gather into HN (lane 0: x, lane 1: y); SC moves on"""
+    e = p.emit
+    e("s_add_u32", s(sSUBJ), s(sH), lit(-1))
+    e("s_add_u32", s(sSTMP), s(sNW), lit(-1))
+    e("s_cmp_eq_u32", s(sJ), s(sSTMP))                      # the top window is unsigned and takes what is left of the scalar
+    e("s_cselect_b32", s(sMASKJ), lit(-1), s(sMASKC))
+    e("s_cselect_b32", s(sHJ), s(sHTOP), s(sH))
+    e("s_cselect_b32", s(sSUBJ), lit(0), s(sSUBJ))
+    e("s_lshl_b32", s(sSTMP), s(sJ), lit(3))
+    e("s_load_dwordx2", sp(sTMPB), sp(sTABLE), s(sSTMP))
+    e("v_and_b32", v(T1), s(sMASKJ), v(SC[0]))
+    e("v_cmp_lt_u32", sp(sTMP), v(T1), s(sSUBJ))            # negative digit
+    e("v_sub_u32", v(T2), v(T1), s(sSUBJ), wrap=True)
+    e("v_sub_u32", v(T3), s(sSUBJ), v(T1), wrap=True)
+    e("v_cndmask_b32", v(MAG), v(T2), v(T3), sp(sTMP))
+    e("v_cndmask_b32", v(SIGN), lit(0), lit(1), sp(sTMP))
+    for i in range(7):
+        e("v_alignbit_b32", v(SC[i]), v(SC[i + 1]), v(SC[i]), s(sC))
+    e("v_lshrrev_b32", v(SC[7]), s(sC), v(SC[7]))
+    e("v_cmp_ne_u32", sp(sTAKE), lit(0), v(MAG))            # quads that have a row to gather
+    e("v_mad_u32_u24", v(T3), v(POINT), s(sHJ), v(MAG))
+    e("s_waitcnt", ("raw", "lgkmcnt(0)"))
+    e("s_sub_u32", s(sTMPB[0]), s(sTMPB[0]), s(sRB))        # minus one row: mag counts from 1
+    e("s_subb_u32", s(sTMPB[1]), s(sTMPB[1]), lit(0))
+    e("v_mad_u64_u32", vp(ADDR[0]), VCC, v(T3), v(VRB), sp(sTMPB))
+    e("s_and_b64", sp(sTMP), sp(sQ0), sp(sTAKE))
+    e("s_and_b64", sp(sTMPB), sp(sQ1), sp(sTAKE))
+    lane_loads(p, HN, False)
+    e("s_mov_b64", EXEC, lit(-1))
+
+
 def build():
     p = CProg()
     e = p.emit
@@ -367,47 +400,32 @@ def build():
         e("v_alignbit_b32", v(SC[i]), v(SC[i + 1]), v(SC[i]), s(sSTMP))
     e("v_lshrrev_b32", v(SC[7]), s(sSTMP), v(SC[7]))
     e("s_mov_b32", s(sPHASE), lit(0))                       # 0: rows, 1: tree
+    row_issue(p)
 
     # ---------------- one step: fetch B (a table row, or another quad's point), then the common addition
     p.label("C_step%=")
     e("s_cmp_eq_u32", s(sPHASE), lit(0))
     e("s_cbranch_scc0", ("label", "C_fetch_tree%="))
-    # ---- a row: window sJ of the scalar in SC
-    e("s_add_u32", s(sSUBJ), s(sH), lit(-1))
-    e("s_add_u32", s(sSTMP), s(sNW), lit(-1))
-    e("s_cmp_eq_u32", s(sJ), s(sSTMP))                      # the top window is unsigned and takes what is left of the scalar
-    e("s_cselect_b32", s(sMASKJ), lit(-1), s(sMASKC))
-    e("s_cselect_b32", s(sHJ), s(sHTOP), s(sH))
-    e("s_cselect_b32", s(sSUBJ), lit(0), s(sSUBJ))
-    e("s_lshl_b32", s(sSTMP), s(sJ), lit(3))
-    e("s_load_dwordx2", sp(sTMPB), sp(sTABLE), s(sSTMP))
-    e("v_and_b32", v(T1), s(sMASKJ), v(SC[0]))
-    e("v_cmp_lt_u32", sp(sTMP), v(T1), s(sSUBJ))            # negative digit
-    e("v_sub_u32", v(T2), v(T1), s(sSUBJ), wrap=True)
-    e("v_sub_u32", v(T3), s(sSUBJ), v(T1), wrap=True)
-    e("v_cndmask_b32", v(MAG), v(T2), v(T3), sp(sTMP))
-    for i in range(7):
-        e("v_alignbit_b32", v(SC[i]), v(SC[i + 1]), v(SC[i]), s(sC))
-    e("v_lshrrev_b32", v(SC[7]), s(sC), v(SC[7]))
-    e("v_cmp_eq_u32", sp(sBINF), lit(0), v(MAG))            # no row: B at infinity
-    e("v_mad_u32_u24", v(T3), v(POINT), s(sHJ), v(MAG))
-    e("s_waitcnt", ("raw", "lgkmcnt(0)"))
-    e("s_sub_u32", s(sTMPB[0]), s(sTMPB[0]), s(sRB))        # minus one row: mag counts from 1
-    e("s_subb_u32", s(sTMPB[1]), s(sTMPB[1]), lit(0))
-    e("v_mad_u64_u32", vp(ADDR[0]), VCC, v(T3), v(VRB), sp(sTMPB))
-    e("s_mov_b64", sp(sADDM), sp(sTMP))                     # (the sign mask, kept until the loads are back)
-    # lanes 0 (x) and 1 (y) of the quads that have a row load; lanes 2, 3 hold ZZ = ZZZ = 1
-    e("s_andn2_b64", sp(sTMP), sp(sQ0), sp(sBINF))
-    e("s_andn2_b64", sp(sTMPB), sp(sQ1), sp(sBINF))
-    lane_loads(p, HB, False)
-    e("s_or_b64", EXEC, sp(sQ2), sp(sQ3))
+    # ---- a row: the gather issued one addition ago has landed in HN
+    e("s_waitcnt", ("raw", "vmcnt(0)"))
+    e("v_cmp_eq_u32", sp(sBINF), lit(0), v(MAG))            # no row (zero digit): B at infinity
+    e("v_cmp_ne_u32", sp(sTMP), lit(0), v(SIGN))
+    e("s_andn2_b64", sp(sTMP), sp(sTMP), sp(sBINF))
+    e("s_or_b64", EXEC, sp(sQ0), sp(sQ1))
+    for i in range(14):
+        e("v_mov_b32", v(HB[i]), v(HN[i]))
+    e("s_or_b64", EXEC, sp(sQ2), sp(sQ3))                   # ZZ = ZZZ = 1
     for i in range(14):
         e("v_mov_b32", v(HB[i]), lit(G.R1[i]))
-    e("s_waitcnt", ("raw", "vmcnt(0)"))
-    e("s_andn2_b64", sp(sTMP), sp(sADDM), sp(sBINF))
     set_exec_and(p, sTMP, sQ1)                              # negative digit: y <- 4p - y
     for i in range(14):
         e("v_sub_u32", v(HB[i]), lit(KP4_1[i]), v(HB[i]))
+    e("s_mov_b64", EXEC, lit(-1))
+    e("s_add_u32", s(sJ), s(sJ), lit(1))
+    e("s_cmp_lt_u32", s(sJ), s(sJEND))
+    e("s_cbranch_scc0", ("label", "C_no_next_row%="))
+    row_issue(p)
+    p.label("C_no_next_row%=")
     e("s_mov_b64", sp(sTAKE), lit(-1))
     e("s_branch", ("label", "C_have_b%="))
     # ---- the tree: B <- A of quad + (1 << level)
@@ -448,8 +466,7 @@ def build():
     # ---------------- what comes next
     e("s_cmp_eq_u32", s(sPHASE), lit(0))
     e("s_cbranch_scc0", ("label", "C_next_level%="))
-    e("s_add_u32", s(sJ), s(sJ), lit(1))
-    e("s_cmp_lt_u32", s(sJ), s(sJEND))
+    e("s_cmp_lt_u32", s(sJ), s(sJEND))                      # (sJ moved on when the row was taken)
     e("s_cbranch_scc1", ("label", "C_step%="))
     e("s_mov_b32", s(sPHASE), lit(1))
     e("s_mov_b32", s(sLVL), lit(0))
