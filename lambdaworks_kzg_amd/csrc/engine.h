@@ -252,8 +252,9 @@ C_KZG_RET commit_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, size
                               int32_t *status);
 C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, const uint8_t *comm48, size_t n, int mode,
                                   hipStream_t st, int32_t *status);
+// (sums_out, one chunk at most: the XYZZ sums stay where they are, *sums_out says where, and the caller inverts and compresses)
 C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const uint8_t *blobs, const uint8_t *z32,
-                                   size_t n, int mode, hipStream_t st, int32_t *status);
+                                   size_t n, int mode, hipStream_t st, int32_t *status, const G1Xyzz29 **sums_out = nullptr);
 C_KZG_RET msm_scalars_raw_device(Ctx *c, uint8_t *out48, const uint32_t *scalars_raw, size_t n, hipStream_t st);
 
 // verify-side helpers (host pointers in and out; GPU work inside; engine.hip)

@@ -1023,7 +1023,7 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
 }
 
 C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const uint8_t *blobs, const uint8_t *z32,
-                                   size_t n, int mode, hipStream_t st, int32_t *status) {
+                                   size_t n, int mode, hipStream_t st, int32_t *status, const G1Xyzz29 **sums_out) {
     C_KZG_RET rc = ctx_reserve(c, n);
     if (rc != C_KZG_OK) return rc;
     Workspace &w = c->ws;
@@ -1035,7 +1035,9 @@ C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const
         coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
         launch_z_from_bytes(z32 + 32 * off, w.z, stt, le, m, st);
         launch_eval_quotient(w.scalars, w.z, w.scalars2, y32 + 32 * off, le, m, st);
-        msm_stages(c, w.scalars2, proof48 + 48 * off, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
+        const bool lg = quotient_to_msm_form(c, mode, m, st);
+        if (sums_out && n <= kMaxChunk) *sums_out = msm_sums_stage(c, w.scalars2, m, st, 0, false, lg);   // the caller finishes on the host
+        else msm_stages(c, w.scalars2, proof48 + 48 * off, m, st, 0, false, lg);
     }
     return C_KZG_OK;
 }
@@ -2329,16 +2331,25 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
         // GPU, main stream: parse the blobs, then the digests as soon as the host threads have them
         coefficients_stage(c, w.blobs, m, mode, w.status, st);
         hasher.join();
-        if (host_validate) {  // after the hashing: both want every host thread
+        LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
+        launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
+        launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+        const bool hf = m <= host_finish_limit();  // a small call: inversion and compression on this thread, at the end
+        const G1Xyzz29 *d_sums = nullptr;
+        auto quotient_msm = [&]() {
+            const bool lg = quotient_to_msm_form(c, mode, m, st);
+            if (hf) d_sums = msm_sums_stage(c, w.scalars2, m, st, 0, false, lg);
+            else msm_stages(c, w.scalars2, w.out48, m, st, 0, false, lg);
+        };
+        quotient_msm();
+        if (host_validate) {
+            // after the hashing (both want every host thread) and after the GPU has been given everything that needs only the
+            // digests: the verdicts are read at the very end, and 0.2 ms of host work per point now runs beside the quotient's MSM
             std::vector<int> vrc(m);
             host_validate_commitments(h_comm, h_canon.data(), vrc.data(), m);
             for (size_t i = 0; i < m; i++)
                 if (vrc[i] == 2) LWK_HIP(hipMemcpyAsync(w.status + i, &h_code[i], 4, hipMemcpyHostToDevice, st));
         }
-        LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
-        launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
-        launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
-        msm_stages(c, w.scalars2, w.out48, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
         if (!host_validate) {
             // (a device-to-host copy into pageable memory blocks this thread until the stream has reached it: the
             // canonical bytes are fetched only now that everything else has been submitted)
@@ -2353,12 +2364,15 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
             launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
             coefficients_stage(c, w.blobs, m, mode, w.status, st);  // (the first attempt's forward transform may have used them as scratch)
             launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
-            msm_stages(c, w.scalars2, w.out48, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
+            quotient_msm();
         }
         std::vector<uint8_t> h_out(m * 48);
-        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
+        std::vector<G1Xyzz29> h_sums(hf ? m : 0);
+        if (hf) LWK_HIP(hipMemcpyAsync(h_sums.data(), d_sums, m * sizeof(G1Xyzz29), hipMemcpyDeviceToHost, c->stream));
+        else LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
         rc = collect_status(c, w.status, m, off, first_bad);
         if (rc != C_KZG_OK) return map_rc(rc, mode);
+        for (size_t i = 0; i < h_sums.size(); i++) host_finish_compress(h_out.data() + 48 * i, h_sums[i]);
         memcpy(out + off, h_out.data(), m * 48);
     }
     return C_KZG_OK;
@@ -2397,13 +2411,18 @@ static C_KZG_RET point_proof_batch_host(Ctx *c, KZGProof *proofs_out, Bytes32 *y
         Workspace &w = c->ws;
         LWK_HIP(hipMemcpyAsync(w.blobs, blobs + off, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
         LWK_HIP(hipMemcpyAsync(w.zbytes, zs + off, m * 32, hipMemcpyHostToDevice, c->stream));
-        rc = point_proof_batch_device(c, w.out48, w.ybytes, w.blobs, w.zbytes, m, mode, c->stream, w.status);
+        const bool hf = m <= host_finish_limit();  // a small call: inversion and compression on this thread
+        const G1Xyzz29 *d_sums = nullptr;
+        rc = point_proof_batch_device(c, w.out48, w.ybytes, w.blobs, w.zbytes, m, mode, c->stream, w.status, hf ? &d_sums : nullptr);
         if (rc != C_KZG_OK) return rc;
         std::vector<uint8_t> h_out(m * 48), h_y(m * 32);
-        LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
+        std::vector<G1Xyzz29> h_sums(hf ? m : 0);
+        if (hf) LWK_HIP(hipMemcpyAsync(h_sums.data(), d_sums, m * sizeof(G1Xyzz29), hipMemcpyDeviceToHost, c->stream));
+        else LWK_HIP(hipMemcpyAsync(h_out.data(), w.out48, m * 48, hipMemcpyDeviceToHost, c->stream));
         LWK_HIP(hipMemcpyAsync(h_y.data(), w.ybytes, m * 32, hipMemcpyDeviceToHost, c->stream));
         rc = collect_status(c, w.status, m, off, first_bad);
         if (rc != C_KZG_OK) return map_rc(rc, mode);
+        for (size_t i = 0; i < h_sums.size(); i++) host_finish_compress(h_out.data() + 48 * i, h_sums[i]);
         memcpy(proofs_out + off, h_out.data(), m * 48);
         memcpy(ys_out + off, h_y.data(), m * 32);
     }
