@@ -480,6 +480,34 @@ def _leg_compact(l):
     return out
 
 
+def api_latency_leg(K, B, ts, bits):
+    """The reference's own call shape (/root/reference/src/lib.rs:253-283, 300-404, 456-505): ONE blob per synchronous call through the
+    nine symbols, host pointers in and out, one thread, on the engine a plain load selected. Wall clock per call (PCIe, launches, the
+    host's share of the work all inside); never `value`."""
+    blob = B.synthetic_blob(9001)
+    c = K.blob_to_kzg_commitment(blob, ts)
+    pr = K.compute_blob_kzg_proof(blob, c, ts)
+    z = blob[32:64]
+    ops = {"blob_to_kzg_commitment": lambda: K.blob_to_kzg_commitment(blob, ts),
+           "compute_blob_kzg_proof": lambda: K.compute_blob_kzg_proof(blob, c, ts),
+           "compute_kzg_proof": lambda: K.compute_kzg_proof(blob, z, ts),
+           "verify_blob_kzg_proof": lambda: K.verify_blob_kzg_proof(blob, c, pr, ts)}
+    out = {"engine_direct_bits": bits, "calls_timed": 20, "unit": "ms per call, one blob, one thread (median; best)",
+           "note": "the nine reference symbols are one-blob synchronous calls: a handful of blobs runs on the cooperative kernel "
+                   "(k_coop_msm_asm, four lanes per group addition) and the inversion + compression of the result on the calling thread"}
+    for name, fn in ops.items():
+        for _ in range(3):
+            fn()
+        t = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            fn()
+            t.append((time.perf_counter() - t0) * 1e3)
+        t.sort()
+        out[name] = {"median_ms": t[10], "best_ms": t[0], "calls_per_s_one_thread": 1e3 / t[10]}
+    return out
+
+
 def compact_line(res, detail_path=None):
     """The ONE stdout line: the contract's fields first, then one small object per engine and per leg. Numbers only; every note,
     breakdown and per-kernel table stays in the detail file. Pure function of the detail dictionary (tests/test_bench_accounting_cpu.py
@@ -505,6 +533,8 @@ def compact_line(res, detail_path=None):
             line[eng]["frac"] = r.get("frac")
     if isinstance(res.get("host_abi"), dict):
         line["host_abi"] = _pick(res["host_abi"], ("value", "unit", "ms_per_call_median", "blobs_per_call"))
+    if isinstance(res.get("api_latency"), dict):
+        line["api_latency_ms"] = {k: v.get("median_ms") for k, v in res["api_latency"].items() if isinstance(v, dict)}
     if isinstance(res.get("configs"), dict):
         line["configs"] = {k: _leg_compact(v) for k, v in res["configs"].items()}
     line["dist"] = _pick(res.get("dist") or {}, ("initialised", "backend", "ranks", "nccl_version"))
@@ -514,7 +544,7 @@ def compact_line(res, detail_path=None):
     line = _round(line)
     text = json.dumps(line, separators=(",", ":"))
     # belt and braces: whatever a future field does, the contract's head of the line survives
-    for drop in ("kernels_avg_ms", "host_abi", "configs", "bucket_engine", "default_engine", "dist"):
+    for drop in ("kernels_avg_ms", "host_abi", "api_latency_ms", "configs", "bucket_engine", "default_engine", "dist"):
         if len(text) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -735,6 +765,8 @@ def main():
         extra["default_engine"] = engine_leg(default_bits, "what load_trusted_setup* selects by itself (LWKZG_DIRECT_BITS unset): the widest "
                                              "direct table of 13..10 bits within a quarter of the free HBM, else buckets")
         extra["default_engine"]["setup_load_s_incl_table_build"] = t_load
+        if rank == 0:
+            extra["api_latency"] = api_latency_leg(K, B, ts, default_bits)
         # (b) the low-memory fallback
         ts.enable_direct_table(0)
         extra["bucket_engine"] = engine_leg(0, "Pippenger buckets over the 9 MB fixed-base table (LWKZG_DIRECT_BITS=0, or no memory for a table)")

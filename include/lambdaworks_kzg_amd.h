@@ -299,6 +299,13 @@ C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, c
  * big-endian scalars; whole tiles per device, one 48-byte partial sum back from each, added on the host. */
 C_KZG_RET lwkzg_multi_g1_msm_tiled(uint8_t out48[48], const uint8_t *scalars_be, size_t n_terms, const LwkzgMulti *m);
 
+/* verify_blob_kzg_proof_batch (src/lib.rs:525-614, 639-692) for a batch that is ALREADY on the device: blobs (n * 131072 bytes),
+ * commitments and proofs (n * 48 each) are device pointers, produced on `stream` (a hipStream_t; NULL = already complete). The call
+ * is synchronous, as the reference's: *ok is a host bool and the pairing check runs on the host; nothing but the 160-byte records
+ * crosses PCIe. Same verdicts, return codes and empty-batch rule as verify_blob_kzg_proof_batch. */
+C_KZG_RET lwkzg_verify_blob_kzg_proof_batch_device(bool *ok, const void *blobs_dev, const void *commitments48_dev, const void *proofs48_dev,
+                                                   size_t n, const KZGSettings *s, void *stream);
+
 /* verify_blob_kzg_proof_batch (src/lib.rs:525-692) for a batch SHARDED over several processes / GPUs, as the
  * reference computes it: ONE Fiat-Shamir scalar r over the whole batch (compute_r_powers, src/utils.rs:166-206), ONE
  * random linear combination, ONE pairing check. Rank k holds blobs [first_k, first_k + n_k) of the n_total:
@@ -318,6 +325,10 @@ C_KZG_RET lwkzg_multi_g1_msm_tiled(uint8_t out48[48], const uint8_t *scalars_be,
 typedef struct LwkzgVerifyShard LwkzgVerifyShard;
 C_KZG_RET lwkzg_verify_shard_begin(LwkzgVerifyShard **shard_out, uint8_t *records_out /* n_local * 160 */, const Blob *blobs,
                                    const Bytes48 *commitments, const Bytes48 *proofs, size_t n_local, const KZGSettings *s);
+/* Step 1 for a shard that is already in HBM: DEVICE pointers (produced on `stream`, NULL = already complete); records to the host. */
+C_KZG_RET lwkzg_verify_shard_begin_device(LwkzgVerifyShard **shard_out, uint8_t *records_out /* n_local * 160, host */, const void *blobs_dev,
+                                          const void *commitments48_dev, const void *proofs48_dev, size_t n_local, const KZGSettings *s,
+                                          void *stream);
 C_KZG_RET lwkzg_verify_shard_partial(uint8_t *partial_out /* 328 */, LwkzgVerifyShard *shard, const uint8_t *records_all /* n_total * 160 */,
                                      size_t n_total, size_t first_index);
 void lwkzg_verify_shard_free(LwkzgVerifyShard *shard);

@@ -10,7 +10,7 @@ from .capi import (  # noqa: F401
     blob_to_kzg_commitment, blob_to_kzg_commitment_batch, blob_to_kzg_commitment_batch_device, commit_and_prove_batch_device,
     compute_blob_kzg_proof, compute_blob_kzg_proof_batch, compute_blob_kzg_proof_batch_device,
     compute_kzg_proof, compute_kzg_proof_batch, get_mode, lib, set_device, set_mode,
-    verify_blob_kzg_proof, verify_blob_kzg_proof_batch, verify_kzg_proof,
+    verify_blob_kzg_proof, verify_blob_kzg_proof_batch, verify_blob_kzg_proof_batch_device, verify_kzg_proof,
 )
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -93,6 +93,8 @@ def lib():
     l.lwkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_challenges_device.argtypes = [vp, vp, vp, sz, ps, vp]
+    l.lwkzg_verify_blob_kzg_proof_batch_device.argtypes = [C.POINTER(C.c_bool), vp, vp, vp, sz, ps, vp]
+    l.lwkzg_verify_shard_begin_device.argtypes = [C.POINTER(vp), C.c_char_p, vp, vp, vp, sz, ps, vp]
     l.lwkzg_commit_and_prove_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_verify_shard_begin.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
     l.lwkzg_verify_shard_partial.argtypes = [C.c_char_p, vp, C.c_char_p, sz, sz]
@@ -443,6 +445,14 @@ def verify_blob_kzg_proof_batch(blobs, commitments_bytes, proofs_bytes, n, ts):
     return bool(ok.value)
 
 
+def verify_blob_kzg_proof_batch_device(blobs_ptr, comm_ptr, proofs_ptr, n, ts, stream=None):
+    """verify_blob_kzg_proof_batch on DEVICE pointers (produced on `stream`); the verdict is a host bool, the call synchronous"""
+    ok = C.c_bool(False)
+    _check("lwkzg_verify_blob_kzg_proof_batch_device",
+           lib().lwkzg_verify_blob_kzg_proof_batch_device(C.byref(ok), blobs_ptr, comm_ptr, proofs_ptr, n, ts.ref(), stream))
+    return bool(ok.value)
+
+
 # ---- sharded batch verification (one batch, one r, one pairing check; include/lambdaworks_kzg_amd.h) ---------
 
 VERIFY_RECORD_BYTES = 160
@@ -461,6 +471,19 @@ class VerifyShard:
         _check("lwkzg_verify_shard_begin",
                lib().lwkzg_verify_shard_begin(C.byref(self.h), rec, blobs, commitments_bytes, proofs_bytes, n_local, ts.ref()))
         self.records = rec.raw[:VERIFY_RECORD_BYTES * n_local]
+
+    @classmethod
+    def from_device(cls, blobs_ptr, comm_ptr, proofs_ptr, n_local, ts, stream=None):
+        """the shard's inputs as device pointers (lwkzg_verify_shard_begin_device); the records come back to the host"""
+        self = cls.__new__(cls)
+        self.n = n_local
+        self.ts = ts
+        self.h = C.c_void_p()
+        rec = C.create_string_buffer(VERIFY_RECORD_BYTES * max(n_local, 1))
+        _check("lwkzg_verify_shard_begin_device",
+               lib().lwkzg_verify_shard_begin_device(C.byref(self.h), rec, blobs_ptr, comm_ptr, proofs_ptr, n_local, ts.ref(), stream))
+        self.records = rec.raw[:VERIFY_RECORD_BYTES * n_local]
+        return self
 
     def partial(self, records_all, n_total, first_index):
         assert len(records_all) == VERIFY_RECORD_BYTES * n_total

@@ -1384,6 +1384,86 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
     return C_KZG_OK;
 }
 
+// The same per-blob pass for a batch that is ALREADY on the device (lwkzg_verify_blob_kzg_proof_batch_device,
+// lwkzg_verify_shard_begin_device; /root/reference/src/lib.rs:525-614, 639-692): nothing crosses PCIe but the 160-byte records. Both point sets are
+// validated on side streams (decompression, subgroup test, canonical bytes, the multiples the linear combinations want) while the main
+// stream hashes ALL blobs in one launch over the caller's commitment bytes; where the validation's canonical bytes differ from the
+// caller's (a valid point in a non-canonical encoding) that blob's challenge is taken again over the canonical ones -- a launch that
+// exits at once otherwise. Then chunk by chunk: parse, y = p(z). `caller`: the stream the inputs were produced on (may be null).
+C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d_comm, const uint8_t *d_proofs, size_t n, int mode,
+                                uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, hipStream_t caller) {
+    if (!vb.owned) vb.hold = std::unique_lock<std::mutex>(c->verify_mu);
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    const int le = mode == LWKZG_MODE_CKZG;
+    const int bad = le ? kStatusBadArgs : kStatusError;
+    hipStream_t st = c->stream, sv = c->vstream, sc = c->aux[0];
+    if (caller && caller != st) {  // the inputs are whatever the caller's stream has produced by now
+        LWK_HIP(hipEventRecord(c->ev_join[3], caller));
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[3], 0));
+    }
+    WsUse wsu(c, st);
+    struct SideDrain {
+        Ctx *c;
+        bool armed = true;
+        ~SideDrain() {
+            if (!armed) return;
+            hipStreamSynchronize(c->vstream);
+            hipStreamSynchronize(c->aux[0]);
+        }
+    } drain{c};
+    if (vb.owned) {
+        if (!vb.pts_c) {
+            C_KZG_RET rcv = verify_buffers_alloc(vb, n < 64 ? 64 : n);
+            if (rcv != C_KZG_OK) return rcv;
+        }
+    } else {
+        C_KZG_RET rcv = vs_reserve(c, n);
+        if (rcv != C_KZG_OK) return rcv;
+        const VerifyBuffers &v = c->vs;
+        vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
+        vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
+        vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
+        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all;
+    }
+    C_KZG_RET rc = ctx_reserve(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != C_KZG_OK) return rc;
+    if (n > kMaxChunk && (rc = ws_long_reserve(c, n)) != C_KZG_OK) return rc;
+    Workspace &w = c->ws;
+    Fr *z = n > kMaxChunk ? w.z_long : w.z;
+    LWK_HIP(hipMemsetAsync(vb.status_all, 0, n * 4, st));
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
+    launch_validate_commitments(d_proofs, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p);
+    launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);
+    LWK_HIP(hipEventRecord(c->ev_join[0], sv));
+    launch_validate_commitments(d_comm, vb.canon_dev, vb.status_all, bad, n, sc, vb.pts_c, vb.kind_c);
+    launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, sc);
+    LWK_HIP(hipEventRecord(c->ev_join[1], sc));
+    launch_challenge(d_blobs, d_comm, z, le, n, st);
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
+    drain.armed = false;  // both side streams are joined into the main stream from here on
+    launch_challenge(d_blobs, vb.canon_dev, z, le, n, st, d_comm);  // only the blobs whose commitment bytes were not canonical
+    LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));
+    rc = first_status(c, vb.status_all, n, st);  // the validation's verdicts, before any more work is queued
+    if (rc != C_KZG_OK) return rc;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
+        coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, w.status, st);
+        launch_eval_quotient(w.scalars, z + off, w.scalars2, w.ybytes, le, m, st);
+        launch_fr_mont_to_bytes(z + off, w.zbytes, le, m, st);
+        LWK_HIP(hipMemcpyAsync(z32 + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
+        rc = first_status(c, w.status, m, st);  // (also the synchronisation that lets the next chunk reuse the staging buffers)
+        if (rc != C_KZG_OK) return rc;
+    }
+    return C_KZG_OK;
+}
+
 // sums[0] = sum r_i pi_i, sums[1] = sum r_i z_i pi_i, sums[2] = sum r_i C_i on the points verify_prepare_host kept
 C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n,
                                uint8_t sums[3][96], int infs[3]) {
