@@ -211,6 +211,8 @@ struct Ctx {
     // of one call (Fiat-Shamir hash, commitment validation) overlaps the ALU-bound MSM of the other.
     std::atomic<Ctx *> twin{nullptr};   // written under mu (pick_ctx), read without it by calls that run on the twin: release / acquire
     bool is_twin = false;
+    // lwkzg_reserve* has been called on this settings object (kept on the primary): its calls never grow pinned staging by themselves
+    std::atomic<bool> reserved{false};
     // Left alone, two proof pipelines that share the GPU fall into step (both hash, then both MSMs fight for the chip).
     // The ALU-bound phase of a proof call therefore takes turns across the two contexts: it waits for this event (the
     // previous call's phase, whichever context ran it) and records it again. Lives in the primary context.
@@ -239,9 +241,9 @@ struct Ctx {
     LoadTiming load_timing;
 };
 
-Ctx *ctx_of(const KZGSettings *s);
+Ctx *ctx_of(const KZGSettings *s);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise
 // is `c` still the live context that was given generation `gen`? Looks only at the registry, never at a caller's KZGSettings
-bool ctx_is_live(const Ctx *c, uint64_t gen);  // resolves fs, or the registry for hand-built settings; nullptr + error otherwise
+bool ctx_is_live(const Ctx *c, uint64_t gen);
 
 int mode_of(const KZGSettings *s);    // the semantics a call on `s` answers in: its own mode if it has one, else the default
 

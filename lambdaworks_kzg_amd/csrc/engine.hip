@@ -245,9 +245,14 @@ static size_t small_proof_host_limit() {
     return v;
 }
 
-static bool sph_reserve(Ctx *c, size_t n) {
+// at_reserve: called from lwkzg_reserve* (the place to pay for pinned memory). From inside a call (at_reserve = false) the staging
+// only grows on settings objects whose owner never reserved anything -- growing means a device synchronisation and up to 64 MiB of
+// hipHostMalloc, which a caller that reserved (a stream-capturing or latency-sensitive one) was promised not to meet:
+// there the call takes the GPU hash path instead.
+static bool sph_reserve(Ctx *c, size_t n, bool at_reserve = false) {
     SmallProofHost &h = c->sph;
     if (h.cap >= n) return true;
+    if (!at_reserve && c->primary->reserved.load(std::memory_order_acquire)) return false;
     hipDeviceSynchronize();  // a host function of an earlier call may still be reading the old buffers
     sph_free(h);
     size_t cap = 16;
@@ -310,6 +315,46 @@ static void chunk_hash_host_fn(void *p) {
         memset(h.dig + 32 * a->first, 0, 32 * a->count);   // (host_parallel_for does not throw; a wrong digest would show as a wrong proof, never silently)
     }
     delete a;
+}
+
+// Mid-size host-assisted hashing: the blobs leave on `sc` chunk by chunk and every chunk's host function runs on `sf` once its copy
+// has landed. All argument blocks are allocated BEFORE anything is enqueued (an allocation failure returns with nothing in flight);
+// if a host function cannot be launched, `join` is made to wait for everything this function has put in flight -- the side copies and
+// the host functions already queued -- so that the caller can return the error without leaving work running against its buffers and
+// the context's staging.
+static C_KZG_RET chunk_host_functions(Ctx *c, const uint8_t *blobs, size_t n, hipStream_t sc, hipStream_t sf, hipStream_t join,
+                                      void (*fn)(void *), const char *prof_name) {
+    SmallProofHost &h = c->sph;
+    const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
+    std::vector<ChunkHashArgs *> args;
+    for (size_t first = 0; first < n; first += per) {
+        ChunkHashArgs *a = new (std::nothrow) ChunkHashArgs{&h, first, n - first < per ? n - first : per};
+        if (!a) {
+            for (ChunkHashArgs *b : args) delete b;
+            return C_KZG_MALLOC;
+        }
+        args.push_back(a);
+    }
+    for (size_t k = 0; k < args.size(); k++) {
+        const size_t first = args[k]->first, cnt = args[k]->count;
+        hipError_t e = hipMemcpyAsync(h.blobs + first * (size_t)kBlobBytes, blobs + first * (size_t)kBlobBytes, cnt * (size_t)kBlobBytes,
+                                      hipMemcpyDeviceToHost, sc);
+        if (e == hipSuccess) e = hipEventRecord(h.chunk_done[k], sc);
+        if (e == hipSuccess) e = hipStreamWaitEvent(sf, h.chunk_done[k], 0);
+        if (e == hipSuccess) {
+            ProfScope p(prof_name, sf);
+            e = hipLaunchHostFunc(sf, fn, args[k]);
+        }
+        if (e != hipSuccess) {
+            for (size_t j = k; j < args.size(); j++) delete args[j];
+            set_error("host-assisted challenge: %s", hipGetErrorString(e));
+            (void)hipGetLastError();
+            if (hipEventRecord(c->ev_join[kMaxSplit - 2], sc) == hipSuccess) hipStreamWaitEvent(join, c->ev_join[kMaxSplit - 2], 0);
+            if (sf != join && hipEventRecord(c->ev_join[kMaxSplit - 3], sf) == hipSuccess) hipStreamWaitEvent(join, c->ev_join[kMaxSplit - 3], 0);
+            return C_KZG_ERROR;
+        }
+    }
+    return C_KZG_OK;
 }
 
 struct SmallProofArgs {
@@ -897,21 +942,11 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
         LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         LWK_HIP(hipMemcpyAsync(h.comm, comm48, n * 48, hipMemcpyDeviceToHost, sc));
-        const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
-        int k = 0;
-        for (size_t first = 0; first < n; first += per, k++) {
-            const size_t cnt = n - first < per ? n - first : per;
-            LWK_HIP(hipMemcpyAsync(h.blobs + first * (size_t)kBlobBytes, blobs + first * (size_t)kBlobBytes, cnt * (size_t)kBlobBytes, hipMemcpyDeviceToHost, sc));
-            LWK_HIP(hipEventRecord(h.chunk_done[k], sc));
-            LWK_HIP(hipStreamWaitEvent(st, h.chunk_done[k], 0));
-            ChunkHashArgs *a = new (std::nothrow) ChunkHashArgs{&h, first, cnt};
-            if (!a) return C_KZG_MALLOC;
-            ProfScope p("host_challenge_chunk", st);
-            const hipError_t e = hipLaunchHostFunc(st, chunk_hash_host_fn, a);
-            if (e != hipSuccess) {
-                delete a;
-                set_error("hipLaunchHostFunc failed: %s", hipGetErrorString(e));
-                return C_KZG_ERROR;
+        {
+            const C_KZG_RET rch = chunk_host_functions(c, blobs, n, sc, st, st, chunk_hash_host_fn, "host_challenge_chunk");
+            if (rch != C_KZG_OK) {
+                hipStreamWaitEvent(st, c->ev_join[0], 0);   // the validation on the side stream: nothing of this call outlives `st`
+                return rch;
             }
         }
         LWK_HIP(hipMemcpyAsync(w.zbytes, h.dig, n * 32, hipMemcpyHostToDevice, st));
@@ -982,22 +1017,9 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
         SmallProofHost &h = c->sph;
         hipStream_t sc = c->aux[0];
         LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
-        const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
-        int k = 0;
-        for (size_t first = 0; first < n; first += per, k++) {
-            const size_t cnt = n - first < per ? n - first : per;
-            LWK_HIP(hipMemcpyAsync(h.blobs + first * (size_t)kBlobBytes, blobs + first * (size_t)kBlobBytes, cnt * (size_t)kBlobBytes, hipMemcpyDeviceToHost, sc));
-            LWK_HIP(hipEventRecord(h.chunk_done[k], sc));
-            LWK_HIP(hipStreamWaitEvent(c->vstream, h.chunk_done[k], 0));
-            ChunkHashArgs *a = new (std::nothrow) ChunkHashArgs{&h, first, cnt};
-            if (!a) return C_KZG_MALLOC;
-            ProfScope p("host_midstate_chunk", c->vstream);
-            const hipError_t e = hipLaunchHostFunc(c->vstream, chunk_midstate_host_fn, a);
-            if (e != hipSuccess) {
-                delete a;
-                set_error("hipLaunchHostFunc failed: %s", hipGetErrorString(e));
-                return C_KZG_ERROR;
-            }
+        {
+            const C_KZG_RET rch = chunk_host_functions(c, blobs, n, sc, c->vstream, st, chunk_midstate_host_fn, "host_midstate_chunk");
+            if (rch != C_KZG_OK) return rch;   // (st has been made to wait for both side streams)
         }
         LWK_HIP(hipMemcpyAsync(mid, h.dig, n * 32, hipMemcpyHostToDevice, c->vstream));
     } else {
@@ -2554,16 +2576,32 @@ C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 
 // ------------------------------------------------------------------------------------------------
 // device-resident entry points
 
+// everything a device-resident call of up to max_batch blobs would otherwise allocate or synchronise for on first use: the workspace,
+// the pinned staging of the host-assisted challenge paths (once, at its final size), and -- for settings that answer in c-kzg mode --
+// the Lagrange form of the setup
+static C_KZG_RET reserve_ctx(Ctx *c, size_t max_batch) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    C_KZG_RET rc = ctx_reserve(c, max_batch);
+    if (rc != C_KZG_OK) return rc;
+    const size_t host_n = max_batch < mid_proof_host_limit() ? max_batch : mid_proof_host_limit();
+    const size_t small_n = max_batch < small_proof_host_limit() ? max_batch : small_proof_host_limit();
+    if (host_n || small_n) (void)sph_reserve(c, host_n > small_n ? host_n : small_n, true);   // (no pinned memory: the calls take the GPU hash)
+    return C_KZG_OK;
+}
+
 C_KZG_RET lwkzg_reserve(const KZGSettings *s, size_t max_batch) {
     Ctx *c = ctx_of(s);
     if (!c) return C_KZG_ERROR;
-    std::lock_guard<std::mutex> lk(c->mu);
-    return ctx_reserve(c, max_batch);
+    ensure_lagrange(c, mode_of(s));
+    C_KZG_RET rc = reserve_ctx(c, max_batch);
+    if (rc == C_KZG_OK) c->reserved.store(true, std::memory_order_release);
+    return rc;
 }
 
 // the same for a caller that will issue device-resident calls on `caller_streams` streams at once: with two or more the
-// settings' second context (own streams and workspace over the same tables, pick_ctx) is created and reserved HERE, so that
-// the first overlapped call neither allocates nor synchronises the device
+// settings' second context (own streams and workspace over the same tables, pick_ctx) is created and reserved HERE -- workspace and
+// pinned staging both --, so that the first overlapped call neither allocates nor synchronises the device
 C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int caller_streams) {
     C_KZG_RET rc = lwkzg_reserve(s, max_batch);
     if (rc != C_KZG_OK || caller_streams < 2 || twin_off()) return rc;  // LWKZG_TWIN=0: pick_ctx never uses a twin
@@ -2578,8 +2616,7 @@ C_KZG_RET lwkzg_reserve_streams(const KZGSettings *s, size_t max_batch, int call
             c->twin.store(t, std::memory_order_release);
         }
     }
-    std::lock_guard<std::mutex> lk(t->mu);
-    return ctx_reserve(t, max_batch);
+    return reserve_ctx(t, max_batch);
 }
 
 // ---- the two forms of the setup and their direct tables --------------------------------------------------------------------------
@@ -2752,6 +2789,7 @@ static void settings_follow_mode(Ctx *c, int mode) {
     Ctx *const twin = c->twin.load(std::memory_order_acquire);
     if (twin) lk_twin = std::unique_lock<std::mutex>(twin->mu);
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return;
+    c->lag_failed = false;   // an explicit request retries a derivation that once ran out of memory (only the lazy path stays off: ADVICE r04)
     tables_follow_mode(c, mode, true);
     hipDeviceSynchronize();
     sync_twin_tables(c);
@@ -2784,6 +2822,7 @@ static C_KZG_RET enable_direct_table(const KZGSettings *s, int window_bits, size
     auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = wall();
     // the primary form: the one the settings' mode commits over (Lagrange only if it can be had)
+    c->lag_failed = false;   // (an explicit request retries a derivation that once ran out of memory)
     const bool primary_lag = mode == LWKZG_MODE_CKZG && lagrange_prepare(c) == C_KZG_OK;
     if (forms >= 2 && !primary_lag) return C_KZG_MALLOC;  // (lagrange_prepare has said why)
     form_drop(c, false);  // (the old and the new tables need not fit side by side)

@@ -21,6 +21,16 @@
 
 namespace lwk {
 extern thread_local int tl_device_override;  // engine.hip: the device the next context of THIS thread is created on (-1: the default)
+namespace {
+// restored on every way out of the scope (an exception included): a thread that kept the override would create its later, unrelated
+// contexts on the wrong GPU
+struct DeviceOverride {
+    explicit DeviceOverride(int dev) { tl_device_override = dev; }
+    ~DeviceOverride() { tl_device_override = -1; }
+    DeviceOverride(const DeviceOverride &) = delete;
+    DeviceOverride &operator=(const DeviceOverride &) = delete;
+};
+}  // namespace
 }
 using namespace lwk;
 
@@ -103,9 +113,8 @@ C_KZG_RET replicate(LwkzgMulti *m) {
                 set_error("setup image to device %d: %s", m->dev[k], hipGetErrorString(e));
                 r = C_KZG_ERROR;
             } else {
-                tl_device_override = m->dev[k];
+                DeviceOverride on(m->dev[k]);
                 r = lwkzg_setup_import_device(&m->s[k], img);  // (chooses and builds this device's MSM engine like a load does)
-                tl_device_override = -1;
             }
             hipFree(img);
             return r;
@@ -126,12 +135,12 @@ C_KZG_RET multi_new(LwkzgMulti **out, const int *devices, size_t n_devices, Load
     try {
         m->dev.assign(devices, devices + n_devices);
         m->s.assign(n_devices, KZGSettings{nullptr, nullptr, nullptr});
-        tl_device_override = m->dev[0];
-        rc = load_first(&m->s[0]);
-        tl_device_override = -1;
+        {
+            DeviceOverride on(m->dev[0]);
+            rc = load_first(&m->s[0]);
+        }
         if (rc == C_KZG_OK) rc = replicate(m);
     } catch (const std::bad_alloc &) {
-        tl_device_override = -1;
         rc = C_KZG_MALLOC;
     }
     if (rc != C_KZG_OK) {

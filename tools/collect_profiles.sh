@@ -24,8 +24,11 @@ LWKZG_BENCH_DETAIL=$O/bench_detail_bucket_compiler_arm.json LWKZG_BUCKET_ASM=0 p
 LWKZG_BENCH_DETAIL=$O/bench_detail_bucket.json python bench.py --direct-bits 0 --no-cpu-baseline --no-config-legs > $O/bench_line_bucket.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_default_engine.json python bench.py --direct-bits default --no-cpu-baseline --no-config-legs > $O/bench_line_default_engine.json 2>> $O/bench_err.txt
 LWKZG_BENCH_DETAIL=$O/bench_detail_gpus2_gloo.json python bench.py --gpus 2 --backend gloo --steps 5 --no-cpu-baseline --no-extra-legs --direct-bits 13 > $O/bench_line_gpus2_gloo_one_device.json 2>> $O/bench_err.txt
-# per-kernel time of the headline command, of the default engine and of the bucket engine
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_line.json 2> $O/kt_err.txt
+# every profiled run below writes its detail file HERE (they used to overwrite ROOT/bench_detail.json, which then no longer
+# described the headline run)
+export LWKZG_BENCH_DETAIL=$O/bench_detail_profiled_runs.json
+# per-kernel time of the headline command (20 timed steps: the kernel's average over >= 20 launches), of the default engine and of the bucket engine
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > $O/kt_line.json 2> $O/kt_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_all -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/kt_all_line.json 2> $O/kt_all_err.txt
 rm -f $O/kt_all/*kernel_trace.csv
 LWKZG_DIRECT_ASM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cpp -o kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/kt_cpp_line.json 2> $O/kt_cpp_err.txt
