@@ -253,6 +253,7 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
     def leg(name, fn):
         try:
             out[name] = fn()
+            out[name]["leg_name"] = name
         except Exception as e:      # noqa: BLE001 -- the headline must survive a leg
             out[name] = {"error": repr(e)}
 
@@ -488,7 +489,16 @@ def _leg_compact(l):
     out = _pick(l, ("value", "unit", "ms_per_step", "steps"))
     name, ms = _dominant(l.get("kernels"))
     if name:
-        out["kernel"], out["kernel_ms"] = name, ms
+        # the dominant kernel as the share of the leg's wall clock its launches add up to (sum of launch durations / wall): a leg whose
+        # launches overlap on two caller streams shows a share above what one stream could have, where a per-launch average longer than
+        # the step looked like an accounting error; one-stream legs carry the per-launch average as well
+        k = l["kernels"][name]
+        wall_ms = (l.get("ms_per_step") or 0) * (l.get("steps") or 0)
+        out["kernel"] = name
+        if wall_ms > 0:
+            out["kernel_sum_over_wall"] = k.get("avg_ms", 0.0) * k.get("launches", 0) / wall_ms
+        if "two_streams" not in str(l.get("leg_name", "")) and ms is not None and ms <= (l.get("ms_per_step") or ms):
+            out["kernel_ms"] = ms
     for sub in ("ntt_roofline", "roofline"):
         if isinstance(l.get(sub), dict):
             out[sub] = _pick(l[sub], ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "traffic"))
@@ -554,7 +564,12 @@ def compact_line(res, detail_path=None):
         line["api_latency_ms"] = {k: v.get("median_ms") for k, v in res["api_latency"].items() if isinstance(v, dict)}
     if isinstance(res.get("configs"), dict):
         line["configs"] = {k: _leg_compact(v) for k, v in res["configs"].items()}
-    line["dist"] = _pick(res.get("dist") or {}, ("initialised", "backend", "ranks", "nccl_version"))
+    line["dist"] = _pick(res.get("dist") or {}, ("initialised", "backend", "ranks", "nccl_version", "devices"))
+    pr = (res.get("dist") or {}).get("per_rank")
+    if isinstance(pr, list) and len(pr) > 1:
+        line["dist"]["per_rank_value"] = [r.get("value") for r in pr]
+    if isinstance(res.get("box"), dict):
+        line["box"] = res["box"]
     line.update(_pick(res, ("msm_path", "hip_first_use_init_s", "setup_load_s", "direct_table_build_s", "direct_table_build_s_max_over_ranks")))
     if detail_path:
         line["detail"] = detail_path
@@ -732,6 +747,8 @@ def main():
             K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, ts, stream,
                                                   d_status.data_ptr())
 
+    local_elapsed = [0.0]     # this rank's own clock over the last timed region (the contract's number is the max over ranks)
+
     def timed_region(steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
         for _ in range(warmup):
@@ -754,6 +771,7 @@ def main():
         el = time.perf_counter() - t0
         capi.profile_enable(False)
         pr = capi.profile_report()
+        local_elapsed[0] = el
         if distributed:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -852,6 +870,25 @@ def main():
         h_proofs = b"".join(K.compute_blob_kzg_proof_batch(h_blobs, h_comms, ts))
 
     elapsed, prof = timed_region(args.steps, args.warmup)
+
+    # who ran where, and how fast each rank was by its own clock (the contract's `value` uses the slowest): rank, device ordinal, a hash
+    # of the device's uuid, the shader clock it holds under a short multiply-add stream, its own ops/s -- so that a SCALE record shows
+    # that N ranks on N devices took part, and a profiles/ summary can be matched to the box a line came from
+    import hashlib
+    props = torch.cuda.get_device_properties(dev)
+    uuid = str(getattr(props, "uuid", "")) or "%s/%d" % (props.name, dev_index)
+    try:
+        clock_mhz = capi.clock_probe_mhz()
+    except Exception:       # noqa: BLE001 -- a measurement aid must not take the run down
+        clock_mhz = 0.0
+    me = {"rank": rank, "device": dev_index, "gpu": props.name, "gpu_uuid_sha256_12": hashlib.sha256(uuid.encode()).hexdigest()[:12],
+          "clock_mhz_under_mad_probe": round(clock_mhz, 1), "elapsed_s": local_elapsed[0],
+          "value": (n * args.steps / local_elapsed[0]) if local_elapsed[0] > 0 and args.op != "tiled_msm" else None}
+    per_rank = [me]
+    if distributed:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        per_rank = gathered
 
     if args.op == "commit" and not args.no_extra_legs and rank == 0:
         # (c) the same batch through the host-pointer C ABI (blobs in pageable host memory: H2D of 128 KiB per blob and D2H
@@ -957,7 +994,11 @@ def main():
                                                  "allocates window j + 1, and kernels = what was left of k_direct_build after the last allocation returned" if direct_bits else None,
             "direct_table_build_note": "every rank builds its own table from the broadcast setup points, once, outside the timed region" if direct_bits else None,
         }
+        dist_info["per_rank"] = per_rank
+        dist_info["devices"] = [r["device"] for r in per_rank]
         res["dist"] = dist_info
+        res["box"] = {"gpu": per_rank[0]["gpu"], "gpu_uuid_sha256_12": per_rank[0]["gpu_uuid_sha256_12"],
+                      "clock_mhz_under_mad_probe": per_rank[0]["clock_mhz_under_mad_probe"]}
         res["hbm_budget"] = hbm_budget
         res.update(extra)
         if world > 1:

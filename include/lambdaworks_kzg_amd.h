@@ -295,6 +295,18 @@ C_KZG_RET lwkzg_multi_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_
                                               const LwkzgMulti *m, size_t *first_bad);
 C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments, const Bytes48 *proofs, size_t n,
                                                   const LwkzgMulti *m);
+/* The same three calls for shards that are ALREADY in HBM: device k's shard is n_per_device[k] blobs behind blobs_dev[k] (a pointer
+ * on device k), results in place behind out48_dev[k] (48 bytes per blob). Nothing crosses PCIe but verdicts and, for the
+ * verification, the 160-byte records. first_bad counts through the shards in device order. Synchronous. */
+C_KZG_RET lwkzg_multi_blob_to_kzg_commitment_batch_device(void *const *out48_dev, const void *const *blobs_dev, const size_t *n_per_device,
+                                                          const LwkzgMulti *m, size_t *first_bad);
+C_KZG_RET lwkzg_multi_compute_blob_kzg_proof_batch_device(void *const *out48_dev, const void *const *blobs_dev, const void *const *commitments48_dev,
+                                                          const size_t *n_per_device, const LwkzgMulti *m, size_t *first_bad);
+C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch_device(bool *ok, const void *const *blobs_dev, const void *const *commitments48_dev,
+                                                         const void *const *proofs48_dev, const size_t *n_per_device, const LwkzgMulti *m);
+/* THE shard rule (multi.hip and lambdaworks_kzg_amd/dist.py both use this function): item i of n_items belongs to part
+ * floor(i * parts / n_items); part k owns [*first, *first + *count) = [ceil(k n / parts), ceil((k + 1) n / parts)). */
+C_KZG_RET lwkzg_shard_range(size_t n_items, size_t parts, size_t k, size_t *first, size_t *count);
 /* BASELINE configs[4] over the devices: out = sum_k scalars[k] * g1[k mod 4096], n_terms a positive multiple of 4096, HOST-resident
  * big-endian scalars; whole tiles per device, one 48-byte partial sum back from each, added on the host. */
 C_KZG_RET lwkzg_multi_g1_msm_tiled(uint8_t out48[48], const uint8_t *scalars_be, size_t n_terms, const LwkzgMulti *m);
@@ -361,6 +373,9 @@ size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap);
 /* First use of the HIP runtime by this process (device context + this library's code object), so that a caller can pay
  * and time it apart from its first real call. 0, or -1 without a GPU. */
 int lwkzg_runtime_init(void);
+/* The shader clock (MHz) the current device holds under ~0.4 ms of dense multiply-adds on every SIMD (clock64 against the 100 MHz
+ * wall clock). A measurement aid: bench.py prints it with a hash of the GPU's uuid so that profiles can be matched to boxes. */
+C_KZG_RET lwkzg_clock_probe_mhz(double *mhz);
 /* MSM plan constants, for roofline arithmetic in bench.py */
 int lwkzg_msm_window_bits(void);
 int lwkzg_msm_num_windows(void);

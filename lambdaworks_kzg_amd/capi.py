@@ -56,6 +56,9 @@ EXPORTED_SYMBOLS = [
     "lwkzg_multi_compute_blob_kzg_proof_batch", "lwkzg_multi_compute_kzg_proof_batch", "lwkzg_multi_verify_blob_kzg_proof_batch",
     "lwkzg_multi_g1_msm_tiled",
     "lwkzg_release_context", "lwkzg_verify_shard_begin", "lwkzg_verify_shard_partial", "lwkzg_verify_shard_free", "lwkzg_verify_shards_finish",
+    "lwkzg_verify_blob_kzg_proof_batch_device", "lwkzg_verify_shard_begin_device", "lwkzg_shard_range",
+    "lwkzg_multi_blob_to_kzg_commitment_batch_device", "lwkzg_multi_compute_blob_kzg_proof_batch_device",
+    "lwkzg_multi_verify_blob_kzg_proof_batch_device", "lwkzg_clock_probe_mhz",
 ]
 
 _lib = None
@@ -94,6 +97,11 @@ def lib():
     l.lwkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_compute_challenges_device.argtypes = [vp, vp, vp, sz, ps, vp]
     l.lwkzg_verify_blob_kzg_proof_batch_device.argtypes = [C.POINTER(C.c_bool), vp, vp, vp, sz, ps, vp]
+    l.lwkzg_shard_range.argtypes = [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]
+    pvp, psz = C.POINTER(vp), C.POINTER(sz)
+    l.lwkzg_multi_blob_to_kzg_commitment_batch_device.argtypes = [pvp, pvp, psz, vp, psz]
+    l.lwkzg_multi_compute_blob_kzg_proof_batch_device.argtypes = [pvp, pvp, pvp, psz, vp, psz]
+    l.lwkzg_multi_verify_blob_kzg_proof_batch_device.argtypes = [C.POINTER(C.c_bool), pvp, pvp, pvp, psz, vp]
     l.lwkzg_verify_shard_begin_device.argtypes = [C.POINTER(vp), C.c_char_p, vp, vp, vp, sz, ps, vp]
     l.lwkzg_commit_and_prove_batch_device.argtypes = [vp, vp, vp, sz, ps, vp, vp]
     l.lwkzg_verify_shard_begin.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, ps]
@@ -176,12 +184,27 @@ def direct_table_bytes(window_bits, row_bytes=112):
     return ((nw - 1) * 4096 * (1 << (window_bits - 1)) + 4096 * (1 << top)) * row_bytes
 
 
+def shard_range(n_items, parts, k):
+    """(first, count) of part k: the library's one shard rule (lwkzg_shard_range; csrc/multi.hip and dist.py both go through it)"""
+    first, count = C.c_size_t(0), C.c_size_t(0)
+    _check("lwkzg_shard_range", lib().lwkzg_shard_range(n_items, parts, k, C.byref(first), C.byref(count)))
+    return first.value, count.value
+
+
 def set_mode(mode):
     return lib().lwkzg_set_mode(mode)
 
 
 def get_mode():
     return lib().lwkzg_get_mode()
+
+
+def clock_probe_mhz():
+    """the shader clock the current device holds under a short dense multiply-add stream (lwkzg_clock_probe_mhz)"""
+    mhz = C.c_double(0.0)
+    lib().lwkzg_clock_probe_mhz.argtypes = [C.POINTER(C.c_double)]
+    _check("lwkzg_clock_probe_mhz", lib().lwkzg_clock_probe_mhz(C.byref(mhz)))
+    return mhz.value
 
 
 def runtime_init():
@@ -379,6 +402,32 @@ class MultiSetup:
         _check("lwkzg_multi_compute_kzg_proof_batch",
                lib().lwkzg_multi_compute_kzg_proof_batch(out, ys, blobs, zs, n, self.h, C.byref(self.first_bad)))
         return [(out.raw[48 * i:48 * i + 48], ys.raw[32 * i:32 * i + 32]) for i in range(n)]
+
+    # ---- shards already in HBM: lists of per-device device pointers and counts (device k's shard on device k)
+    @staticmethod
+    def _ptrs(ptrs):
+        return (C.c_void_p * len(ptrs))(*ptrs)
+
+    def blob_to_kzg_commitment_batch_device(self, out_ptrs, blob_ptrs, counts):
+        cnt = (C.c_size_t * len(counts))(*counts)
+        self.first_bad = C.c_size_t(0)
+        _check("lwkzg_multi_blob_to_kzg_commitment_batch_device",
+               lib().lwkzg_multi_blob_to_kzg_commitment_batch_device(self._ptrs(out_ptrs), self._ptrs(blob_ptrs), cnt, self.h, C.byref(self.first_bad)))
+
+    def compute_blob_kzg_proof_batch_device(self, out_ptrs, blob_ptrs, comm_ptrs, counts):
+        cnt = (C.c_size_t * len(counts))(*counts)
+        self.first_bad = C.c_size_t(0)
+        _check("lwkzg_multi_compute_blob_kzg_proof_batch_device",
+               lib().lwkzg_multi_compute_blob_kzg_proof_batch_device(self._ptrs(out_ptrs), self._ptrs(blob_ptrs), self._ptrs(comm_ptrs), cnt, self.h,
+                                                                     C.byref(self.first_bad)))
+
+    def verify_blob_kzg_proof_batch_device(self, blob_ptrs, comm_ptrs, proof_ptrs, counts):
+        cnt = (C.c_size_t * len(counts))(*counts)
+        ok = C.c_bool(False)
+        _check("lwkzg_multi_verify_blob_kzg_proof_batch_device",
+               lib().lwkzg_multi_verify_blob_kzg_proof_batch_device(C.byref(ok), self._ptrs(blob_ptrs), self._ptrs(comm_ptrs), self._ptrs(proof_ptrs), cnt,
+                                                                    self.h))
+        return bool(ok.value)
 
     def verify_blob_kzg_proof_batch(self, blobs, commitments, proofs, n):
         ok = C.c_bool(False)

@@ -1671,6 +1671,65 @@ extern "C" int lwkzg_runtime_init(void) {
     return 0;
 }
 
+// What shader clock does this box hold under a dense multiply-add stream? One wave per SIMD runs ~0.4 ms of dependent v_mad_u64_u32
+// and reads the shader clock (clock64) and the 100 MHz wall clock (wall_clock64) around it; MHz = the ratio, averaged over the waves.
+// bench.py prints it next to a hash of the GPU's uuid so that a profiles/ summary can be matched to the box a line came from (boxes
+// of this pool differ by several per cent). Launched on a stream of its own -- never the NULL stream (see lwkzg_runtime_init).
+__global__ __launch_bounds__(256) void k_clock_probe(unsigned long long *out, uint32_t iters, uint32_t seed) {
+    uint64_t acc = seed + threadIdx.x;
+    const uint32_t a = (seed * 2654435761u) | 1u, b = seed ^ 0x9e3779b9u;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) acc = (uint64_t)(uint32_t)acc * a + (acc >> 32) + b;
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        out[3 * w] = (unsigned long long)(c1 - c0);
+        out[3 * w + 1] = (unsigned long long)(w1 - w0);
+        out[3 * w + 2] = acc;
+    }
+}
+
+extern "C" C_KZG_RET lwkzg_clock_probe_mhz(double *mhz) {
+    if (!mhz) return C_KZG_BADARGS;
+    *mhz = 0;
+    if (!gpu_available()) {
+        set_error("no GPU: lambdaworks_kzg_amd has no CPU fallback");
+        return C_KZG_ERROR;
+    }
+    LWK_HIP(hipSetDevice(g_default_device.load()));
+    const unsigned wgs = 256, waves = wgs * 4;
+    unsigned long long *d = nullptr;
+    hipStream_t st = nullptr;
+    LWK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (hipMalloc((void **)&d, waves * 3 * sizeof(unsigned long long)) != hipSuccess) {
+        hipStreamDestroy(st);
+        return C_KZG_MALLOC;
+    }
+    std::vector<unsigned long long> h(waves * 3);
+    hipError_t e = hipSuccess;
+    for (int rep = 0; rep < 3 && e == hipSuccess; rep++) {   // (the last of three back-to-back launches is the one read)
+        hipLaunchKernelGGL(k_clock_probe, dim3(wgs), dim3(256), 0, st, d, 250u, 12345u + rep);
+        e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipFree(d);
+    hipStreamDestroy(st);
+    if (e != hipSuccess) {
+        set_error("lwkzg_clock_probe_mhz: %s", hipGetErrorString(e));
+        return C_KZG_ERROR;
+    }
+    double clk = 0, wall = 0;
+    for (unsigned w = 0; w < waves; w++) {
+        clk += (double)h[3 * w];
+        wall += (double)h[3 * w + 1];
+    }
+    if (wall > 0) *mhz = clk / wall * 100.0;   // wall_clock64 ticks at 100 MHz
+    return C_KZG_OK;
+}
+
 // JSON: where the milliseconds of this settings object's load and of its last table build went
 extern "C" size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap) {
     Ctx *c = ctx_of(s);

@@ -41,9 +41,11 @@ struct LwkzgMulti {
 
 namespace {
 
+// THE shard rule of this library (lwkzg_shard_range, which dist.py calls too): item i of n belongs to part floor(i parts / n), i.e.
+// part k owns [ceil(k n / parts), ceil((k + 1) n / parts)) -- contiguous, covering [0, n) exactly once, sizes differing by at most one
 inline void shard_range(size_t n, size_t k, size_t parts, size_t &lo, size_t &hi) {
-    lo = n * k / parts;
-    hi = n * (k + 1) / parts;
+    lo = (n * k + parts - 1) / parts;
+    hi = (n * (k + 1) + parts - 1) / parts;
 }
 
 // f(k) on one host thread per device; the first failing shard (lowest k) decides the return code and its thread's error text
@@ -178,6 +180,15 @@ C_KZG_RET sharded_batch(const LwkzgMulti *m, size_t n, size_t *first_bad, Call c
 
 extern "C" {
 
+C_KZG_RET lwkzg_shard_range(size_t n_items, size_t parts, size_t k, size_t *first, size_t *count) {
+    if (!first || !count || parts == 0 || k >= parts) return C_KZG_BADARGS;
+    size_t lo, hi;
+    shard_range(n_items, k, parts, lo, hi);
+    *first = lo;
+    *count = hi - lo;
+    return C_KZG_OK;
+}
+
 C_KZG_RET lwkzg_multi_load(LwkzgMulti **out, const uint8_t *g1_bytes, size_t n1, const uint8_t *g2_bytes, size_t n2, const int *devices,
                            size_t n_devices) {
     return multi_new(out, devices, n_devices, [&](KZGSettings *s) { return load_trusted_setup(s, g1_bytes, n1, g2_bytes, n2); });
@@ -233,6 +244,100 @@ C_KZG_RET lwkzg_multi_compute_kzg_proof_batch(KZGProof *proofs_out, Bytes32 *ys_
     return sharded_batch(m, n, first_bad, [&](const KZGSettings *s, size_t lo, size_t cnt, size_t *fb) {
         return lwkzg_compute_kzg_proof_batch(proofs_out + lo, ys_out + lo, blobs + lo, zs + lo, cnt, s, fb);
     });
+}
+
+// ---- the same calls for shards that are ALREADY in HBM: device k's shard is n_per_device[k] blobs behind blobs_dev[k] (pointers on
+// device k), results in place behind out48_dev[k]. A node-level caller that produces or receives its blobs on the GPUs never touches
+// pageable host memory; nothing crosses PCIe but the verdicts. first_bad counts through the shards in device order.
+}  // extern "C" (a template cannot have C linkage)
+namespace {
+template <class Call>
+C_KZG_RET sharded_device_batch(const LwkzgMulti *m, const size_t *n_per_device, size_t *first_bad, Call call) {
+    if (!m || !n_per_device) return C_KZG_BADARGS;
+    if (first_bad) *first_bad = (size_t)-1;
+    const size_t parts = m->s.size();
+    std::vector<size_t> bad(parts, (size_t)-1);
+    C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
+        const size_t cnt = n_per_device[k];
+        if (!cnt) return C_KZG_OK;
+        LWK_HIP(hipSetDevice(m->dev[k]));
+        int32_t *d_status = nullptr;
+        LWK_HIP(hipMalloc((void **)&d_status, cnt * sizeof(int32_t)));
+        std::vector<int32_t> h(cnt);
+        int r = call(k, cnt, d_status);
+        if (r == C_KZG_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), d_status, cnt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)) {
+            set_error("device %d: %s", m->dev[k], hipGetErrorString(hipGetLastError()));
+            r = C_KZG_ERROR;
+        }
+        hipFree(d_status);
+        if (r != C_KZG_OK) return r;
+        for (size_t i = 0; i < cnt; i++)
+            if (h[i] != 0) {
+                bad[k] = i;
+                set_error("blob %zu of device %d's shard rejected (status %d)", i, m->dev[k], h[i]);
+                return h[i];   // (the status words are C_KZG_RET values: ERROR in reference mode, BADARGS in c-kzg mode)
+            }
+        return C_KZG_OK;
+    });
+    if (first_bad) {
+        size_t base = 0;
+        for (size_t k = 0; k < parts && *first_bad == (size_t)-1; k++) {
+            if (bad[k] != (size_t)-1) *first_bad = base + bad[k];
+            base += n_per_device[k];
+        }
+    }
+    return rc;
+}
+}  // namespace
+extern "C" {
+
+C_KZG_RET lwkzg_multi_blob_to_kzg_commitment_batch_device(void *const *out48_dev, const void *const *blobs_dev, const size_t *n_per_device,
+                                                          const LwkzgMulti *m, size_t *first_bad) {
+    if (!out48_dev || !blobs_dev) return C_KZG_BADARGS;
+    return sharded_device_batch(m, n_per_device, first_bad, [&](size_t k, size_t cnt, int32_t *d_status) -> int {
+        return lwkzg_blob_to_kzg_commitment_batch_device(out48_dev[k], blobs_dev[k], cnt, &m->s[k], nullptr, d_status);
+    });
+}
+
+C_KZG_RET lwkzg_multi_compute_blob_kzg_proof_batch_device(void *const *out48_dev, const void *const *blobs_dev, const void *const *commitments48_dev,
+                                                          const size_t *n_per_device, const LwkzgMulti *m, size_t *first_bad) {
+    if (!out48_dev || !blobs_dev || !commitments48_dev) return C_KZG_BADARGS;
+    return sharded_device_batch(m, n_per_device, first_bad, [&](size_t k, size_t cnt, int32_t *d_status) -> int {
+        return lwkzg_compute_blob_kzg_proof_batch_device(out48_dev[k], blobs_dev[k], commitments48_dev[k], cnt, &m->s[k], nullptr, d_status);
+    });
+}
+
+// ONE batch (one r, one linear combination, one pairing check) whose shards live on the devices: the records and the partial sums are
+// all that reaches the host
+C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch_device(bool *ok, const void *const *blobs_dev, const void *const *commitments48_dev,
+                                                         const void *const *proofs48_dev, const size_t *n_per_device, const LwkzgMulti *m) {
+    if (!ok) return C_KZG_BADARGS;
+    *ok = false;
+    if (!m || !blobs_dev || !commitments48_dev || !proofs48_dev || !n_per_device) return C_KZG_BADARGS;
+    const size_t parts = m->s.size();
+    std::vector<LwkzgVerifyShard *> shard(parts, nullptr);
+    std::vector<size_t> first(parts + 1, 0);
+    for (size_t k = 0; k < parts; k++) first[k + 1] = first[k] + n_per_device[k];
+    const size_t n = first[parts];
+    if (n == 0) return verify_blob_kzg_proof_batch(ok, nullptr, nullptr, nullptr, 0, &m->s[0]);   // (the empty batch's mode-dependent verdict)
+    std::vector<uint8_t> records, partials;
+    try {
+        records.resize(n * LWKZG_VERIFY_RECORD_BYTES + 1);
+        partials.resize(parts * LWKZG_VERIFY_PARTIAL_BYTES);
+    } catch (const std::bad_alloc &) {
+        return C_KZG_MALLOC;
+    }
+    C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
+        return lwkzg_verify_shard_begin_device(&shard[k], records.data() + first[k] * LWKZG_VERIFY_RECORD_BYTES, blobs_dev[k], commitments48_dev[k],
+                                               proofs48_dev[k], n_per_device[k], &m->s[k], nullptr);
+    });
+    if (rc == C_KZG_OK)
+        rc = on_every_device(parts, [&](size_t k) -> int {
+            return lwkzg_verify_shard_partial(partials.data() + k * LWKZG_VERIFY_PARTIAL_BYTES, shard[k], records.data(), n, first[k]);
+        });
+    for (LwkzgVerifyShard *sh : shard) lwkzg_verify_shard_free(sh);
+    if (rc != C_KZG_OK) return rc;
+    return lwkzg_verify_shards_finish(ok, partials.data(), parts, n, &m->s[0]);
 }
 
 // verify_blob_kzg_proof_batch (src/lib.rs:525-692) over the devices: per-blob work sharded, ONE r, ONE linear combination, ONE pairing check

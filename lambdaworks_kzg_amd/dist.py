@@ -19,9 +19,8 @@ def shard_range(n_items, world_size, rank):
     Returns (start, count) for `rank`; the shards cover [0, n_items) exactly once."""
     if world_size <= 0 or not (0 <= rank < world_size):
         raise ValueError("bad rank/world_size")
-    start = -(-rank * n_items // world_size)          # ceil(rank * n / G)
-    end = -(-(rank + 1) * n_items // world_size)
-    return start, end - start
+    # ONE rule for the C library's node-level entry points (csrc/multi.hip) and for this module: the library's own function
+    return capi.shard_range(n_items, world_size, rank)
 
 
 def owner_of(item, n_items, world_size):

@@ -210,6 +210,31 @@ def test_c_consumers_compile_and_link_against_the_header_and_library(tmp_path):
         assert os.path.exists(exe)
 
 
+def test_one_shard_rule_from_c_and_python(tmp_path):
+    """csrc/multi.hip cut its shards at floor(n k / G) while dist.py and the header said ceil -- both contiguous, two rules
+    for one contract. There is ONE function now (lwkzg_shard_range: part k owns [ceil(k n / G), ceil((k + 1) n / G)), i.e. item i belongs
+    to part floor(i G / n)); multi.hip uses it, dist.shard_range calls it. A C program prints it for fewer items than parts, one more
+    than parts, none at all, and the bench's shapes; the closed form and the Python binding must agree line by line."""
+    from lambdaworks_kzg_amd import dist as D
+    lib_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "lib")
+    exe = str(tmp_path / "shard_rule")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "shard_rule_harness.c"), "-o", exe, "-L", lib_dir, "-llambdaworks_kzg",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    cases = [(3, 8), (9, 8), (0, 8), (8, 8), (1, 1), (0, 1), (5, 2), (7, 3), (4096, 8), (1024, 3), (256, 5)]
+    out = subprocess.check_output([exe] + [str(x) for c in cases for x in c], text=True).split("\n")
+    rows = [tuple(int(x) for x in l.split()) for l in out if l.strip()]
+    assert len(rows) == sum(g for _, g in cases)
+    for n, g, k, first, count in rows:
+        lo, hi = -(-k * n // g), -(-(k + 1) * n // g)
+        assert (first, count) == (lo, hi - lo), (n, g, k)
+        assert D.shard_range(n, g, k) == (first, count)
+        for i in range(first, first + count):
+            assert D.owner_of(i, n, g) == k == i * g // n
+    src = open(os.path.join(ROOT, "lambdaworks_kzg_amd", "csrc", "multi.hip")).read()
+    assert "n * k / parts" not in src       # the old floor rule
+
+
 def test_generated_constant_tables_are_current():
     """field29_consts.inc / fr28_consts.inc are what tools/gen_field_consts.py prints (p, r, their Montgomery constants and
     the borrowed multiples the lazy subtractions add)."""

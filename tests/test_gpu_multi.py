@@ -148,3 +148,49 @@ def test_multi_from_a_c_program(K, single, tmp_path, devices, mode):
             assert kv["bad_blob_rc"] == "%d first_bad %d" % (K.C_KZG_BADARGS, n - 2)
     finally:
         single.set_mode(-1)
+
+
+@pytest.mark.parametrize("counts_of", [lambda g: [5] * g, lambda g: [0] + [3] * (g - 1) if g > 1 else [4], lambda g: [70] + [1] * (g - 1)])
+def test_multi_device_resident_shards(K, single, multi, counts_of):
+    """lwkzg_multi_*_device: every device's shard already in HBM (on a one-GPU box: several contexts on device 0, each with its own
+    buffers), results in place; commitments, proofs and the one-r batch verification equal the single-device calls on the concatenated
+    batch; an empty shard is allowed; a rejected blob is reported by its index through the shards"""
+    import torch
+    g = multi.device_count()
+    counts = counts_of(g)
+    n = sum(counts)
+    data = B.synthetic_batch(84000 + n, n)
+    want_c = K.blob_to_kzg_commitment_batch(data, single)
+    want_p = K.compute_blob_kzg_proof_batch(data, b"".join(want_c), single)
+    d_blobs, d_comm, d_proof, off = [], [], [], 0
+    for c in counts:
+        chunk = data[off * B.BYTES_PER_BLOB:(off + c) * B.BYTES_PER_BLOB]
+        d_blobs.append(torch.frombuffer(bytearray(chunk) if c else bytearray(1), dtype=torch.uint8).cuda())
+        d_comm.append(torch.zeros(max(48 * c, 1), dtype=torch.uint8, device="cuda"))
+        d_proof.append(torch.zeros(max(48 * c, 1), dtype=torch.uint8, device="cuda"))
+        off += c
+    torch.cuda.synchronize()
+    ptr = lambda ts: [t.data_ptr() for t in ts]
+    multi.blob_to_kzg_commitment_batch_device(ptr(d_comm), ptr(d_blobs), counts)
+    got_c = b"".join(bytes(t.cpu().numpy())[:48 * c] for t, c in zip(d_comm, counts))
+    assert got_c == b"".join(want_c)
+    multi.compute_blob_kzg_proof_batch_device(ptr(d_proof), ptr(d_blobs), ptr(d_comm), counts)
+    got_p = b"".join(bytes(t.cpu().numpy())[:48 * c] for t, c in zip(d_proof, counts))
+    assert got_p == b"".join(want_p)
+    assert multi.verify_blob_kzg_proof_batch_device(ptr(d_blobs), ptr(d_comm), ptr(d_proof), counts) is True
+    # one proof replaced by another blob's (a valid point): rejected, whichever shard it sits in
+    k = max(range(g), key=lambda j: counts[j])
+    keep = d_proof[k][:48].clone()
+    d_proof[k][:48] = torch.frombuffer(bytearray(want_p[(sum(counts[:k]) + 1) % n]), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert multi.verify_blob_kzg_proof_batch_device(ptr(d_blobs), ptr(d_comm), ptr(d_proof), counts) is (n == 1)
+    d_proof[k][:48] = keep
+    # a commitment that is not a point: an error, reported with its index through the shards
+    bad_at = sum(counts[:k]) + counts[k] - 1
+    d_comm[k][48 * (counts[k] - 1):48 * counts[k]] = 0
+    torch.cuda.synchronize()
+    with pytest.raises(K.KzgError) as e:
+        multi.compute_blob_kzg_proof_batch_device(ptr(d_proof), ptr(d_blobs), ptr(d_comm), counts)
+    assert e.value.rc == K.C_KZG_ERROR and multi.first_bad.value == bad_at
+    with pytest.raises(K.KzgError):
+        multi.verify_blob_kzg_proof_batch_device(ptr(d_blobs), ptr(d_comm), ptr(d_proof), counts)
