@@ -149,10 +149,14 @@ void free_direct_table(DirectTable &t) {
     t.bytes = 0;
 }
 
-hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &t, size_t row_bytes, hipStream_t st, double *ms) {
+// in_place: `t` already holds a table of the same width and row size (over ANOTHER point set: the other form of the setup) -- its
+// window allocations are kept and only the build kernels run again over them: no hipFree, no hipMalloc, no wait for the driver's
+// scrub of 275 GB just released (lwkzg_settings_set_mode on a table that leaves no room for a second one: 7-8.5 s -> the kernels' 0.5 s)
+hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &t, size_t row_bytes, hipStream_t st, double *ms, bool in_place) {
     const DirectPlanRt P = make_plan(bits);
     if (!P.entries || P.nw > kDirectMaxWindows) return hipErrorInvalidValue;
-    free_direct_table(t);
+    if (in_place && (t.nw != P.nw || t.bytes != P.entries * row_bytes || !t.win_dev)) return hipErrorInvalidValue;
+    if (!in_place) free_direct_table(t);
     G1Affine29 *qbase = nullptr;
     F29<2> *scratch = nullptr;
     const double t0 = wall_ms();
@@ -161,7 +165,7 @@ hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &t, 
     const size_t n_threads = bits >= 14 ? 256 * 1024 : 64 * 1024;
     hipError_t e = hipMalloc((void **)&qbase, (size_t)P.nw * kBlobElems * sizeof(G1Affine29));
     if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)kChunk * 5 * n_threads * sizeof(F29<2>));
-    if (e == hipSuccess) e = hipMalloc((void **)&t.win_dev, kDirectMaxWindows * sizeof(uint64_t));
+    if (e == hipSuccess && !in_place) e = hipMalloc((void **)&t.win_dev, kDirectMaxWindows * sizeof(uint64_t));
     const double t1 = wall_ms();
     double malloc_ms = 0, t_last_malloc = t1;
     if (e == hipSuccess) {
@@ -173,17 +177,19 @@ hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &t, 
         for (int j = 0; j < P.nw && e == hipSuccess; j++) {
             const bool top = j == P.nw - 1;
             const size_t rows = (size_t)kBlobElems * (top ? P.htop : P.h);
-            const double a0 = wall_ms();
-            e = hipMalloc(&t.win[j], rows * row_bytes);
-            t_last_malloc = wall_ms();
-            malloc_ms += t_last_malloc - a0;
-            if (e != hipSuccess) break;
-            t.bytes += rows * row_bytes;
+            if (!in_place) {
+                const double a0 = wall_ms();
+                e = hipMalloc(&t.win[j], rows * row_bytes);
+                t_last_malloc = wall_ms();
+                malloc_ms += t_last_malloc - a0;
+                if (e != hipSuccess) break;
+                t.bytes += rows * row_bytes;
+            }
             ProfScope p("k_direct_build", st);
             hipLaunchKernelGGL(k_direct_build, dim3((unsigned)(n_threads / 256)), dim3(256), 0, st, qbase + (size_t)j * kBlobElems,
                                (G1Affine29 *)t.win[j], (size_t)kBlobElems, scratch, n_threads, (int)(top ? P.htop : P.h), row_bytes);
         }
-        if (e == hipSuccess) {
+        if (e == hipSuccess && !in_place) {
             uint64_t h[kDirectMaxWindows] = {};
             for (int j = 0; j < P.nw; j++) h[j] = (uint64_t)(uintptr_t)t.win[j];
             e = hipMemcpyAsync(t.win_dev, h, sizeof h, hipMemcpyHostToDevice, st);

@@ -105,6 +105,10 @@ void verify_buffers_free(VerifyBuffers &v);
 // Up to this many blobs a verification / proof call validates its points on the host threads: ~0.2 ms per point per
 // thread against a 2 ms latency-shaped kernel. 4 per usable hardware thread, at most 64.
 size_t host_small_batch_limit();
+// sha256_host.hip: the host threads' last job (steady-clock ns, 0 = none yet), the clock itself, and a job that wakes every worker
+int64_t host_last_active_ns();
+int64_t host_now_ns();
+void host_pool_warm();
 
 // Coalescing front of the single-blob symbols (engine.hip: combine_commit). The reference's KZGSettings is read-only
 // after load, so any number of threads may call blob_to_kzg_commitment on one settings object at once
@@ -154,6 +158,7 @@ struct BuildTiming {
     // table_malloc_ms: the windows' hipMallocs, summed (the GPU builds window j meanwhile); kernels_ms: what was left of the build
     // kernels after the last allocation returned
     double free_old_ms = 0, table_malloc_ms = 0, scratch_malloc_ms = 0, kernels_ms = 0, scratch_free_ms = 0, total_ms = 0;
+    bool in_place = false;   // the other form's allocations were kept and only the build kernels ran (lwkzg_settings_set_mode)
 };
 struct LoadTiming {
     double context_ms = 0;           // streams, events, the small device buffers

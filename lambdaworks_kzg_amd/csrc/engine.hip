@@ -292,6 +292,27 @@ static size_t mid_proof_host_limit() {
     return v;
 }
 
+// Are the host threads warm? The mid-size host-assisted challenge (hashing on the host threads, pipelined with the copy out) beats
+// the GPU's hash kernel only when they are: a pool that does not exist yet, or threads idle for longer than LWKZG_HOST_WARM_MS
+// (default 2000; measured: up to a second of idleness costs the first two calls 0.2 ms, tools/experiments/r05_host_cold.py), make the
+// call take the GPU kernel this once -- and wake the threads on the side, from a host function, so that the NEXT call finds them warm
+// (a cold burst of host-assisted calls ran at 30.7k proofs/s where the GPU path does 41.5k).
+static bool host_assist_warm() {
+    static const int64_t window_ns = [] {
+        const char *e = getenv("LWKZG_HOST_WARM_MS");
+        const long ms = e ? atol(e) : 2000;
+        return (int64_t)(ms < 0 ? 0 : ms) * 1000000;
+    }();
+    const int64_t last = host_last_active_ns();
+    return last != 0 && host_now_ns() - last <= window_ns;
+}
+static void host_warm_fn(void *) {
+    try {
+        host_pool_warm();
+    } catch (...) {
+    }
+}
+
 struct ChunkHashArgs {
     SmallProofHost *h;
     size_t first, count;
@@ -929,6 +950,16 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         LWK_HIP(hipMemcpyAsync(canon, h.canon, n * 48, hipMemcpyHostToDevice, st));
         launch_z_from_bytes(w.zbytes, z, nullptr, le, n, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_challenge(blobs, canon, z, le, n, st, comm48);
+    } else if (n <= mid_proof_host_limit() && !peer_busy(c) && !host_assist_warm()) {
+        // mid-size call, host threads cold: the GPU's hash kernel this once, and a nudge for the threads on the side stream
+        LWK_HIP(hipEventRecord(c->ev_fork, st));
+        LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
+        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
+        if (hipLaunchHostFunc(c->vstream, host_warm_fn, nullptr) != hipSuccess) (void)hipGetLastError();
+        LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
+        launch_challenge(blobs, comm48, z, le, n, st);
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        launch_challenge(blobs, canon, z, le, n, st, comm48);
     } else if (n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n)) {
         // mid-size call on a settings object whose other context is idle (a producer that alternates two caller streams hides the GPU's hash
         // behind the other call's MSM at no cost, and two calls' host hashing would queue for the same host threads: 70.9k against 49.7k
@@ -1012,7 +1043,9 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
     LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
     // mid-size calls on a settings object whose other context is idle: the commitment-free part of the hashes on the host threads,
     // chunk by chunk beside the copy out (as blob_proof_batch_device does for whole hashes), instead of the 3.2 ms kernel beside the MSM
-    const bool host_mid = n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n);
+    const bool host_cold = n <= mid_proof_host_limit() && !peer_busy(c) && !host_assist_warm();
+    if (host_cold && hipLaunchHostFunc(c->vstream, host_warm_fn, nullptr) != hipSuccess) (void)hipGetLastError();   // (the GPU kernel this once)
+    const bool host_mid = !host_cold && n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n);
     if (host_mid) {
         SmallProofHost &h = c->sph;
         hipStream_t sc = c->aux[0];
@@ -1468,22 +1501,19 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
     drain.armed = false;  // both side streams are joined into the main stream from here on
     launch_challenge(d_blobs, vb.canon_dev, z, le, n, st, d_comm);  // only the blobs whose commitment bytes were not canonical
-    LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
-    LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));
-    rc = first_status(c, vb.status_all, n, st);  // the validation's verdicts, before any more work is queued
-    if (rc != C_KZG_OK) return rc;
+    // chunk by chunk with no host round trip in between: y and z bytes of ALL blobs collect in the linear combinations' scalar
+    // buffers (idle until lincomb3), the parser's verdicts beside the validation's
     for (size_t off = 0; off < n; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        LWK_HIP(hipMemsetAsync(w.status, 0, m * 4, st));
-        coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, w.status, st);
-        launch_eval_quotient(w.scalars, z + off, w.scalars2, w.ybytes, le, m, st);
-        launch_fr_mont_to_bytes(z + off, w.zbytes, le, m, st);
-        LWK_HIP(hipMemcpyAsync(z32 + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
-        LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
-        rc = first_status(c, w.status, m, st);  // (also the synchronisation that lets the next chunk reuse the staging buffers)
-        if (rc != C_KZG_OK) return rc;
+        coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, vb.status_all + off, st);
+        launch_eval_quotient(w.scalars, z + off, w.scalars2, vb.d_r + 32 * off, le, m, st);
+        launch_fr_mont_to_bytes(z + off, vb.d_rz + 32 * off, le, m, st);
     }
-    return C_KZG_OK;
+    LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(z32, vb.d_rz, n * 32, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(y32, vb.d_r, n * 32, hipMemcpyDeviceToHost, st));
+    return first_status(c, vb.status_all, n, st);  // the validation's verdicts and the parser's
 }
 
 // sums[0] = sum r_i pi_i, sums[1] = sum r_i z_i pi_i, sums[2] = sum r_i C_i on the points verify_prepare_host kept
@@ -1742,9 +1772,9 @@ extern "C" size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t ca
         k = snprintf(tmp, sizeof tmp,
                      "{\"load\": {\"context_ms\": %.3f, \"points_and_tables_ms\": %.3f, \"g2_and_fft_ms\": %.3f, \"default_table_ms\": %.3f, "
                      "\"total_ms\": %.3f}, \"last_table_build\": {\"bits\": %d, \"row_bytes\": %zu, \"table_bytes\": %zu, \"free_old_ms\": %.3f, "
-                     "\"table_malloc_ms\": %.3f, \"scratch_malloc_ms\": %.3f, \"kernels_ms\": %.3f, \"scratch_free_ms\": %.3f, \"total_ms\": %.3f}}",
+                     "\"table_malloc_ms\": %.3f, \"scratch_malloc_ms\": %.3f, \"kernels_ms\": %.3f, \"scratch_free_ms\": %.3f, \"total_ms\": %.3f, \"in_place\": %d}}",
                      l.context_ms, l.points_and_tables_ms, l.g2_and_fft_ms, l.default_table_ms, l.total_ms, b.bits, b.row_bytes, b.table_bytes,
-                     b.free_old_ms, b.table_malloc_ms, b.scratch_malloc_ms, b.kernels_ms, b.scratch_free_ms, b.total_ms);
+                     b.free_old_ms, b.table_malloc_ms, b.scratch_malloc_ms, b.kernels_ms, b.scratch_free_ms, b.total_ms, (int)b.in_place);
     } else {
         k = snprintf(tmp, sizeof tmp, "{}");
     }
@@ -2645,7 +2675,14 @@ static C_KZG_RET reserve_ctx(Ctx *c, size_t max_batch) {
     if (rc != C_KZG_OK) return rc;
     const size_t host_n = max_batch < mid_proof_host_limit() ? max_batch : mid_proof_host_limit();
     const size_t small_n = max_batch < small_proof_host_limit() ? max_batch : small_proof_host_limit();
-    if (host_n || small_n) (void)sph_reserve(c, host_n > small_n ? host_n : small_n, true);   // (no pinned memory: the calls take the GPU hash)
+    if (host_n || small_n) {
+        if (sph_reserve(c, host_n > small_n ? host_n : small_n, true)) {   // (no pinned memory: the calls take the GPU hash)
+            SmallProofHost &h = c->sph;   // first touches of the staging happen here, not in the first call
+            memset(h.blobs, 0, h.cap * (size_t)kBlobBytes);
+            memset(h.dig, 0, h.cap * 32);
+        }
+        host_pool_warm();   // the host threads exist and have run once
+    }
     return C_KZG_OK;
 }
 
@@ -2820,7 +2857,41 @@ static void tables_follow_mode(Ctx *c, int mode, bool may_swap) {
     BuildTiming bt;
     if (form_build(c, want_lag, bits, 0, may_swap ? 1 : 2, bt) == hipSuccess) return;  // fits beside the other: both forms live
     if (!may_swap) return;
-    form_drop(c, !want_lag);
+    // The two forms' tables have the SAME geometry (width, windows, row size): the other form's allocations move over as they are and
+    // the build kernels run again over them -- no hipFree / hipMalloc of 275 GB, no wait for the driver's scrub (7-8.5 s ->
+    // the kernels' half second). LWKZG_SET_MODE_IN_PLACE=0: free and allocate, the A/B arm.
+    static const bool in_place_on = !(getenv("LWKZG_SET_MODE_IN_PLACE") && atoi(getenv("LWKZG_SET_MODE_IN_PLACE")) == 0);
+    FormRef other = form_ref(c, !want_lag);
+    if (in_place_on && other.bits == bits && other.table0) {
+        auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = wall();
+        const size_t row = other.row;
+        mine.tab = other.tab;
+        other.tab = DirectTable();
+        other.table0 = nullptr;
+        other.bits = 0;
+        double ms[4] = {0, 0, 0, 0};
+        if (build_direct_table(bits, mine.points, mine.tab, row, c->stream, ms, true) == hipSuccess) {
+            mine.table0 = (G1Affine29 *)mine.tab.win[0];
+            mine.bits = bits;
+            mine.row = row;
+            bt.bits = bits;
+            bt.row_bytes = row;
+            bt.table_bytes = direct_table_entries(bits) * row;
+            bt.scratch_malloc_ms = ms[0];
+            bt.kernels_ms = ms[2];
+            bt.scratch_free_ms = ms[3];
+            bt.total_ms = wall() - t0;
+            bt.in_place = true;
+            c->last_build = bt;
+            return;
+        }
+        (void)hipGetLastError();   // (the failed build freed what it held: fall through to a build from nothing)
+        mine.table0 = nullptr;
+        mine.bits = 0;
+    } else {
+        form_drop(c, !want_lag);
+    }
     if (form_build(c, want_lag, bits, 0, 0, bt) != hipSuccess) (void)form_build(c, !want_lag, bits, 0, 0, bt);  // (cannot happen: the other form's table just left)
     c->last_build = bt;
 }

@@ -59,7 +59,9 @@ struct DirectTable {
 };
 // ms[0] = scratch allocations, ms[1] = the windows' hipMallocs (summed), ms[2] = what was left of the build kernels after the
 // last allocation returned, ms[3] = freeing the scratch (host wall clock; may be null). On failure nothing stays allocated.
-hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &table, size_t row_bytes, hipStream_t st, double *ms = nullptr);
+// in_place: keep the window allocations `table` already has (same width, same row size) and only run the build kernels over them
+hipError_t build_direct_table(int bits, const G1Affine *points, DirectTable &table, size_t row_bytes, hipStream_t st, double *ms = nullptr,
+                              bool in_place = false);
 void free_direct_table(DirectTable &table);
 // sums[b] = sum_i scalars[b][i] * P_i. `partials` needs up to 64 * n_blobs entries when a blob is spread over several workgroups (unused
 // otherwise); `lane_scratch` 4096 * n_blobs entries (the per-lane sums of the hand-scheduled kernel) and `redo` n_blobs words (its flags).

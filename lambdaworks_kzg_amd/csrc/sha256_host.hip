@@ -5,6 +5,8 @@
 // core with SHA extensions ~0.1 ms. When the blobs are in host memory anyway (the reference's C ABI),
 // the digests are computed here, one std::thread per slice of the batch, while the GPU validates the
 // commitments and parses the blobs; the device-resident entry points keep using k_challenge.
+#include <chrono>
+#include <atomic>
 #include <immintrin.h>
 #include <stdint.h>
 #include <string.h>
@@ -262,6 +264,11 @@ class HostPool {
 
 }  // namespace
 
+namespace {
+std::atomic<int64_t> g_host_last_active_ns{0};
+int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 // fn(0) .. fn(n - 1), each exactly once, on the host threads (the caller works too); returns when all are done.
 // Calls from different threads take turns. fn must not call host_parallel_for itself.
 void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) {
@@ -279,6 +286,25 @@ void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) {
         p = pool;
     }
     p->run(n, fn);
+    g_host_last_active_ns.store(now_ns(), std::memory_order_release);
+}
+
+// when did the host threads last finish a job (0: never in this process)? The host-assisted challenge paths of the device-resident
+// proof calls ask: threads that have been idle for long wake slowly (first touches, parked cores), and the first job of a process
+// also creates the pool (engine.hip: host_assist_warm)
+int64_t host_last_active_ns() { return g_host_last_active_ns.load(std::memory_order_acquire); }
+int64_t host_now_ns() { return now_ns(); }
+
+// wake every worker with a job of a few microseconds each (creates the pool on first use): lwkzg_reserve* calls it, and so does a
+// proof call that finds the threads cold and takes the GPU's hash kernel this once
+void host_pool_warm() {
+    const unsigned nt = host_threads();
+    std::atomic<unsigned> sink{0};
+    host_parallel_for(4 * (size_t)nt, [&](size_t i) {
+        uint8_t buf[64] = {(uint8_t)i}, dg[32];
+        sha256_host(dg, buf, sizeof buf);
+        sink.fetch_add(dg[0], std::memory_order_relaxed);
+    });
 }
 
 // mid[8 i .. 8 i + 7] = the SHA-256 chaining value after the 2048 blocks of the compute_challenge message that do not contain a byte of

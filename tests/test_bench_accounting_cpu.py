@@ -118,7 +118,7 @@ def test_stdout_line_of_every_committed_detail_file_fits_the_drivers_tail():
         if "configs" in res:
             for name, leg in res["configs"].items():
                 if isinstance(leg, dict) and "value" in leg:
-                    assert set(line["configs"][name]) <= {"value", "unit", "ms_per_step", "steps", "kernel", "kernel_ms", "kernel_sum_over_wall", "ntt_roofline", "roofline"}
+                    assert set(line["configs"][name]) <= {"value", "unit", "ms_per_step", "steps", "cold_value", "kernel", "kernel_ms", "kernel_sum_over_wall", "ntt_roofline", "roofline"}
             assert "achieved" in line["configs"]["ckzg_commit_b1024_with_ntt"]["ntt_roofline"]
 
 
