@@ -695,4 +695,24 @@ void launch_direct_msm(int bits, const uint64_t *table, size_t row_bytes, const 
     }
 }
 
+template <int CT>
+static void launch_direct_only_t(const DirectPlanRt &plan, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *sums,
+                                 const uint32_t *only_if, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_direct_redo", st);
+    hipLaunchKernelGGL(k_direct_accumulate<CT>, dim3(1, (unsigned)n_blobs, 1), dim3(kDirThreads), 0, st, table, (const uint4 *)scalars_raw, sums,
+                       kBlobElems / kDirThreads, plan, (uint32_t)row_bytes, only_if);
+}
+
+void launch_direct_msm_only(int bits, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *sums, const uint32_t *only_if,
+                            size_t n_blobs, hipStream_t st) {
+    const DirectPlanRt plan = make_plan(bits);
+    if (!plan.entries) return;
+    switch (bits) {
+        case 14: launch_direct_only_t<14>(plan, table, row_bytes, scalars_raw, sums, only_if, n_blobs, st); break;
+        case 15: launch_direct_only_t<15>(plan, table, row_bytes, scalars_raw, sums, only_if, n_blobs, st); break;
+        case 16: launch_direct_only_t<16>(plan, table, row_bytes, scalars_raw, sums, only_if, n_blobs, st); break;
+        default: launch_direct_only_t<0>(plan, table, row_bytes, scalars_raw, sums, only_if, n_blobs, st); break;
+    }
+}
+
 }  // namespace lwk

@@ -177,7 +177,8 @@ struct SmallProofHost {
     int32_t *code = nullptr;                                                      // cap status words (0 or the mode's rejection code)
     size_t cap = 0;
     static constexpr int kChunks = 16;                                            // mid-size calls: the blobs leave in chunks, hashed as they land
-    hipEvent_t chunk_done[kChunks] = {};
+    hipEvent_t chunk_done[kChunks] = {};                                          // chunk k has landed in `blobs`
+    hipEvent_t hashed[kChunks] = {};                                              // chunk k's host function has run (the pipelined mid-size path)
 };
 
 // The Lagrange form of the setup (c-kzg mode without the transform): L_i = [l_i(tau)]G in the blob's own

@@ -243,11 +243,12 @@ constexpr int kEvalChunk = kBlobElems / kEvalThreads;  // 16
 __global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__restrict__ coeffs_raw,
                                                                 const Fr *__restrict__ z_mont,
                                                                 uint4 *__restrict__ quot_raw, uint8_t *__restrict__ y_out,
-                                                                int le) {
+                                                                int le, const uint32_t *__restrict__ only_if) {
     __shared__ Fr sh_m[kEvalThreads];
     __shared__ Fr sh_v[kEvalThreads];
     const int t = threadIdx.x;
     const size_t blob = blockIdx.x;
+    if (only_if && !only_if[blob]) return;   // a second pass over the blobs whose challenge changed (engine.hip: blob_proof_batch_device)
     const uint4 *cin = coeffs_raw + (blob * kBlobElems + (size_t)t * kEvalChunk) * 2;
     const Fr z = z_mont[blob];
 
@@ -310,10 +311,25 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__r
 }
 
 void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
-                          size_t n_blobs, hipStream_t st) {
-    ProfScope p("k_eval_quotient", st);
+                          size_t n_blobs, hipStream_t st, const uint32_t *only_if) {
+    ProfScope p(only_if ? "k_eval_quotient_redo" : "k_eval_quotient", st);
     hipLaunchKernelGGL(k_eval_quotient, dim3((unsigned)n_blobs), dim3(kEvalThreads), 0, st, (const uint4 *)coeffs_raw,
-                       z_mont, (uint4 *)quot_raw, y_out, le);
+                       z_mont, (uint4 *)quot_raw, y_out, le, only_if);
+}
+
+// flags[i] = the 48 bytes at a + 48 i differ from those at b + 48 i (a commitment whose canonical encoding is not what the caller sent)
+__global__ __launch_bounds__(256) void k_flag_differs48(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                        uint32_t *__restrict__ flags, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) d |= a[12 * i + k] ^ b[12 * i + k];
+    flags[i] = d != 0;
+}
+void launch_flag_differs48(const uint8_t *a, const uint8_t *b, uint32_t *flags, size_t n, hipStream_t st) {
+    ProfScope p("k_flag_differs48", st);
+    hipLaunchKernelGGL(k_flag_differs48, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t *)a, (const uint32_t *)b, flags, n);
 }
 
 // ---- c-kzg mode without the transform: the Lagrange form of the setup ------------------------------------------

@@ -68,6 +68,9 @@ void free_direct_table(DirectTable &table);
 // fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
 void launch_direct_msm(int bits, const uint64_t *win_dev, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
                        G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0);
+// sums[b] recomputed for the blobs with only_if[b] != 0 (one workgroup each, complete branches; exits at once for the others)
+void launch_direct_msm_only(int bits, const uint64_t *win_dev, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *sums,
+                            const uint32_t *only_if, size_t n_blobs, hipStream_t st);
 
 // ---- setup (setup.hip)
 // 48-byte compressed -> affine Montgomery + status (0 ok, 1 infinity, 2 invalid); optional [r]P check
@@ -105,8 +108,11 @@ void launch_fr_mont_to_bytes(const Fr *in, uint8_t *out, int le, size_t n, hipSt
 // y = p(z) and q = (p - y)/(x - z) per blob (Polynomial::evaluate + ruffini_division, call sites
 // /root/reference/src/lib.rs:320,329,389,394). coeffs_raw/quot_raw: canonical limbs. y_out: 32 bytes,
 // big-endian (le = 0) or little-endian (le = 1); may be NULL.
+// only_if (optional): one word per blob; blobs whose word is zero are left as they are (a second pass over a few blobs)
 void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
-                          size_t n_blobs, hipStream_t st);
+                          size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
+// flags[i] = (a[48 i ..] != b[48 i ..])
+void launch_flag_differs48(const uint8_t *a, const uint8_t *b, uint32_t *flags, size_t n, hipStream_t st);
 // z bytes -> Montgomery. le = 0: big-endian, reduced. le = 1: little-endian, must be canonical else BADARGS.
 void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, int le, size_t n, hipStream_t st);
 

@@ -496,3 +496,41 @@ def test_small_device_resident_call_rejects_only_the_bad_commitment_and_rehashes
         for i in range(m):
             if want[i] is not None:
                 assert got[48 * i:48 * i + 48] == want[i], (k, i)
+
+
+@pytest.mark.parametrize("n", [128, 256, 300, 384])
+@pytest.mark.parametrize("mode_c", [False, True], ids=["reference", "ckzg"])
+def test_pipelined_mid_size_call_takes_odd_encodings_through_its_second_pass(K, gpu_setup, oracle, oracle_setup, mode_c, n):
+    """r05: a mid-size device-resident call starts each sub-batch's quotient and MSM as soon as ITS chunks are hashed -- over the caller's
+    commitment bytes, without waiting for the validation; a commitment that is valid but NOT canonically encoded (infinity with stray
+    bits, for the zero blob) must get its challenge, quotient and proof again once the canonical bytes exist. One such blob in every
+    sub-batch (and none in a control call): every proof against the host-pointer call blob by blob, and the oracle on a sample."""
+    import torch
+    mode = K.MODE_CKZG if mode_c else K.MODE_REFERENCE
+    K.set_mode(mode)
+    data = bytearray(B.synthetic_batch(36000 + n, n, big_endian=not mode_c))
+    zeros = sorted(set([3, n // 4 + 1, n // 2 + 2, 3 * n // 4 + 3, n - 1]))
+    for i in zeros:
+        data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB] = bytes(B.BYTES_PER_BLOB)
+    data = bytes(data)
+    comms = bytearray(b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup)))
+    canonical = bytes(comms)
+    for k, i in enumerate(zeros):
+        assert comms[48 * i] == 0xc0
+        comms[48 * i + 1:48 * i + 48] = bytes((7 * k + j) % 251 + 1 for j in range(47))      # stray bits behind the infinity flag
+    comms = bytes(comms)
+    omode = oracle.MODE_C if mode_c else oracle.MODE_R
+    want = K.compute_blob_kzg_proof_batch(data, canonical, gpu_setup)
+    for i in (0, zeros[1], n - 2):
+        assert oracle.compute_blob_kzg_proof(data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB], canonical[48 * i:48 * i + 48], oracle_setup, omode) == (0, want[i])
+    d_blobs = _dev(data)
+    for cm in (comms, canonical, comms):
+        d_comm = _dev(cm)
+        d_out = torch.empty(48 * n, dtype=torch.uint8, device="cuda")
+        d_st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+        K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, gpu_setup, None, d_st.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_st.abs().sum()) == 0
+        got = _host(d_out)
+        bad = [i for i in range(n) if got[48 * i:48 * i + 48] != want[i]]
+        assert not bad, bad[:8]
