@@ -237,84 +237,120 @@ void launch_raw_to_be(const uint32_t *raw, uint8_t *out_be, size_t n_elems, hipS
 // uniform Montgomery pipeline would need never happen. The coefficients arrive reduced (k_parse_be_reduce, the
 // inverse transform's exit), which is what the product's "first operand < r" requirement and the additions need.
 
-constexpr int kEvalThreads = 256;
-constexpr int kEvalChunk = kBlobElems / kEvalThreads;  // 16
+// Arithmetic (r05): fr28.cuh -- 10 lazy limbs of 28 bits, a product is 200 multiply-adds with no carry handling (the 8 x 32-bit CIOS
+// form this kernel used needs ~2x the instructions); sums keep their carries; a quotient coefficient (< 3r: c + z acc with the product
+// < 2r) is brought to its canonical form by one carry ripple and two conditional subtractions. Bounds: every product has the
+// multiplier (z or a power of z: a product's result, normalised, < 2r) on one side and a value of at most 24 limb units / 2^24 r
+// on the other; the scan's values grow by one product result per level (<= 3r + 10 x 2r, limbs <= 12 units).
+//
+// 256 lanes x 16 coefficients: 51 products deep.
 
-__global__ __launch_bounds__(kEvalThreads) void k_eval_quotient(const uint4 *__restrict__ coeffs_raw,
-                                                                const Fr *__restrict__ z_mont,
-                                                                uint4 *__restrict__ quot_raw, uint8_t *__restrict__ y_out,
-                                                                int le, const uint32_t *__restrict__ only_if) {
-    __shared__ Fr sh_m[kEvalThreads];
-    __shared__ Fr sh_v[kEvalThreads];
+// value < 4r, lazy limbs -> canonical (< r): one ripple, then r is taken off at most three times
+__device__ __forceinline__ Fr28 fr28_canonical_lazy(const Fr28 &a) {
+    Fr28 v = fr28_norm(a);
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {
+        Fr28 d;
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const uint32_t t = v.l[i] - R28::MOD[i] - borrow;
+            borrow = t >> 31;
+            d.l[i] = t & R28::MASK;
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) v.l[i] = borrow ? v.l[i] : d.l[i];
+    }
+    return v;
+}
+
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_eval_quotient(const uint4 *__restrict__ coeffs_raw, const Fr *__restrict__ z_mont,
+                                                            uint4 *__restrict__ quot_raw, uint8_t *__restrict__ y_out, int le,
+                                                            const uint32_t *__restrict__ only_if) {
+    constexpr int kChunk = kBlobElems / kThreads;
+    __shared__ Fr28 sh_m[kThreads];
+    __shared__ Fr28 sh_v[kThreads];
     const int t = threadIdx.x;
     const size_t blob = blockIdx.x;
     if (only_if && !only_if[blob]) return;   // a second pass over the blobs whose challenge changed (engine.hip: blob_proof_batch_device)
-    const uint4 *cin = coeffs_raw + (blob * kBlobElems + (size_t)t * kEvalChunk) * 2;
-    const Fr z = z_mont[blob];
+    const uint4 *cin = coeffs_raw + (blob * kBlobElems + (size_t)t * kChunk) * 2;
+    const Fr28 z = fr28_from_mont256(z_mont[blob]);   // z 2^280, normalised, < 2r
 
-    Fr c[kEvalChunk];
+    Fr28 c[kChunk];
 #pragma unroll
-    for (int k = 0; k < kEvalChunk; k++) {
-        uint4 lo = cin[2 * k], hi = cin[2 * k + 1];
-        const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int q = 0; q < 8; q++) c[k].l[q] = s[q];  // raw
+    for (int k = 0; k < kChunk; k++) {
+        const uint4 lo = cin[2 * k], hi = cin[2 * k + 1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        c[k] = fr28_pack(w);  // raw, canonical
     }
-    Fr L = c[kEvalChunk - 1];
+    Fr28 L = c[kChunk - 1];
 #pragma unroll
-    for (int k = kEvalChunk - 2; k >= 0; k--) L = z * L + c[k];  // (Montgomery multiplier first: it is the operand < r)
-    Fr m = z;
+    for (int k = kChunk - 2; k >= 0; k--) L = fr28_add(fr28_mul(z, L), c[k]);   // < 3r, limbs < 2 units
+    Fr28 m = z;
 #pragma unroll
-    for (int k = 1; k < kEvalChunk; k <<= 1) m = sqr(m);  // z^16
+    for (int k = 1; k < kChunk; k <<= 1) m = fr28_mul(m, m);  // z^kChunk
 
-    Fr v = L;
+    Fr28 v = L;
     sh_m[t] = m;
     sh_v[t] = v;
     __syncthreads();
-    for (int d = 1; d < kEvalThreads; d <<= 1) {
-        bool has = t + d < kEvalThreads;
-        Fr om = has ? sh_m[t + d] : Fr::zero();
-        Fr ov = has ? sh_v[t + d] : Fr::zero();
+    for (int d = 1; d < kThreads; d <<= 1) {
+        const bool has = t + d < kThreads;
+        Fr28 om, ov;
+        if (has) {
+            om = sh_m[t + d];
+            ov = sh_v[t + d];
+        }
         __syncthreads();
         if (has) {
-            v = v + m * ov;
-            m = m * om;
+            v = fr28_add(v, fr28_mul(m, ov));   // (one more product result per level: the value and limb bounds above)
+            m = fr28_mul(m, om);
         }
         sh_m[t] = m;
         sh_v[t] = v;
         __syncthreads();
     }
     // v == H_t
-    Fr acc = (t + 1 < kEvalThreads) ? sh_v[t + 1] : Fr::zero();
-    uint4 *qout = quot_raw + (blob * kBlobElems) * 2;
-    const int i0 = t * kEvalChunk;
+    Fr28 acc;
+    if (t + 1 < kThreads) {
+        acc = fr28_canonical(LWK_FR28_MUL_CONST(sh_v[t + 1], ONE));   // (up to 3r + 10 x 2r with lazy limbs: one product by 2^280 mod r brings it under 2r)
+    } else {
 #pragma unroll
-    for (int k = kEvalChunk - 1; k >= 0; k--) {
-        acc = c[k] + z * acc;
-        int i = i0 + k;
+        for (int i = 0; i < 10; i++) acc.l[i] = 0;
+    }
+    uint4 *qout = quot_raw + (blob * kBlobElems) * 2;
+    const int i0 = t * kChunk;
+#pragma unroll
+    for (int k = kChunk - 1; k >= 0; k--) {
+        acc = fr28_canonical_lazy(fr28_add(c[k], fr28_mul(z, acc)));
+        const int i = i0 + k;
         if (i >= 1) {
-            qout[2 * (i - 1)] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
-            qout[2 * (i - 1) + 1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+            uint32_t w[8];
+            fr28_unpack(w, acc);
+            qout[2 * (i - 1)] = make_uint4(w[0], w[1], w[2], w[3]);
+            qout[2 * (i - 1) + 1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
     }
-    if (t == kEvalThreads - 1) {
+    if (t == kThreads - 1) {
         qout[2 * (kBlobElems - 1)] = make_uint4(0, 0, 0, 0);
         qout[2 * (kBlobElems - 1) + 1] = make_uint4(0, 0, 0, 0);
     }
     if (t == 0 && y_out) {
-        uint32_t s[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) s[q] = acc.l[q];  // acc_0 = y, raw already
+        uint32_t w[8];
+        fr28_unpack(w, acc);  // acc_0 = y, raw and canonical
         uint8_t *yo = y_out + 32 * blob;
-        if (le) raw_to_le<8>(yo, s); else raw_to_be<8>(yo, s);
+        if (le) raw_to_le<8>(yo, w); else raw_to_be<8>(yo, w);
     }
 }
 
 void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
                           size_t n_blobs, hipStream_t st, const uint32_t *only_if) {
     ProfScope p(only_if ? "k_eval_quotient_redo" : "k_eval_quotient", st);
-    hipLaunchKernelGGL(k_eval_quotient, dim3((unsigned)n_blobs), dim3(kEvalThreads), 0, st, (const uint4 *)coeffs_raw,
-                       z_mont, (uint4 *)quot_raw, y_out, le, only_if);
+    // (512 and 1024 lanes per blob -- a chain of 37 / 29 products instead of 51 -- measured SLOWER for one blob, 0.061 / 0.077 ms against 0.054:
+    // the barriers of 8 / 16 waves cost more than the shorter chain saves; gpurun_out r05)
+    hipLaunchKernelGGL(k_eval_quotient<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)coeffs_raw, z_mont, (uint4 *)quot_raw,
+                       y_out, le, only_if);
 }
 
 // flags[i] = the 48 bytes at a + 48 i differ from those at b + 48 i (a commitment whose canonical encoding is not what the caller sent)
