@@ -60,6 +60,16 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/pmc_cpp_grb
 unset LWKZG_DIRECT_ASM
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_bucket -o sq -- $P --direct-bits 0 > $O/pmc_sq_bucket_line.json 2> $O/pmc_sq_bucket_err.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm_bucket -o grbm -- $P --direct-bits 0 > $O/pmc_grbm_bucket_line.json 2> $O/pmc_grbm_bucket_err.txt
+# the cooperative kernel (one blob per call through the reference's symbols): per-kernel time over 60 calls of each, issue-side counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -o kt -- python3 tools/single_blob_loop.py 60 > $O/kt_single_out.txt 2> $O/kt_single_err.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_single_sq -o sq -- python3 tools/single_blob_loop.py 20 > $O/pmc_single_sq_out.txt 2> $O/pmc_single_sq_err.txt
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $O/pmc_single_grbm -o grbm -- python3 tools/single_blob_loop.py 20 > $O/pmc_single_grbm_out.txt 2> $O/pmc_single_grbm_err.txt
+python tools/small_batch_timing.py > $O/small_batch_timing.txt 2>&1
+LWKZG_COOP=0 python tools/small_batch_timing.py > $O/small_batch_timing_coop_off.txt 2>&1
+LWKZG_COOP=0 LWKZG_HOST_FINISH=0 python tools/single_blob_timing.py > $O/single_blob_timing_r04_arm.txt 2>&1
+LWKZG_MID_PROOF_PIPE=0 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256_unpiped.json python bench.py --op blob_proof --batch 256 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_line_blob_proof_b256_unpiped.json 2>> $O/bench_err.txt
+python tools/experiments/r05_host_cold.py > $O/host_cold.txt 2>&1
+tools/ubench_latency_bin > $O/ubench_latency.txt 2>&1
 python tools/host_api_timing.py > $O/host_api_timing.txt 2>&1
 python tools/single_blob_timing.py > $O/single_blob_timing.txt 2>&1
 python tools/config_sweep.py --direct-bits 16 > $O/config_sweep_direct16.json 2> $O/sweep_err.txt

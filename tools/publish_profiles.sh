@@ -2,7 +2,7 @@
 # Copies what tools/collect_profiles.sh left under gpurun_out/final into profiles/ (tracked), keeping only our kernels' rows.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/final; P=profiles; TAG=${1:-r04}
+O=gpurun_out/final; P=profiles; TAG=${1:-r05}
 for f in bench_line bench_line_force_dist bench_line_compiler_scheduled_arm bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
          bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm \
          bench_line_bucket bench_line_bucket_compiler_arm bench_line_default_engine bench_line_gpus2_gloo_one_device; do
@@ -13,6 +13,10 @@ for f in bench_detail bench_detail_compiler_scheduled_arm bench_detail_bucket be
   [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json
 done
 [ -s $O/single_blob_timing.txt ] && grep -v "amdgpu.ids" $O/single_blob_timing.txt > $P/${TAG}_single_blob_timing.txt
+for f in small_batch_timing small_batch_timing_coop_off single_blob_timing_r04_arm host_cold ubench_latency; do
+  [ -s $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${TAG}_$f.txt
+done
+[ -s $O/bench_line_blob_proof_b256_unpiped.json ] && tail -1 $O/bench_line_blob_proof_b256_unpiped.json > $P/${TAG}_bench_line_blob_proof_b256_unpiped.json
 [ -s $O/kt_line.json ] && tail -1 $O/kt_line.json > $P/${TAG}_bench_kernel_stats_run_line.json   # the line the profiled run itself printed
 for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
 grep -v "amdgpu.ids" $O/host_api_timing.txt > $P/${TAG}_host_api_timing.txt || true
@@ -22,7 +26,7 @@ tag = sys.argv[1]
 O = 'gpurun_out/final'
 def ours(rows, col):
     return [rows[0]] + [r for r in rows[1:] if 'lwk::' in r[col] or 'rocclr' in r[col]]
-for d, name in (('kt', 'bench_kernel_stats'), ('kt_all', 'bench_all_legs_kernel_stats'), ('kt_cpp', 'compiler_scheduled_arm_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats')):
+for d, name in (('kt_single', 'single_blob_calls_kernel_stats'), ('kt', 'bench_kernel_stats'), ('kt_all', 'bench_all_legs_kernel_stats'), ('kt_cpp', 'compiler_scheduled_arm_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats')):
     f = '%s/%s/kt_kernel_stats.csv' % (O, d)
     if os.path.exists(f):
         rows = list(csv.reader(open(f)))
@@ -48,6 +52,7 @@ pmc(['write'], 'profiles/%s_pmc_write_size.csv' % tag)
 pmc(['fetch_bucket'], 'profiles/%s_pmc_bucket_fetch_size.csv' % tag)
 pmc(['write_bucket'], 'profiles/%s_pmc_bucket_write_size.csv' % tag)
 pmc(['fetch_default'], 'profiles/%s_pmc_default_engine_fetch_size.csv' % tag)
+pmc(['pmc_single_sq', 'pmc_single_grbm'], 'profiles/%s_pmc_single_blob_calls_sq_counters.csv' % tag)
 PY
 python3 tools/pmc_summary.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv $TAG 1024 16 | grep -E "direct_acc|wrote"
 python3 tools/pmc_issue_summary.py k_direct_accumulate $P/${TAG}_issue_summary_compiler_scheduled_arm.json $O/pmc_cpp_sq1/sq_counter_collection.csv $O/pmc_cpp_sq2/sq_counter_collection.csv $O/pmc_cpp_grbm/grbm_counter_collection.csv > /dev/null
