@@ -82,6 +82,7 @@ echo "pytest rc=$?" >> $O/gpu_test_log.txt
 timeout 1200 python tools/soak.py --batches 300 --direct-bits 16 > $O/soak.json 2> $O/soak_err.txt
 echo "{\"soak_rc\": $?}" >> $O/soak.json
 timeout 600 python tools/soak_ckzg.py --batches 60 > $O/soak_ckzg.json 2> $O/soak_ckzg_err.txt
+timeout 900 python tools/soak_small.py --rounds 600 2> $O/soak_small_err.txt | tail -1 > $O/soak_small.json
 LWKZG_DIRECT=16 timeout 400 python tools/soak_verify.py 180 2> $O/soak_verify_err.txt | tail -1 > $O/soak_verify_direct16.json
 timeout 400 python tools/soak_verify.py 180 2>> $O/soak_verify_err.txt | tail -1 > $O/soak_verify_default.json
 du -sh $O

@@ -64,5 +64,5 @@ ls $P | grep $TAG | wc -l
 [ -s $O/kt_two_streams_untuned/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams_untuned/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_untuned_timeline.txt
 true
 [ -s $O/gpu_test_log.txt ] && grep -v "amdgpu.ids" $O/gpu_test_log.txt > $P/${TAG}_gpu_test_log.txt
-[ -s $O/soak.json ] && cat $O/soak.json $O/soak_ckzg.json $O/soak_verify_direct16.json $O/soak_verify_default.json >> $P/${TAG}_soak.jsonl
+[ -s $O/soak.json ] && cat $O/soak.json $O/soak_ckzg.json $O/soak_small.json $O/soak_verify_direct16.json $O/soak_verify_default.json >> $P/${TAG}_soak.jsonl
 true
