@@ -72,12 +72,19 @@ struct Workspace {
     uint8_t *ybytes = nullptr;       // cap x 32
     Fr *z = nullptr;                 // cap
     int32_t *status = nullptr;       // cap
+    // scratch of the three-launch validation of a proof call's commitments (decompressed points, kinds, the quad test's verdicts)
+    G1Affine29 *val_pts = nullptr;   // cap
+    int32_t *val_kind = nullptr;     // cap
+    uint32_t *val_verdict = nullptr; // cap
     // device-resident proof calls longer than one chunk hash / validate ALL their blobs up front (both kernels are
     // latency chains whose run time does not depend on the batch size); grow-only
     size_t long_cap = 0;             // blobs
     Fr *z_long = nullptr;            // long_cap
     uint8_t *canon_long = nullptr;   // long_cap x 48
     int32_t *status_long = nullptr;  // long_cap (when the caller passes no status array)
+    G1Affine29 *val_pts_long = nullptr;      // long_cap: the validation's scratch for such a call
+    int32_t *val_kind_long = nullptr;
+    uint32_t *val_verdict_long = nullptr;
 };
 
 // device-side scratch of one batch verification (points kept between its two GPU phases). The memory belongs to the
@@ -90,6 +97,7 @@ struct VerifyBuffers {
     uint8_t *proof_in = nullptr;  // compressed proofs as uploaded (validated on an auxiliary stream)
     uint8_t *comm_in = nullptr, *canon_dev = nullptr;  // commitments as uploaded; canonical bytes (n commitments, n proofs)
     int32_t *status_all = nullptr;                      // per-blob verdicts of the up-front validation
+    uint32_t *verdict_c = nullptr, *verdict_p = nullptr; // the quad subgroup test's words (k_subgroup_coop_asm), per point set
     uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
     G1Xyzz29 *d_part = nullptr;
     int32_t *d_inf = nullptr;

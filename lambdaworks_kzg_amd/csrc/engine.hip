@@ -171,6 +171,9 @@ static void ws_free(Workspace &w) {
     dev_free(w.ybytes);
     dev_free(w.z);
     dev_free(w.status);
+    dev_free(w.val_pts);
+    dev_free(w.val_kind);
+    dev_free(w.val_verdict);
     w.cap = 0;
 }
 
@@ -179,6 +182,9 @@ static void ws_long_free(Workspace &w) {
     dev_free(w.canon_long);
     dev_free(w.status_long);
     w.long_cap = 0;
+    dev_free(w.val_pts_long);
+    dev_free(w.val_kind_long);
+    dev_free(w.val_verdict_long);
 }
 
 C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
@@ -214,6 +220,9 @@ C_KZG_RET ctx_reserve(Ctx *c, size_t n) {
     WS_ALLOC(ybytes, cap * 32);
     WS_ALLOC(z, cap * sizeof(Fr));
     WS_ALLOC(status, cap * 4);
+    WS_ALLOC(val_pts, cap * sizeof(G1Affine29));
+    WS_ALLOC(val_kind, cap * 4);
+    WS_ALLOC(val_verdict, cap * 4);
 #undef WS_ALLOC
     w.cap = cap;
     return C_KZG_OK;
@@ -236,12 +245,13 @@ static void sph_free(SmallProofHost &h) {
 }
 
 // Up to this many blobs a device-resident blob-proof call takes its Fiat-Shamir challenges and its commitment validation from the
-// host threads (0 = never). Default 128 (default engine, same box, ms per call with / without: 1 blob 0.80 / 3.62, 16: 0.87 / 3.61, 64: 1.96 / 4.29,
+// host threads (0 = never). Default 64 since r05 (the GPU's validation went from 2.0 to 1.1 ms: at 128 blobs the mid-size path below takes 2.9 ms where this one
+// takes 3.6, at 64 both 2.25, at 16 this one 1.2 against 1.8; gpurun_out r05/gpu14); r04's table, when the default was 128 (default engine, same box, ms per call with / without: 1 blob 0.80 / 3.62, 16: 0.87 / 3.61, 64: 1.96 / 4.29,
 // 128: 3.41 / 5.05, 256: 6.43 / 6.68 -- beyond that the copy out and the host threads cost what the GPU chains did; gpurun_out r04c).
 static size_t small_proof_host_limit() {
     static const size_t v = [] {
         const char *e = getenv("LWKZG_SMALL_PROOF_HOST");
-        long x = e ? atol(e) : 128;
+        long x = e ? atol(e) : 64;
         return (size_t)(x < 0 ? 0 : x > (long)kMaxChunk ? (long)kMaxChunk : x);
     }();
     return v;
@@ -811,9 +821,24 @@ static bool commit_on_lagrange(const Ctx *c, int mode) {
 static bool proof_on_lagrange(const Ctx *c, int mode) {
     return mode == LWKZG_MODE_CKZG && c->lag.ready && c->lag.direct_table && !c->direct_table;
 }
+// r05: a c-kzg-mode proof whose MSM can run on the Lagrange form at full speed (that form has a direct table, or no form has one)
+// computes its quotient in EVALUATION form (fr_ops.hip: k_eval_quotient_evalform): the blob's evaluations as they stand, one batch
+// inversion per blob, no transform in front of the quotient and none behind it. LWKZG_CKZG_EVAL_PROOFS=0 is the A/B arm (the inverse
+// transform, Horner / Ruffini, and a forward transform where the Lagrange table is the only one).
+static bool proof_in_evaluation_form(const Ctx *c, int mode) {
+    static const bool on = !(getenv("LWKZG_CKZG_EVAL_PROOFS") && atoi(getenv("LWKZG_CKZG_EVAL_PROOFS")) == 0);
+    return on && mode == LWKZG_MODE_CKZG && c->lag.ready && (c->lag.direct_table || !c->direct_table);
+}
+// quotient (and y = p(z)) of n blobs whose scalars coefficients_stage left at `in`, in the form that function chose
+static void quotient_stage(Ctx *c, int mode, const uint32_t *in, const Fr *z, uint32_t *quot, uint8_t *y_out, int le, size_t n, hipStream_t st,
+                           const uint32_t *only_if = nullptr) {
+    if (proof_in_evaluation_form(c, mode)) launch_eval_quotient_evalform(in, z, c->tw28_fwd, quot, y_out, le, n, st, only_if);
+    else launch_eval_quotient(in, z, quot, y_out, le, n, st, only_if);
+}
 // the quotients in w.scalars2 (slots base ..) -> the form their MSM runs on; returns that form (true = Lagrange). The coefficients
 // in w.scalars (same slots) are dead by now and serve as scratch.
 static bool quotient_to_msm_form(Ctx *c, int mode, size_t n, hipStream_t st, size_t base = 0) {
+    if (proof_in_evaluation_form(c, mode)) return true;   // (already evaluations)
     if (!proof_on_lagrange(c, mode)) return false;
     Workspace &w = c->ws;
     const size_t so = base * (size_t)kBlobElems;
@@ -821,16 +846,17 @@ static bool quotient_to_msm_form(Ctx *c, int mode, size_t n, hipStream_t st, siz
     return true;
 }
 
-// blob bytes -> the scalars of an MSM in ws.scalars (slots base .. base + n): canonical monomial coefficients, or -- c-kzg mode,
-// `evaluations_ok` (the caller only commits) and a usable Lagrange form -- the blob's own evaluations, copied and range-checked with
-// no transform at all. Returns true in that case: the MSM must then run on the Lagrange form.
+// blob bytes -> the scalars of an MSM in ws.scalars (slots base .. base + n): canonical monomial coefficients, or -- c-kzg mode
+// and a usable Lagrange form: `evaluations_ok` (the caller only commits), or a proof call whose quotient is taken in evaluation
+// form (proof_in_evaluation_form; quotient_stage reads what this function left) -- the blob's own evaluations, copied and
+// range-checked with no transform at all. Returns true in that case: an MSM of these scalars must run on the Lagrange form.
 static bool coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st,
                                size_t base = 0, bool evaluations_ok = false) {
     Workspace &w = c->ws;
     uint32_t *scalars = w.scalars + base * (size_t)kBlobElems * 8;
     if (mode == LWKZG_MODE_REFERENCE) {
         launch_parse_be_reduce(blobs, scalars, n * kBlobElems, st);
-    } else if (evaluations_ok && commit_on_lagrange(c, mode)) {
+    } else if (evaluations_ok ? commit_on_lagrange(c, mode) : proof_in_evaluation_form(c, mode)) {
         launch_copy_le_check(blobs, scalars, status, n, st);
         return true;
     } else {
@@ -898,7 +924,8 @@ static C_KZG_RET ws_long_reserve(Ctx *c, size_t n) {
     size_t cap = 2 * kMaxChunk;
     while (cap < n) cap <<= 1;
     if (hipMalloc((void **)&w.z_long, cap * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&w.canon_long, cap * 48) != hipSuccess ||
-        hipMalloc((void **)&w.status_long, cap * 4) != hipSuccess) {
+        hipMalloc((void **)&w.status_long, cap * 4) != hipSuccess || hipMalloc((void **)&w.val_pts_long, cap * sizeof(G1Affine29)) != hipSuccess ||
+        hipMalloc((void **)&w.val_kind_long, cap * 4) != hipSuccess || hipMalloc((void **)&w.val_verdict_long, cap * 4) != hipSuccess) {
         (void)hipGetLastError();
         ws_long_free(w);
         set_error("proof batch of %zu blobs: out of device memory for the challenges", n);
@@ -959,7 +986,8 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         // mid-size call, host threads cold: the GPU's hash kernel this once, and a nudge for the threads on the side stream
         LWK_HIP(hipEventRecord(c->ev_fork, st));
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
-        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
+        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream, longcall ? w.val_pts_long : w.val_pts,
+                                    longcall ? w.val_kind_long : w.val_kind, longcall ? w.val_verdict_long : w.val_verdict);
         if (hipLaunchHostFunc(c->vstream, host_warm_fn, nullptr) != hipSuccess) (void)hipGetLastError();
         LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         launch_challenge(blobs, comm48, z, le, n, st);
@@ -980,12 +1008,16 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         // instruction for every other blob. 256 blobs: hash 2.1 ms -> MSM 2.3 ms in series becomes 1.05 -> 1.2 || 1.05 -> 1.2.
         static const bool pipe_on = !(getenv("LWKZG_MID_PROOF_PIPE") && atoi(getenv("LWKZG_MID_PROOF_PIPE")) == 0);
         const size_t chunks = (n + ((n + mid_proof_chunks() - 1) / mid_proof_chunks()) - 1) / ((n + mid_proof_chunks() - 1) / mid_proof_chunks());
-        const bool piped = pipe_on && c->direct_table && !proof_on_lagrange(c, mode) && n >= 128 && chunks >= 2 && chunks % 2 == 0 && n <= kMaxChunk;
+        static const size_t pipe_min = getenv("LWKZG_MID_PROOF_PIPE_MIN") ? (size_t)atol(getenv("LWKZG_MID_PROOF_PIPE_MIN")) : 192;   // (128 blobs: 3.3 ms pipelined, 2.9 not)
+        const bool evf = proof_in_evaluation_form(c, mode);   // (then the quotient's MSM runs on the Lagrange form's table)
+        const bool piped = pipe_on && (evf ? c->lag.direct_table != nullptr : c->direct_table && !proof_on_lagrange(c, mode)) && n >= pipe_min &&
+                           chunks >= 2 && chunks % 2 == 0 && n <= kMaxChunk;
         LWK_HIP(hipEventRecord(c->ev_fork, st));
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
         LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
         if (piped) LWK_HIP(hipStreamWaitEvent(sh, c->ev_fork, 0));
-        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
+        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream, longcall ? w.val_pts_long : w.val_pts,
+                                    longcall ? w.val_kind_long : w.val_kind, longcall ? w.val_verdict_long : w.val_verdict);
         LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         LWK_HIP(hipMemcpyAsync(h.comm, comm48, n * 48, hipMemcpyDeviceToHost, sc));
         {
@@ -1000,7 +1032,8 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
             // sub-batches of whole chunks, alternating between the call's stream and a second one: a sub-batch's quotient and MSM start
             // when ITS chunks are hashed, and its latency-shaped folds run beside the next sub-batch's accumulation
             static const size_t parts_env = getenv("LWKZG_MID_PROOF_PARTS") ? (size_t)atoi(getenv("LWKZG_MID_PROOF_PARTS")) : 0;
-            size_t parts = parts_env ? parts_env : (n >= 256 ? 4 : 2);
+            // (four measured best at 256 while the validation took 2 ms; with 1.1 ms of it two win there, 61.9k against 59.7k proofs/s; at 384 four: 66.0k against 63.7k)
+            size_t parts = parts_env ? parts_env : (n >= 320 ? 4 : 2);
             while (parts > 1 && chunks % parts) parts--;
             const size_t cps = chunks / parts;   // chunks per sub-batch
             uint32_t *differs = w.perm;   // (bucket-engine scratch, idle on a direct table: one word per blob)
@@ -1015,8 +1048,8 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
                 LWK_HIP(hipMemcpyAsync(w.zbytes + 32 * off, h.dig + 32 * off, m * 32, hipMemcpyHostToDevice, sk));
                 launch_z_from_bytes(w.zbytes + 32 * off, z + off, nullptr, le, m, sk);
                 coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt + off, sk, off);
-                launch_eval_quotient(w.scalars + off * (size_t)kBlobElems * 8, z + off, w.scalars2 + off * (size_t)kBlobElems * 8, nullptr, le, m, sk);
-                (void)msm_sums_stage(c, w.scalars2 + off * (size_t)kBlobElems * 8, m, sk, off, false, false);
+                quotient_stage(c, mode, w.scalars + off * (size_t)kBlobElems * 8, z + off, w.scalars2 + off * (size_t)kBlobElems * 8, nullptr, le, m, sk);
+                (void)msm_sums_stage(c, w.scalars2 + off * (size_t)kBlobElems * 8, m, sk, off, false, evf);
             }
             LWK_HIP(hipEventRecord(c->ev_join[2], s2));
             LWK_HIP(hipStreamWaitEvent(st, c->ev_join[2], 0));
@@ -1024,8 +1057,9 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
             LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
             launch_flag_differs48(canon, comm48, differs, n, st);
             launch_challenge(blobs, canon, z, le, n, st, comm48);
-            launch_eval_quotient(w.scalars, z, w.scalars2, nullptr, le, n, st, differs);
-            launch_direct_msm_only(c->direct_bits, c->direct_tab.win_dev, c->direct_row_bytes, w.scalars2, w.sums, differs, n, st);
+            quotient_stage(c, mode, w.scalars, z, w.scalars2, nullptr, le, n, st, differs);
+            launch_direct_msm_only(evf ? c->lag.direct_bits : c->direct_bits, evf ? c->lag.direct_tab.win_dev : c->direct_tab.win_dev,
+                                   evf ? c->lag.direct_row_bytes : c->direct_row_bytes, w.scalars2, w.sums, differs, n, st);
             launch_finalize_compress(w.sums, out48, n, st);
             return C_KZG_OK;
         }
@@ -1036,7 +1070,8 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
     } else {
         LWK_HIP(hipEventRecord(c->ev_fork, st));
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
-        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream);
+        launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream, longcall ? w.val_pts_long : w.val_pts,
+                                    longcall ? w.val_kind_long : w.val_kind, longcall ? w.val_verdict_long : w.val_verdict);
         LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         launch_challenge(blobs, comm48, z, le, n, st);
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
@@ -1056,7 +1091,7 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt + off, st);
-        launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
+        quotient_stage(c, mode, w.scalars, z + off, w.scalars2, nullptr, le, m, st);
         G1Xyzz29 *sums = msm_sums_stage(c, w.scalars2, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
         if (heavy_serial && off + kMaxChunk >= n) {  // the last accumulation is in the queue: the other context's phase may follow it
             std::lock_guard<std::mutex> hk(pr->heavy_mu);
@@ -1111,8 +1146,9 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
     for (size_t off = 0; off < n; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         const uint8_t *b = blobs + off * (size_t)kBlobBytes;
-        coefficients_stage(c, b, m, mode, stt + off, st);  // (coefficients: the quotient needs them)
-        if (proof_on_lagrange(c, mode)) {  // the only direct table is the Lagrange one: the commitment comes from the evaluations as they stand
+        if (coefficients_stage(c, b, m, mode, stt + off, st)) {  // evaluations: commitment and quotient both on the Lagrange form
+            msm_stages(c, w.scalars, comm_out48 + 48 * off, m, st, 0, off == 0 && !host_mid, true);
+        } else if (proof_on_lagrange(c, mode)) {  // coefficients for the quotient, but the only direct table is the Lagrange one: the commitment comes from the evaluations as they stand
             launch_copy_le_check(b, (uint32_t *)w.fr, nullptr, m, st);
             msm_stages(c, (const uint32_t *)w.fr, comm_out48 + 48 * off, m, st, 0, off == 0 && !host_mid, true);
         } else {
@@ -1120,7 +1156,7 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
         }
         if (off == 0) LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge_finish(b, comm_out48 + 48 * off, mid + 8 * off, z + off, le, m, st);
-        launch_eval_quotient(w.scalars, z + off, w.scalars2, nullptr, le, m, st);
+        quotient_stage(c, mode, w.scalars, z + off, w.scalars2, nullptr, le, m, st);
         msm_stages(c, w.scalars2, proof_out48 + 48 * off, m, st, 0, false, quotient_to_msm_form(c, mode, m, st));
     }
     return C_KZG_OK;
@@ -1138,7 +1174,7 @@ C_KZG_RET point_proof_batch_device(Ctx *c, uint8_t *proof48, uint8_t *y32, const
         LWK_HIP(hipMemsetAsync(stt, 0, m * 4, st));
         coefficients_stage(c, blobs + off * (size_t)kBlobBytes, m, mode, stt, st);
         launch_z_from_bytes(z32 + 32 * off, w.z, stt, le, m, st);
-        launch_eval_quotient(w.scalars, w.z, w.scalars2, y32 + 32 * off, le, m, st);
+        quotient_stage(c, mode, w.scalars, w.z, w.scalars2, y32 + 32 * off, le, m, st);
         const bool lg = quotient_to_msm_form(c, mode, m, st);
         if (sums_out && n <= kMaxChunk) *sums_out = msm_sums_stage(c, w.scalars2, m, st, 0, false, lg);   // the caller finishes on the host
         else msm_stages(c, w.scalars2, proof48 + 48 * off, m, st, 0, false, lg);
@@ -1172,6 +1208,8 @@ void verify_buffers_free(VerifyBuffers &v) {
     dev_free(v.comm_in);
     dev_free(v.canon_dev);
     dev_free(v.status_all);
+    dev_free(v.verdict_c);
+    dev_free(v.verdict_p);
     dev_free(v.d_r);
     dev_free(v.d_rz);
     dev_free(v.d_aff);
@@ -1195,6 +1233,7 @@ static C_KZG_RET verify_buffers_alloc(VerifyBuffers &v, size_t cap) {
               hipMalloc((void **)&v.proof_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.d_r, cap * 32) == hipSuccess &&
               hipMalloc((void **)&v.comm_in, cap * 48) == hipSuccess && hipMalloc((void **)&v.canon_dev, 2 * cap * 48) == hipSuccess &&
               hipMalloc((void **)&v.status_all, cap * 4) == hipSuccess &&
+              hipMalloc((void **)&v.verdict_c, cap * 4) == hipSuccess && hipMalloc((void **)&v.verdict_p, cap * 4) == hipSuccess &&
               hipMalloc((void **)&v.d_rz, cap * 32) == hipSuccess &&
               hipMalloc((void **)&v.d_part, (3 * nblk + 3) * sizeof(G1Xyzz29)) == hipSuccess &&
               hipMalloc((void **)&v.d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&v.d_inf, 3 * 4) == hipSuccess;
@@ -1243,10 +1282,10 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
     LWK_HIP(hipEventRecord(c->ev_fork, st));
     LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
     LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, n * 48, hipMemcpyHostToDevice, sv));
-    launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p);
+    launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p, vb.verdict_p);
     launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);  // for the linear combinations; needs no scalar
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
-    launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c);
+    launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c, vb.verdict_c);
     launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));
     // the canonical bytes come back the first time the host needs them: a device-to-host copy into pageable memory
@@ -1306,7 +1345,7 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
             launch_challenge(w.blobs + base * (size_t)kBlobBytes, vb.canon_dev + 48 * off, d_z, le, m, sk);
         }
-        launch_eval_quotient(w.scalars + base * (size_t)kBlobElems * 8, d_z, w.scalars2 + base * (size_t)kBlobElems * 8, d_yb, le, m,
+        quotient_stage(c, mode, w.scalars + base * (size_t)kBlobElems * 8, d_z, w.scalars2 + base * (size_t)kBlobElems * 8, d_yb, le, m,
                              sk);
         launch_fr_mont_to_bytes(d_z, d_zb, le, m, sk);
         LWK_HIP(hipMemcpyAsync(z32 + 32 * off, d_zb, m * 32, hipMemcpyDeviceToHost, sk));
@@ -1380,7 +1419,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
         vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
         vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
-        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all;
+        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all; vb.verdict_c = v.verdict_c; vb.verdict_p = v.verdict_p;
     }
     if (n > kMaxChunk && proofs48 && !trusted_canon_c)  // up to one chunk the single pass below is ~1 ms shorter
         return verify_prepare_long(c, blobs, comm48, proofs48, n, mode, z32, y32, canon_c, canon_p, vb);
@@ -1416,12 +1455,12 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, m * 48, hipMemcpyHostToDevice, sa));
             launch_decompress_points(vb.proof_in, vb.pts_p, vb.kind_p, m, sa);
             LWK_HIP(hipEventRecord(c->ev_join[4], sa));
-            launch_subgroup_canon(vb.pts_p, vb.kind_p, w.out48, w.status, bad, m, sa);
+            launch_subgroup_canon(vb.pts_p, vb.kind_p, w.out48, w.status, bad, m, sa, vb.verdict_p);
             LWK_HIP(hipEventRecord(c->ev_join[0], sa));
             LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
             launch_decompress_points(w.comm48, vb.pts_c, vb.kind_c, m, sc);
             LWK_HIP(hipEventRecord(c->ev_join[5], sc));
-            launch_subgroup_canon(vb.pts_c, vb.kind_c, w.canon48, w.status, bad, m, sc);
+            launch_subgroup_canon(vb.pts_c, vb.kind_c, w.canon48, w.status, bad, m, sc, vb.verdict_c);
             LWK_HIP(hipEventRecord(c->ev_join[1], sc));
             LWK_HIP(hipStreamWaitEvent(sm, c->ev_join[4], 0));
             LWK_HIP(hipStreamWaitEvent(sm, c->ev_join[5], 0));
@@ -1436,7 +1475,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             memcpy(canon_c + 48 * off, trusted_canon_c + 48 * off, m * 48);
             hc = trusted_canon_c + 48 * off;
         } else if (!host_validate && !proofs48) {
-            launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off);
+            launch_validate_commitments(w.comm48, w.canon48, w.status, bad, m, st, vb.pts_c + off, vb.kind_c + off, vb.verdict_c + off);
         }
         std::vector<int32_t> h_code(m, bad), h_kind;
         std::vector<G1Affine29> h_aff;
@@ -1475,7 +1514,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             if (host_validate) LWK_HIP(hipMemcpyAsync(w.canon48, canon_c + 48 * off, m * 48, hipMemcpyHostToDevice, st));
             launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
         }
-        launch_eval_quotient(w.scalars, w.z, w.scalars2, w.ybytes, le, m, st);
+        quotient_stage(c, mode, w.scalars, w.z, w.scalars2, w.ybytes, le, m, st);
         launch_fr_mont_to_bytes(w.z, w.zbytes, le, m, st);
         LWK_HIP(hipMemcpyAsync(z32 + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
         LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
@@ -1528,7 +1567,7 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
         vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
         vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
         vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
-        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all;
+        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all; vb.verdict_c = v.verdict_c; vb.verdict_p = v.verdict_p;
     }
     C_KZG_RET rc = ctx_reserve(c, n < kMaxChunk ? n : kMaxChunk);
     if (rc != C_KZG_OK) return rc;
@@ -1539,10 +1578,10 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     LWK_HIP(hipEventRecord(c->ev_fork, st));
     LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
     LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
-    launch_validate_commitments(d_proofs, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p);
+    launch_validate_commitments(d_proofs, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p, vb.verdict_p);
     launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);
     LWK_HIP(hipEventRecord(c->ev_join[0], sv));
-    launch_validate_commitments(d_comm, vb.canon_dev, vb.status_all, bad, n, sc, vb.pts_c, vb.kind_c);
+    launch_validate_commitments(d_comm, vb.canon_dev, vb.status_all, bad, n, sc, vb.pts_c, vb.kind_c, vb.verdict_c);
     launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, sc);
     LWK_HIP(hipEventRecord(c->ev_join[1], sc));
     launch_challenge(d_blobs, d_comm, z, le, n, st);
@@ -1555,7 +1594,7 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     for (size_t off = 0; off < n; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, vb.status_all + off, st);
-        launch_eval_quotient(w.scalars, z + off, w.scalars2, vb.d_r + 32 * off, le, m, st);
+        quotient_stage(c, mode, w.scalars, z + off, w.scalars2, vb.d_r + 32 * off, le, m, st);
         launch_fr_mont_to_bytes(z + off, vb.d_rz + 32 * off, le, m, st);
     }
     LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
@@ -2193,6 +2232,17 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
         if (rc != C_KZG_OK) return rc;
         Workspace &w = c->ws;
         LWK_HIP(hipMemcpyAsync(w.blobs, blobs, n * (size_t)kBlobBytes, hipMemcpyHostToDevice, c->stream));
+        if (n <= host_finish_limit()) {   // a handful of results: the sums come back as they are, inversion and compression on this thread
+            LWK_HIP(hipMemsetAsync(w.status, 0, n * 4, c->stream));
+            const bool lg = coefficients_stage(c, w.blobs, n, mode, w.status, c->stream, 0, true);
+            const G1Xyzz29 *d_sums = msm_sums_stage(c, w.scalars, n, c->stream, 0, false, lg);
+            std::vector<G1Xyzz29> h_sums(n);
+            LWK_HIP(hipMemcpyAsync(h_sums.data(), d_sums, n * sizeof(G1Xyzz29), hipMemcpyDeviceToHost, c->stream));
+            rc = collect_status(c, w.status, n, 0, first_bad);
+            if (rc != C_KZG_OK) return map_rc(rc, mode);
+            for (size_t i = 0; i < n; i++) host_finish_compress(out[i].bytes, h_sums[i]);
+            return C_KZG_OK;
+        }
         rc = commit_batch_device(c, w.out48, w.blobs, n, mode, c->stream, w.status);
         if (rc != C_KZG_OK) return rc;
         std::vector<uint8_t> h_out(n * 48);
@@ -2324,7 +2374,7 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
         LWK_HIP(hipMemcpyAsync(d_blobs, blobs + off * (size_t)kBlobBytes, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
         coefficients_stage(c, d_blobs, cnt, mode, d_status + off, sk, lo);
         launch_z_from_bytes(d_z + 32 * off, w.z + lo, d_status + off, le, cnt, sk);
-        launch_eval_quotient(w.scalars + so, w.z + lo, w.scalars2 + so, d_y + 32 * off, le, cnt, sk);
+        quotient_stage(c, mode, w.scalars + so, w.z + lo, w.scalars2 + so, d_y + 32 * off, le, cnt, sk);
         msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo, false, quotient_to_msm_form(c, mode, cnt, sk, lo));
     }
     for (int j = 0; j < 2; j++) {
@@ -2410,7 +2460,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
         } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
             launch_challenge(d_blobs, d_canon + 48 * off, w.z + lo, le, cnt, sk);
         }
-        launch_eval_quotient(w.scalars + so, w.z + lo, w.scalars2 + so, nullptr, le, cnt, sk);
+        quotient_stage(c, mode, w.scalars + so, w.z + lo, w.scalars2 + so, nullptr, le, cnt, sk);
         msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo, false, quotient_to_msm_form(c, mode, cnt, sk, lo));
     }
     for (int j = 0; j < 2; j++) {
@@ -2565,7 +2615,7 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
         if (!host_validate) {
             LWK_HIP(hipEventRecord(c->ev_fork, st));
             LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
-            launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, c->vstream);
+            launch_validate_commitments(w.comm48, w.canon48, w.status, le ? kStatusBadArgs : kStatusError, m, c->vstream, w.val_pts, w.val_kind, w.val_verdict);
             LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
         }
         // GPU, main stream: parse the blobs, then the digests as soon as the host threads have them
@@ -2573,7 +2623,7 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
         hasher.join();
         LWK_HIP(hipMemcpyAsync(w.zbytes, h_dig.data(), m * 32, hipMemcpyHostToDevice, st));
         launch_z_from_bytes(w.zbytes, w.z, nullptr, le, m, st);  // digest -> Fr, reduced (utils.rs:148-154)
-        launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+        quotient_stage(c, mode, w.scalars, w.z, w.scalars2, nullptr, le, m, st);
         const bool hf = m <= host_finish_limit();  // a small call: inversion and compression on this thread, at the end
         const G1Xyzz29 *d_sums = nullptr;
         auto quotient_msm = [&]() {
@@ -2603,7 +2653,7 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
             if (host_validate) LWK_HIP(hipMemcpyAsync(w.canon48, h_canon.data(), m * 48, hipMemcpyHostToDevice, st));
             launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
             coefficients_stage(c, w.blobs, m, mode, w.status, st);  // (the first attempt's forward transform may have used them as scratch)
-            launch_eval_quotient(w.scalars, w.z, w.scalars2, nullptr, le, m, st);
+            quotient_stage(c, mode, w.scalars, w.z, w.scalars2, nullptr, le, m, st);
             quotient_msm();
         }
         std::vector<uint8_t> h_out(m * 48);

@@ -284,12 +284,22 @@ LWK_HD Fp dbl(const Fp &a) { return fe_dbl<FpParams>(a); }
 // A lane that inverts is a lane on a serial dependency chain (the final step of every commitment, k_finalize_compress),
 // so what counts is the length of that chain: ~28 batches x (30 cheap word steps + two 2x2-matrix-times-vector
 // updates) is ~15x shorter than the ~480 Montgomery products of Fermat's a^(p-2).
-struct Gcd30 {
+struct Gcd30 {   // Fp: 381 bits
     static constexpr int L = 13;
+    static constexpr int NW = 12;      // 32-bit words of a canonical value
+    static constexpr int BATCHES = 40; // 1103 steps bound the worst case; typical inputs finish in <= 28 batches
     static constexpr int32_t M30 = (1 << 30) - 1;
     static constexpr uint32_t PINV = 0x30003u;  // p^-1 mod 2^30
     static constexpr int32_t P[13] = {0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673,
                                       0x12e13ce1, 0x2cd76477, 0x1ed90d2e, 0x29a4b1ba, 0x3a8e5ff9, 0x001a0111};
+};
+struct Gcd30Fr {  // Fr: 255 bits (r05: the evaluation-form quotient's one inversion per blob, fr_ops.hip)
+    static constexpr int L = 9;
+    static constexpr int NW = 8;
+    static constexpr int BATCHES = 26; // 741 steps bound a 256-bit modulus from delta = 1
+    static constexpr int32_t M30 = (1 << 30) - 1;
+    static constexpr uint32_t PINV = 0x1u;      // r = 1 mod 2^32
+    static constexpr int32_t P[9] = {0x1, 0x3ffffffc, 0x3fe5bfef, 0x2f6900bf, 0x21d80553, 0x27602026, 0x17d48333, 0x29d4ca67, 0x73ed};
 };
 
 // 30 division steps on the low words; t = (u, v, q, r) with 2^30 (f', g') = (u f + v g, q f + r g)
@@ -319,101 +329,108 @@ LWK_HD int32_t gcd30_divsteps(int32_t eta, uint32_t f, uint32_t g, int32_t t[4])
 }
 
 // (f, g) <- t (f, g) / 2^30, exact
+template <class G = Gcd30>
 LWK_HD void gcd30_update_fg(int32_t *f, int32_t *g, const int32_t t[4]) {
     const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
     int64_t cf = u * f[0] + v * g[0], cg = q * f[0] + r * g[0];
     cf >>= 30;
     cg >>= 30;
 #pragma unroll
-    for (int i = 1; i < Gcd30::L; i++) {
+    for (int i = 1; i < G::L; i++) {
         cf += u * f[i] + v * g[i];
         cg += q * f[i] + r * g[i];
-        f[i - 1] = (int32_t)cf & Gcd30::M30;
-        g[i - 1] = (int32_t)cg & Gcd30::M30;
+        f[i - 1] = (int32_t)cf & G::M30;
+        g[i - 1] = (int32_t)cg & G::M30;
         cf >>= 30;
         cg >>= 30;
     }
-    f[Gcd30::L - 1] = (int32_t)cf;
-    g[Gcd30::L - 1] = (int32_t)cg;
+    f[G::L - 1] = (int32_t)cf;
+    g[G::L - 1] = (int32_t)cg;
 }
 
 // (d, e) <- t (d, e) / 2^30 mod p, both kept in (-2p, p)
+template <class G = Gcd30>
 LWK_HD void gcd30_update_de(int32_t *d, int32_t *e, const int32_t t[4]) {
     const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
-    const int32_t sd = d[Gcd30::L - 1] >> 31, se = e[Gcd30::L - 1] >> 31;
+    const int32_t sd = d[G::L - 1] >> 31, se = e[G::L - 1] >> 31;
     int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
     int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0], ce = (int64_t)q * d[0] + (int64_t)r * e[0];
     // multiples of p that clear the low 30 bits
-    md -= (int32_t)((Gcd30::PINV * (uint32_t)cd + (uint32_t)md) & (uint32_t)Gcd30::M30);
-    me -= (int32_t)((Gcd30::PINV * (uint32_t)ce + (uint32_t)me) & (uint32_t)Gcd30::M30);
-    cd += (int64_t)Gcd30::P[0] * md;
-    ce += (int64_t)Gcd30::P[0] * me;
+    md -= (int32_t)((G::PINV * (uint32_t)cd + (uint32_t)md) & (uint32_t)G::M30);
+    me -= (int32_t)((G::PINV * (uint32_t)ce + (uint32_t)me) & (uint32_t)G::M30);
+    cd += (int64_t)G::P[0] * md;
+    ce += (int64_t)G::P[0] * me;
     cd >>= 30;
     ce >>= 30;
 #pragma unroll
-    for (int i = 1; i < Gcd30::L; i++) {
-        cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)Gcd30::P[i] * md;
-        ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)Gcd30::P[i] * me;
-        d[i - 1] = (int32_t)cd & Gcd30::M30;
-        e[i - 1] = (int32_t)ce & Gcd30::M30;
+    for (int i = 1; i < G::L; i++) {
+        cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)G::P[i] * md;
+        ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)G::P[i] * me;
+        d[i - 1] = (int32_t)cd & G::M30;
+        e[i - 1] = (int32_t)ce & G::M30;
         cd >>= 30;
         ce >>= 30;
     }
-    d[Gcd30::L - 1] = (int32_t)cd;
-    e[Gcd30::L - 1] = (int32_t)ce;
+    d[G::L - 1] = (int32_t)cd;
+    e[G::L - 1] = (int32_t)ce;
 }
 
-// canonical x in [0, p) as 12 x u32 -> x^-1 mod p in [0, p) (0 -> 0)
-LWK_HD void fp_inv_raw32(uint32_t out[12], const uint32_t x[12]) {
-    int32_t f[13], g[13], d[13], e[13];
+// canonical x in [0, p) as NW x u32 -> x^-1 mod p in [0, p) (0 -> 0)
+template <class G>
+LWK_HD void gcd30_inv_raw32(uint32_t *out, const uint32_t *x) {
+    constexpr int L = G::L, NW = G::NW;
+    int32_t f[L], g[L], d[L], e[L];
 #pragma unroll
-    for (int i = 0; i < 13; i++) {
+    for (int i = 0; i < L; i++) {
         const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
         uint32_t lo = x[w] >> sh;
-        if (sh + 30 > 32 && w + 1 < 12) lo |= x[w + 1] << (32 - sh);
-        g[i] = (int32_t)(lo & (uint32_t)Gcd30::M30);
-        f[i] = Gcd30::P[i];
+        if (sh + 30 > 32 && w + 1 < NW) lo |= x[w + 1] << (32 - sh);
+        g[i] = (int32_t)(lo & (uint32_t)G::M30);
+        f[i] = G::P[i];
         d[i] = 0;
         e[i] = (i == 0) ? 1 : 0;
     }
     int32_t eta = -1;
-    for (int it = 0; it < 40; it++) {  // 1103 steps bound the worst case; typical inputs finish in <= 28 batches
+    for (int it = 0; it < G::BATCHES; it++) {
         int32_t nz = 0;
 #pragma unroll
-        for (int i = 0; i < 13; i++) nz |= g[i];
+        for (int i = 0; i < L; i++) nz |= g[i];
         if (nz == 0) break;
         int32_t t[4];
         eta = gcd30_divsteps(eta, (uint32_t)f[0], (uint32_t)g[0], t);
-        gcd30_update_de(d, e, t);
-        gcd30_update_fg(f, g, t);
+        gcd30_update_de<G>(d, e, t);
+        gcd30_update_fg<G>(f, g, t);
     }
     // f = +-1 (or +-p for x = 0, where d = 0): d <- sign(f) d, into [0, p)
-    const int32_t fneg = f[12] >> 31;
-    int32_t add = d[12] >> 31;
+    const int32_t fneg = f[L - 1] >> 31;
+    int32_t add = d[L - 1] >> 31;
 #pragma unroll
-    for (int i = 0; i < 13; i++) d[i] = ((d[i] + (Gcd30::P[i] & add)) ^ fneg) - fneg;
+    for (int i = 0; i < L; i++) d[i] = ((d[i] + (G::P[i] & add)) ^ fneg) - fneg;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < L - 1; i++) {
         d[i + 1] += d[i] >> 30;
-        d[i] &= Gcd30::M30;
+        d[i] &= G::M30;
     }
-    add = d[12] >> 31;
+    add = d[L - 1] >> 31;
 #pragma unroll
-    for (int i = 0; i < 13; i++) d[i] += Gcd30::P[i] & add;
+    for (int i = 0; i < L; i++) d[i] += G::P[i] & add;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < L - 1; i++) {
         d[i + 1] += d[i] >> 30;
-        d[i] &= Gcd30::M30;
+        d[i] &= G::M30;
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) out[i] = 0;
+    for (int i = 0; i < NW; i++) out[i] = 0;
 #pragma unroll
-    for (int i = 0; i < 13; i++) {
+    for (int i = 0; i < L; i++) {
         const int bit = 30 * i, k = bit >> 5, sh = bit & 31;
         out[k] |= (uint32_t)d[i] << sh;
-        if (sh + 30 > 32 && k + 1 < 12) out[k + 1] |= (uint32_t)d[i] >> (32 - sh);
+        if (sh + 30 > 32 && k + 1 < NW) out[k + 1] |= (uint32_t)d[i] >> (32 - sh);
     }
 }
+
+LWK_HD void fp_inv_raw32(uint32_t out[12], const uint32_t x[12]) { gcd30_inv_raw32<Gcd30>(out, x); }
+LWK_HD void fr_inv_raw32(uint32_t out[8], const uint32_t x[8]) { gcd30_inv_raw32<Gcd30Fr>(out, x); }
 
 // Fp inversion: division steps; fe_inv<FpParams> (Fermat) stays as the cross-check
 LWK_HD Fp inv(const Fp &a) {
@@ -424,6 +441,13 @@ LWK_HD Fp inv(const Fp &a) {
 }
 LWK_HD Fp inv_fermat(const Fp &a) { return fe_inv<FpParams>(a); }
 LWK_HD Fr inv(const Fr &a) { return fe_inv<FrParams>(a); }
+// the same by division steps (~15x shorter as a dependency chain: one lane inverts per blob in fr_ops.hip: k_eval_quotient_evalform)
+LWK_HD Fr inv_divsteps(const Fr &a) {
+    uint32_t x[8], y[8];
+    fe_to_raw<FrParams>(x, a);
+    fr_inv_raw32(y, x);
+    return fe_from_raw<FrParams>(y);
+}
 
 // byte conversions (canonical big-endian, as the reference's to_bytes_be / from_bytes_be) -------
 

@@ -458,16 +458,29 @@ LWK_HD Fp f29_to_fp(const F29<B, false, LB> &a) {
     return fe_from_raw<FpParams>(raw);
 }
 
-// a^e, public exponent, NE little-endian 32-bit limbs
+// a^e, public exponent, NE little-endian 32-bit limbs. Fixed 4-bit windows (r05): 14 products of table, then four squares and at most
+// one product per window -- 380 + 95 + 14 products for the 380-bit exponent of the square root instead of the 380 + ~190 of
+// square-and-multiply (the chain is what a commitment's validation waits for: k_decompress_points, k_validate_commitments)
 template <int NE, int B, int LB>
 LWK_HD F29<2> f29_pow(const F29<B, false, LB> &a, const uint32_t *e) {
+    F29<2> tab[16];
+    tab[0] = F29<2>::one();
+    tab[1] = a * F29<1>::one();  // a * R / R = a, but weakly reduced to < 2p
+#pragma unroll 1
+    for (int k = 2; k < 16; k++) tab[k] = tab[k - 1] * tab[1];
     F29<2> acc = F29<2>::one();
-    F29<2> base = a * F29<1>::one();  // a * R / R = a, but weakly reduced to < 2p
     bool started = false;
-    for (int i = NE * 32 - 1; i >= 0; i--) {
-        if (started) acc = sqr(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) {
-            acc = started ? acc * base : base;
+#pragma unroll 1
+    for (int w = NE * 8 - 1; w >= 0; w--) {
+        const uint32_t d = (e[w >> 3] >> (4 * (w & 7))) & 15u;
+        if (started) {
+            acc = sqr(acc);
+            acc = sqr(acc);
+            acc = sqr(acc);
+            acc = sqr(acc);
+        }
+        if (d) {
+            acc = started ? acc * tab[d] : tab[d];
             started = true;
         }
     }

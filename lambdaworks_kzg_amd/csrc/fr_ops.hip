@@ -353,6 +353,245 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
                        y_out, le, only_if);
 }
 
+// ---- the quotient in EVALUATION form (r05) --------------------------------------------------------------------
+//
+// c-kzg mode on the Lagrange form of the setup: the blob IS the polynomial's evaluations p_i = p(w_i) on the bit-reversed domain
+// (w_i = w^bitrev12(i)), and the proof is the MSM of the QUOTIENT's evaluations q_i = (p_i - y) / (w_i - z) over [l_i(tau)]G -- no
+// transform anywhere. With inv_i = 1 / (z - w_i) (ONE inversion per blob: Montgomery's trick as a product tree over the workgroup,
+// its root inverted by division steps on one lane),
+//     y   = (z^4096 - 1) / 4096 * sum_i p_i w_i inv_i          (barycentric formula; w_i inv_i = z inv_i - 1, so the sum is
+//                                                               z sum_i p_i inv_i - sum_i p_i: no product by w_i)
+//     q_i = (y - p_i) inv_i
+// and when z IS a domain point w_m (the root of the tree is zero: found, d_m replaced by 1, the tree built again):
+//     y = p_m,   q_m = -(1 / w_m) sum_(i != m) q_i w_i         (the limit of the same quotient; c-kzg-4844's compute_kzg_proof_impl)
+// Arithmetic on fr28.cuh: z, w_i, inv_i in Montgomery form (x 2^280), p_i, y, q_i plain; bounds in the comments as (value in units of r,
+// limb in units of 2^28). 5 products per element + 2 per tree node, against 3 (Horner + Ruffini) + 2 x 7.5 (two transforms).
+__device__ __forceinline__ Fr28 fr28_neg_canonical(const Fr28 &a) {   // a canonical -> (r - a) mod r, canonical
+    Fr28 d;
+    uint32_t borrow = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint32_t t = R28::MOD[i] - a.l[i] - borrow;
+        borrow = t >> 31;
+        d.l[i] = t & R28::MASK;
+        nz |= a.l[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) d.l[i] = nz ? d.l[i] : 0u;
+    return d;
+}
+__device__ __forceinline__ Fr28 fr28_const_one() {
+    Fr28 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = R28::ONE[i];
+    return r;
+}
+// w_i for i = 16 t + k, canonical Montgomery form: w^e with e = bitrev12(i); tw[j] = w^j for j < 2048, w^(j + 2048) = -w^j
+__device__ __forceinline__ Fr28 evalform_omega(const Fr28 *__restrict__ tw28, uint32_t i) {
+    const uint32_t e = __brev(i) >> 20;
+    const Fr28 w = tw28[e & (kBlobElems / 2 - 1)];
+    return e >= kBlobElems / 2 ? fr28_neg_canonical(w) : w;
+}
+__device__ __forceinline__ Fr28 evalform_load(const uint4 *__restrict__ p) {
+    const uint4 lo = p[0], hi = p[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return fr28_pack(w);
+}
+// block sum of one lazy value per thread (normalised limbs in, value bound v): the sum of 256 in `out` of every thread, bound 256 v
+template <int kThreads>
+__device__ __forceinline__ Fr28 evalform_block_sum(Fr28 *sh, const Fr28 &mine, int t) {
+    __syncthreads();   // (sh is the tree's storage: every thread has read what it needed)
+    sh[t] = mine;
+    __syncthreads();
+    for (int d = kThreads / 2; d >= 1; d >>= 1) {
+        if (t < d) sh[t] = fr28_norm(fr28_add(sh[t], sh[t + d]));
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// two sums at once (sh holds 2 x kThreads values)
+template <int kThreads>
+__device__ __forceinline__ void evalform_block_sum2(Fr28 *sh, Fr28 &a, Fr28 &b, int t) {
+    __syncthreads();
+    sh[t] = a;
+    sh[kThreads + t] = b;
+    __syncthreads();
+    for (int d = kThreads / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+            sh[t] = fr28_norm(fr28_add(sh[t], sh[t + d]));
+            sh[kThreads + t] = fr28_norm(fr28_add(sh[kThreads + t], sh[kThreads + t + d]));
+        }
+        __syncthreads();
+    }
+    a = sh[0];
+    b = sh[kThreads];
+}
+
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4 *__restrict__ evals_raw, const Fr *__restrict__ z_mont,
+                                                                     const Fr28 *__restrict__ tw28, uint4 *__restrict__ quot_raw,
+                                                                     uint8_t *__restrict__ y_out, int le, const uint32_t *__restrict__ only_if) {
+    constexpr int kChunk = kBlobElems / kThreads;
+    static_assert(kChunk == 16 && kThreads == 256, "the index arithmetic below is for 256 x 16");
+    __shared__ Fr28 tree[2 * kThreads];   // heap order: node j has children 2j, 2j + 1; leaf of thread t = tree[kThreads + t]
+    __shared__ int sh_m;
+    __shared__ uint32_t sh_zero;
+    const int t = threadIdx.x;
+    const size_t blob = blockIdx.x;
+    if (only_if && !only_if[blob]) return;
+    const uint4 *pin = evals_raw + (blob * kBlobElems + (size_t)t * kChunk) * 2;
+    const uint32_t i0 = (uint32_t)t * kChunk;
+    const Fr28 z = fr28_from_mont256(z_mont[blob]);   // (2, 1)
+    const Fr28 one = fr28_const_one();
+    if (t == 0) sh_m = -1;
+    __syncthreads();
+
+    // (the three loops over the 16 elements are NOT unrolled: 100 products of 230 instructions would be three times the instruction cache;
+    // pre[] lives in scratch, 40 bytes in and out per product)
+    Fr28 pre[kChunk];   // first the prefix products d_0 .. d_k, then (in place, from the top) inv_k
+    // prefix products, the product tree and its root's inverse; `m_`: the index whose d is replaced by 1 (none: -1). True: the root was zero.
+    auto build = [&](const int m_) -> bool {
+#pragma unroll 1
+        for (int k = 0; k < kChunk; k++) {   // d_k = z - w_k: (6, 3)
+            const Fr28 d = (int)(i0 + k) == m_ ? one : fr28_sub(z, evalform_omega(tw28, i0 + k));
+            pre[k] = k == 0 ? d : fr28_mul(pre[k - 1], d);   // (2, 1) x (6, 3)
+        }
+        tree[kThreads + t] = pre[kChunk - 1];
+        __syncthreads();
+#pragma unroll 1
+        for (int w = kThreads / 2; w >= 1; w >>= 1) {   // nodes w .. 2w - 1
+            if (t < w) tree[w + t] = fr28_mul(tree[2 * (w + t)], tree[2 * (w + t) + 1]);
+            __syncthreads();
+        }
+        // the root's inverse, by one lane (of a different wave from workgroup to workgroup: the four workgroups of a compute unit
+        // then invert on four different SIMDs)
+        if (t == (int)((blockIdx.x & 3u) * 64u)) {
+            const Fr28 rc = fr28_canonical(tree[1]);
+            uint32_t x[8], xi[8], nz = 0;
+            fr28_unpack(x, rc);
+#pragma unroll
+            for (int k = 0; k < 8; k++) nz |= x[k];
+            fr_inv_raw32(xi, x);
+            tree[1] = LWK_FR28_MUL_CONST(fr28_pack(xi), R3);   // 1 / (P 2^280) -> 2^280 / P
+            sh_zero = nz == 0;
+        }
+        __syncthreads();
+        return sh_zero != 0;
+    };
+    int m = -1;         // the index whose w_m == z, if any (uniform over the workgroup)
+    if (build(-1)) {    // z is a domain point: which one?
+        const Fr28 zc = fr28_canonical(z);
+#pragma unroll 1
+        for (int k = 0; k < kChunk; k++) {
+            const Fr28 w = evalform_omega(tw28, i0 + k);
+            uint32_t diff = 0;
+#pragma unroll
+            for (int j = 0; j < 10; j++) diff |= w.l[j] ^ zc.l[j];
+            if (!diff) sh_m = (int)(i0 + k);
+        }
+        __syncthreads();
+        m = sh_m;
+        __syncthreads();
+        (void)build(m);
+    }
+    // down: the inverse of a node = the parent's inverse times the sibling
+    for (int w = 1; w < kThreads; w <<= 1) {   // parents w .. 2w - 1
+        if (t < w) {
+            const Fr28 ip = tree[w + t], l = tree[2 * (w + t)], r = tree[2 * (w + t) + 1];
+            tree[2 * (w + t)] = fr28_mul(ip, r);
+            tree[2 * (w + t) + 1] = fr28_mul(ip, l);
+        }
+        __syncthreads();
+    }
+    // inv_k in place of the prefix products, from the top; the barycentric sum on the way
+    Fr28 run = tree[kThreads + t];   // 1 / (d_0 .. d_15)
+    Fr28 acc, psum;   // sum of p_k inv_k, sum of p_k (both plain)
+#pragma unroll
+    for (int j = 0; j < 10; j++) acc.l[j] = psum.l[j] = 0;
+#pragma unroll 1
+    for (int k = kChunk - 1; k >= 0; k--) {
+        Fr28 inv_k = run;
+        if (k > 0) {
+            inv_k = fr28_mul(run, pre[k - 1]);
+            const Fr28 d = (int)(i0 + k) == m ? one : fr28_sub(z, evalform_omega(tw28, i0 + k));
+            run = fr28_mul(run, d);
+        }
+        pre[k] = inv_k;
+        if (m < 0) {   // (uniform; on the domain y is p_m and the sums are not needed)
+            const Fr28 pk = evalform_load(pin + 2 * k);
+            acc = fr28_add(acc, fr28_mul(pk, inv_k));   // (2, 1) each
+            psum = fr28_add(psum, pk);                  // (1, 1) each
+            if (k == kChunk / 2) {                      // (8 x 2 units of limb at most between ripples)
+                acc = fr28_norm(acc);
+                psum = fr28_norm(psum);
+            }
+        }
+    }
+    Fr28 yc;
+    if (m < 0) {
+        acc = fr28_norm(acc);     // (32, 1)
+        psum = fr28_norm(psum);   // (16, 1)
+        evalform_block_sum2<kThreads>(tree, acc, psum, t);   // (8192, 1), (4096, 1)
+        Fr28 zn = z;
+#pragma unroll 1
+        for (int k = 0; k < 12; k++) zn = fr28_mul(zn, zn);
+        const Fr28 c = LWK_FR28_MUL_CONST(fr28_sub(zn, one), NINV_M);   // (z^4096 - 1) / 4096, Montgomery form, (2, 1)
+        const Fr28 a = fr28_sub(fr28_mul(acc, z), LWK_FR28_MUL_CONST(psum, ONE));   // z sum p inv - sum p: (6, 3)
+        yc = fr28_canonical(fr28_mul(a, c));
+    } else {
+        __syncthreads();
+        if ((int)i0 <= m && m < (int)(i0 + kChunk)) tree[0] = evalform_load(pin + 2 * (m - (int)i0));
+        __syncthreads();
+        yc = tree[0];   // p_m
+    }
+    uint4 *qout = quot_raw + (blob * kBlobElems + (size_t)t * kChunk) * 2;
+    Fr28 part;   // z on the domain: sum of q_i w_i over this thread's i != m
+#pragma unroll
+    for (int j = 0; j < 10; j++) part.l[j] = 0;
+#pragma unroll 1
+    for (int k = 0; k < kChunk; k++) {
+        const Fr28 q = fr28_canonical(fr28_mul(fr28_sub(yc, evalform_load(pin + 2 * k)), pre[k]));   // (6, 3) x (2, 1)
+        if ((int)(i0 + k) != m) {
+            uint32_t wd[8];
+            fr28_unpack(wd, q);
+            qout[2 * k] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+            qout[2 * k + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+            if (m >= 0) {
+                part = fr28_add(part, fr28_mul(q, evalform_omega(tw28, i0 + k)));
+                if (k == kChunk / 2) part = fr28_norm(part);
+            }
+        }
+    }
+    if (m >= 0) {   // (uniform)
+        const Fr28 sum = evalform_block_sum<kThreads>(tree, fr28_norm(part), t);
+        if ((int)i0 <= m && m < (int)(i0 + kChunk)) {
+            const uint32_t e = __brev((uint32_t)m) >> 20, j = (kBlobElems - e) & (kBlobElems - 1);   // 1 / w^e = w^(4096 - e)
+            const Fr28 tj = tw28[j & (kBlobElems / 2 - 1)];
+            const Fr28 winv = j >= kBlobElems / 2 ? fr28_neg_canonical(tj) : tj;
+            const Fr28 qm = fr28_neg_canonical(fr28_canonical(fr28_mul(sum, winv)));
+            uint32_t wd[8];
+            fr28_unpack(wd, qm);
+            const int k = m - (int)i0;
+            qout[2 * k] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+            qout[2 * k + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+        }
+    }
+    if (t == 0 && y_out) {
+        uint32_t wd[8];
+        fr28_unpack(wd, yc);
+        uint8_t *yo = y_out + 32 * blob;
+        if (le) raw_to_le<8>(yo, wd); else raw_to_be<8>(yo, wd);
+    }
+}
+
+void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, const Fr28 *tw28_fwd, uint32_t *quot_raw, uint8_t *y_out, int le,
+                                   size_t n_blobs, hipStream_t st, const uint32_t *only_if) {
+    ProfScope p(only_if ? "k_eval_quotient_evalform_redo" : "k_eval_quotient_evalform", st);
+    hipLaunchKernelGGL(k_eval_quotient_evalform<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)evals_raw, z_mont, tw28_fwd,
+                       (uint4 *)quot_raw, y_out, le, only_if);
+}
+
 // flags[i] = the 48 bytes at a + 48 i differ from those at b + 48 i (a commitment whose canonical encoding is not what the caller sent)
 __global__ __launch_bounds__(256) void k_flag_differs48(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                         uint32_t *__restrict__ flags, size_t n) {

@@ -111,6 +111,9 @@ void launch_fr_mont_to_bytes(const Fr *in, uint8_t *out, int le, size_t n, hipSt
 // only_if (optional): one word per blob; blobs whose word is zero are left as they are (a second pass over a few blobs)
 void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
                           size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
+// the same in evaluation form (c-kzg mode on the Lagrange form): evaluations in, the quotient's evaluations out, y = p(z) by the barycentric formula
+void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, const Fr28 *tw28_fwd, uint32_t *quot_raw, uint8_t *y_out, int le,
+                                   size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
 // flags[i] = (a[48 i ..] != b[48 i ..])
 void launch_flag_differs48(const uint8_t *a, const uint8_t *b, uint32_t *flags, size_t n, hipStream_t st);
 // z bytes -> Montgomery. le = 0: big-endian, reduced. le = 1: little-endian, must be canonical else BADARGS.
@@ -120,8 +123,10 @@ void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, in
 // validate + canonicalise commitments (decompress incl. subgroup check, recompress), then
 // z = sha256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blob | commitment) as Fr
 // (compute_challenge, /root/reference/src/utils.rs:120-154).
+// verdict_scratch (n words, with aff_out and kind_out): the validation runs as three launches with the subgroup test on a quad of
+// lanes per point (k_subgroup_coop_asm) instead of one lane per point for the whole chain
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                                 hipStream_t st, G1Affine29 *aff_out = nullptr, int32_t *kind_out = nullptr);
+                                 hipStream_t st, G1Affine29 *aff_out = nullptr, int32_t *kind_out = nullptr, uint32_t *verdict_scratch = nullptr);
 // verify side: three variable-base linear combinations in one launch (setup.hip).
 //   set 0 = sum r_i P_i, set 1 = sum rz_i P_i (P = proofs), set 2 = sum r_i C_i (C = commitments);
 // per-block partial sums to partial[set * nblk + block]
@@ -134,7 +139,7 @@ void launch_point_multiples2(const G1Affine29 *pts_a, const int32_t *kind_a, G1A
 // launch_validate_commitments in two launches (sha256.hip): the multiples above can start after the first
 void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st);
 void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                           hipStream_t st);
+                           hipStream_t st, uint32_t *verdict_scratch = nullptr);
 void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *proof_mult, const G1Affine29 *comms,
                      const int32_t *comm_kind, const G1Affine29 *comm_mult, const uint8_t *sc_r_be, const uint8_t *sc_rz_be,
                      G1Xyzz29 *partial, size_t n, hipStream_t st);

@@ -538,8 +538,24 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
     if (kind_out) kind_out[i] = rc;
 }
 
+static bool validate_coop_enabled() {
+    static const bool on = !(getenv("LWKZG_VALIDATE_COOP") && atoi(getenv("LWKZG_VALIDATE_COOP")) == 0);
+    return on;
+}
+
+void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st);
+void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n, hipStream_t st,
+                           uint32_t *verdict_scratch);
+
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                                 hipStream_t st, G1Affine29 *aff_out, int32_t *kind_out) {
+                                 hipStream_t st, G1Affine29 *aff_out, int32_t *kind_out, uint32_t *verdict_scratch) {
+    // r05: with scratch for the points and the verdicts the validation is three launches -- the square root (one lane per point, windowed),
+    // the subgroup test on a quad of lanes per point (k_subgroup_coop_asm), canonical bytes + verdicts -- 2.0 -> ~1.0 ms whatever the batch
+    if (aff_out && kind_out && verdict_scratch && n && validate_coop_enabled()) {
+        launch_decompress_points(comm48, aff_out, kind_out, n, st);
+        launch_subgroup_canon(aff_out, kind_out, canon48, status, bad_code, n, st, verdict_scratch);
+        return;
+    }
     ProfScope p("k_validate_commitments", st);
     // The kernel is a one-wave-per-workgroup latency chain that runs beside other latency chains (the Fiat-Shamir hash of
     // the device-resident proofs, the other point set's validation). Where a wave of each shares a SIMD, both run at
@@ -581,9 +597,11 @@ __global__ __launch_bounds__(64) void k_decompress_points(const uint8_t *__restr
     kind[i] = rc | (want_greater ? 0x100 : 0);
 }
 
+// verdict (optional): the cooperative subgroup test's word per point (k_subgroup_coop_asm: 0 = not in G1, 1 = in G1, 2 = undetermined --
+// an addition met P = +-Q in its low 56 bits --, which this kernel settles with the complete-branches test)
 __global__ __launch_bounds__(64) void k_subgroup_canon(G1Affine29 *__restrict__ pts, int32_t *__restrict__ kind,
                                                        uint8_t *__restrict__ canon48, int32_t *__restrict__ status, int bad_code,
-                                                       size_t n) {
+                                                       size_t n, const uint32_t *__restrict__ verdict) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int k0 = kind[i];
@@ -594,9 +612,14 @@ __global__ __launch_bounds__(64) void k_subgroup_canon(G1Affine29 *__restrict__ 
         o[0] = 0xc0;
     } else if (rc == 0) {
         const G1Affine29 aff = pts[i];
-        uint32_t braw[12];
-        g1_beta_raw(braw);
-        if (!g1_in_subgroup_endo<G1Xyzz29>(aff.x, aff.y, f29_from_raw32(braw))) {
+        const uint32_t vd = verdict ? verdict[i] : 2u;
+        bool in_g1 = vd == 1u;
+        if (vd >= 2u) {
+            uint32_t braw[12];
+            g1_beta_raw(braw);
+            in_g1 = g1_in_subgroup_endo<G1Xyzz29>(aff.x, aff.y, f29_from_raw32(braw));
+        }
+        if (!in_g1) {
             rc = 2;
             G1Affine29 z;
             z.x = F29<2>::zero();
@@ -620,10 +643,39 @@ void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kin
     hipLaunchKernelGGL(k_decompress_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in48, pts, kind, n);
 }
 
+// The subgroup test on a QUAD of lanes per point (tools/gen_subgroup_asm.py writes subgroup_asm.inc and explains it): doublings in three
+// rounds of one product per lane, the cooperative MSM kernel's addition, the public bits of |z| as a scalar loop. Workgroups of four
+// unrelated waves (one per SIMD of a compute unit), 16 points per wave.
+__global__ __launch_bounds__(256) void k_subgroup_coop_asm(const G1Affine29 *__restrict__ pts, const int32_t *__restrict__ kind,
+                                                           uint32_t *__restrict__ verdict, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t first = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 16;
+    __builtin_amdgcn_s_setprio(2);
+    asm volatile(
+#include "subgroup_asm.inc"
+        :
+        : "s"(pts), "s"(kind), "s"(verdict), "s"(n), "s"(first), "v"(lane)
+        :
+#include "subgroup_asm_clobbers.inc"
+    );
+#endif
+}
+
+void launch_subgroup_coop(const G1Affine29 *pts, const int32_t *kind, uint32_t *verdict, size_t n, hipStream_t st) {
+    ProfScope p("k_subgroup_coop_asm", st);
+    hipLaunchKernelGGL(k_subgroup_coop_asm, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, pts, kind, verdict, (uint32_t)n);
+}
+
 void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                           hipStream_t st) {
+                           hipStream_t st, uint32_t *verdict_scratch) {
+    const uint32_t *verdict = nullptr;
+    if (verdict_scratch && validate_coop_enabled()) {
+        launch_subgroup_coop(pts, kind, verdict_scratch, n, st);
+        verdict = verdict_scratch;
+    }
     ProfScope p("k_subgroup_canon", st);
-    hipLaunchKernelGGL(k_subgroup_canon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pts, kind, canon48, status, bad_code, n);
+    hipLaunchKernelGGL(k_subgroup_canon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pts, kind, canon48, status, bad_code, n, verdict);
 }
 
 }  // namespace lwk

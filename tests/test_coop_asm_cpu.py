@@ -170,3 +170,31 @@ def test_equal_partial_sums_raise_the_redo_flag(which):
     prob = C.Problem(seed=12, c=4, nw=4, wtop=3, log_points=4, rpq=2, scalars=scalars, point_ks=ks)
     C.run_problem(prob)
     assert prob.mem.get(prob.REDO, 0) == 1
+
+
+def test_subgroup_asm_inc_is_current_and_judges_points_on_a_simulated_wave():
+    """the cooperative subgroup test (csrc/subgroup_asm.inc, tools/gen_subgroup_asm.py: doublings in three rounds of one product per lane, the
+    cooperative kernel's addition, the bits of |z| as a scalar loop): the committed files are what the generator writes; a simulated wave judges
+    points of G1 (verdict 1), points of E(Fp) outside G1 (0), a point of small order (0 or `undetermined`, never 1), skips slots whose kind is not 0
+    and slots beyond n; about 1780 vector instructions per doubling (one lane per point: nine products, ~4300)"""
+    import gen_subgroup_asm as S
+    import gen_direct_asm as G
+    assert open(S.OUT).read() == S.render(S.build())
+    assert open(S.OUT.replace(".inc", "_clobbers.inc")).read().split("\n", 1)[1].strip() == S.clobbers()
+    assert S.NUM_VGPRS <= 168 and S.NUM_SGPRS <= 100
+    rnd = random.Random(77)
+    prog = S.build()
+    pts, kinds, want = [], [], []
+    for k in range(5):
+        pts.append(G.ec_mul(rnd.randrange(1, R), G.G1)); kinds.append(0); want.append(1)
+    for k in range(3):
+        pts.append(S.curve_point_outside_g1(rnd)); kinds.append(0); want.append(0)
+    pts.append(G.ec_mul(R, S.curve_point_outside_g1(rnd))); kinds.append(0); want.append(None)    # small order: 0 or 2
+    pts.append(G.G1); kinds.append(0); want.append(1)                                                # the generator itself
+    pts.append(None); kinds.append(1); want.append(0xEE)                                             # infinity: skipped, its word untouched
+    pts.append(S.curve_point_outside_g1(rnd)); kinds.append(2); want.append(0xEE)                    # invalid encoding upstream: skipped
+    pts.append(G.ec_mul(rnd.randrange(1, R), G.G1)); kinds.append(0x100); want.append(1)             # the sign flag in bit 8 is not a kind
+    got, sim = S.run_points(pts, kinds, prog)
+    for g, w in zip(got, want):
+        assert (g in (0, 2)) if w is None else g == w, (got, want)
+    assert sim.valu_executed < 126 * 1850 + 10 * 2300 + 4000

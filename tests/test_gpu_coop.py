@@ -134,3 +134,56 @@ def test_single_blob_proofs_vs_oracle(K, table, oracle, oracle_setup):
         z = blob[64:96]
         rc, pw, yw = O.compute_kzg_proof(blob, z, oracle_setup, O.MODE_R)
         assert rc == 0 and K.compute_kzg_proof(blob, z, ts) == (pw, yw)
+
+
+def _compress(pt):
+    from conftest import P
+    x, y = pt
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if y > P - y else 0)
+    return bytes(b)
+
+
+@pytest.mark.parametrize("n", [40, 300, 1500])
+def test_validation_on_quads_of_lanes_judges_every_point_like_the_oracle(K, gpu_setup, oracle, n):
+    """r05: a proof call's commitments are validated by square root + the quad-of-lanes subgroup test (k_subgroup_coop_asm) + canonical bytes.
+    A batch of commitments of every kind -- points of G1, points of E(Fp) OUTSIDE G1 (random x with a square x^3 + 4: the cofactor is
+    ~2^125, so almost all of them), points of small order (a cofactor-cleared... r-cleared point), infinity, x not on the curve, bytes
+    without the compression flag -- goes through the device-resident proof call: the per-blob status is non-zero exactly where the CPU
+    oracle's decompression (which includes the reference's [r]P == O test, compression.rs:22-27) rejects; n = 40: the host-assisted small
+    path validates on the host instead (same verdicts); 1500: a call longer than one chunk"""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_subgroup_asm as S
+    import gen_direct_asm as G
+    rnd = random.Random(8800 + n)
+    comms = []
+    for i in range(n):
+        kind = i % 6
+        if kind in (0, 1):
+            comms.append(oracle.g1_generator_mul(rnd.randrange(1, R)))
+        elif kind == 2:
+            comms.append(_compress(S.curve_point_outside_g1(rnd)))
+        elif kind == 3 and i % 30 == 3:
+            comms.append(_compress(G.ec_mul(R, S.curve_point_outside_g1(rnd))))          # order divides the cofactor
+        elif kind == 4 and i % 12 == 4:
+            comms.append(bytes([0xc0]) + bytes(47))                                       # infinity
+        elif kind == 5 and i % 12 == 5:
+            comms.append(bytes([0x80]) + rnd.randbytes(47))                               # a random x: on the curve or not, in G1 almost never
+        else:
+            comms.append(oracle.g1_generator_mul(rnd.randrange(1, R)))
+    want_ok = [oracle.g1_decompress(c) is not None for c in comms]
+    assert 0.4 < sum(want_ok) / n < 0.95
+    data = B.synthetic_batch(9900, min(n, 8)) * ((n + 7) // 8)
+    data = data[:n * B.BYTES_PER_BLOB]
+    d_blobs = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    d_comm = torch.frombuffer(bytearray(b"".join(comms)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(48 * n, dtype=torch.uint8, device="cuda")
+    d_st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    K.compute_blob_kzg_proof_batch_device(d_out.data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), n, gpu_setup, None, d_st.data_ptr())
+    torch.cuda.synchronize()
+    st = d_st.cpu().tolist()
+    wrong = [i for i in range(n) if (st[i] == 0) != want_ok[i]]
+    assert not wrong, (wrong[:10], [st[i] for i in wrong[:10]])
+    assert all(s in (0, K.C_KZG_ERROR) for s in st)

@@ -98,6 +98,11 @@ def test_full_range_and_edge_elements(K, lag, mono):
              b"".join((rnd.randrange(R) if k % 97 == 0 else 0).to_bytes(32, "little") for k in range(4096))]
     data = b"".join(blobs)
     assert K.blob_to_kzg_commitment_batch(data, lag) == K.blob_to_kzg_commitment_batch(data, mono)
+    # r05: and their proofs, whose quotient is taken in evaluation form on the Lagrange form (full-range p_i, y and q_i; z = -1 and z = 1 are domain points)
+    comms = b"".join(K.blob_to_kzg_commitment_batch(data, mono))
+    assert K.compute_blob_kzg_proof_batch(data, comms, lag) == K.compute_blob_kzg_proof_batch(data, comms, mono)
+    zb = b"".join(z.to_bytes(32, "little") for z in (R - 1, 1, 0, rnd.randrange(R)))
+    assert K.compute_kzg_proof_batch(data, zb, lag) == K.compute_kzg_proof_batch(data, zb, mono)
     bad = bytearray(data)
     bad[2 * B.BYTES_PER_BLOB + 32 * 77:2 * B.BYTES_PER_BLOB + 32 * 78] = R.to_bytes(32, "little")
     out = C.create_string_buffer(48 * 4)
@@ -184,6 +189,31 @@ def test_proofs_equal_the_transform_path(K, lag, mono, oracle, oracle_setup, n):
     if n == 1:
         assert K.compute_blob_kzg_proof(data, comms, lag) == want[0] and K.compute_kzg_proof(data, zb, lag) == want_pz[0]
     assert K.verify_blob_kzg_proof_batch(data, comms, b"".join(want), n, lag) is True
+
+
+def test_evaluation_form_quotient_with_z_on_the_domain(K, lag, mono, oracle, oracle_setup):
+    """r05: on a usable Lagrange form a c-kzg-mode proof takes its quotient in EVALUATION form (fr_ops.hip: k_eval_quotient_evalform; one batch
+    inversion per blob, y by the barycentric formula). z = w_m makes the batch inversion's product zero: the kernel finds m, sets y = p_m and
+    takes q_m from the other quotients. m at every position that matters to a workgroup of 256 threads x 16 elements (first and last of
+    a thread, of a wave, of the blob; w = 1 and w = -1), beside ordinary z in the same launch, against the coefficient-form path
+    (a monomial-only table) and the oracle"""
+    ms = [0, 1, 2, 15, 16, 17, 1023, 1024, 2047, 2048, 4094, 4095, 777, 3001]
+    n = 2 * len(ms)
+    data = B.synthetic_batch(93100, n, big_endian=False)
+    zs = []
+    for j, m in enumerate(ms):
+        zs += [pow(W4096, _brp(m), R), (R - 1 - 1000 * j) % R]
+    zb = b"".join(z.to_bytes(32, "little") for z in zs)
+    want = K.compute_kzg_proof_batch(data, zb, mono)
+    got = K.compute_kzg_proof_batch(data, zb, lag)
+    assert got == want
+    for j in (0, 1, 6, 22):
+        rc, pr, y = oracle.compute_kzg_proof(data[j * B.BYTES_PER_BLOB:(j + 1) * B.BYTES_PER_BLOB], zb[32 * j:32 * j + 32], oracle_setup, oracle.MODE_C)
+        assert rc == 0 and (pr, y) == got[j]
+    for j, m in enumerate(ms):   # y = p(w_m) is the blob's own element m
+        assert got[2 * j][1] == data[2 * j * B.BYTES_PER_BLOB + 32 * m:2 * j * B.BYTES_PER_BLOB + 32 * m + 32]
+    # one blob per call (the cooperative kernel's path) with z on the domain
+    assert K.compute_kzg_proof(data[:B.BYTES_PER_BLOB], zb[:32], lag) == want[0]
 
 
 def test_reference_mode_on_a_lagrange_form_table_still_answers(K, lag, oracle):

@@ -894,6 +894,8 @@ class WaveSim:
                 self.scc = int({"eq": x == y, "lt": x < y, "gt": x > y}[op[6:8]])
             elif op == "s_cmp_eq_u64":
                 self.scc = int(self.g64(a[0]) == self.g64(a[1]))
+            elif op == "s_bitcmp1_b64":
+                self.scc = (self.g64(a[0]) >> (self.g32(a[1]) & 63)) & 1
             elif op == "s_cselect_b32":
                 self.p32(a[0], self.g32(a[1]) if self.scc else self.g32(a[2]))
             elif op == "s_cbranch_scc0":

@@ -62,6 +62,21 @@ int main() {
         ok &= same(inv(fa), inv_fermat(fa));
         if (!ok && bad++ < 5) printf("inversion mismatch at case %d\n", k);
     }
+    for (int k = 0; k < 2000; k++) {   // the scalar field's division-step inversion (9 limbs of 30 bits) against Fermat
+        uint32_t raw[8];
+        for (int i = 0; i < 8; i++) raw[i] = (uint32_t)sm(seed);
+        raw[7] &= 0x3fffffffu;  // < 2^254 < r
+        if (k == 0) for (int i = 0; i < 8; i++) raw[i] = 0;
+        if (k == 1) for (int i = 0; i < 8; i++) raw[i] = i == 0;
+        if (k == 2) { for (int i = 0; i < 8; i++) raw[i] = FrParams::MOD[i]; raw[0] -= 1; }
+        if (k == 3) { for (int i = 0; i < 8; i++) raw[i] = 0; raw[0] = 2; }
+        if (k >= 4 && k < 260) { for (int i = 0; i < 8; i++) raw[i] = 0; raw[(k - 4) >> 5] = 1u << ((k - 4) & 31); if (k - 4 >= 254) raw[7] = 1; }
+        const Fr a = fe_from_raw<FrParams>(raw);
+        const Fr i1 = inv_divsteps(a), i2 = inv(a);
+        bool ok = true;
+        for (int i = 0; i < 8; i++) ok &= i1.l[i] == i2.l[i];
+        if (!ok && bad++ < 5) printf("Fr inversion mismatch at case %d\n", k);
+    }
     // ---- 2. field operations, lazy bounds included
     for (int k = 0; k < 2000; k++) {
         uint32_t ra[12], rb[12], rc[12], rd[12];
