@@ -323,6 +323,27 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                 "value": nb * steps / el, "unit": "pairs/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern}
     leg("commit_prove_b256", commit_prove)
 
+    def blob_proof_1024(ckzg):
+        """a whole chunk of proofs per call on one stream: reference mode here, c-kzg mode after the settings object has moved to the Lagrange form
+        (last leg but one): there the quotient is taken in evaluation form (k_eval_quotient_evalform) and no transform runs at all"""
+        def run():
+            n = BLOBS_PER_GPU
+            d_b = dev_bytes(B.synthetic_batch(7000, n, big_endian=not ckzg))
+            d_c = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+            d_p = torch.empty(48 * n, dtype=torch.uint8, device=dev)
+            d_s = torch.zeros(n, dtype=torch.int32, device=dev)
+            K.blob_to_kzg_commitment_batch_device(d_c.data_ptr(), d_b.data_ptr(), n, ts, stream, d_s.data_ptr())
+            torch.cuda.synchronize(dev)
+            assert int(d_s.abs().sum().item()) == 0
+            steps = 10
+            el, kern = region(lambda: K.compute_blob_kzg_proof_batch_device(d_p.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), n, ts, stream, d_s.data_ptr()), steps, 3)
+            assert int(d_s.abs().sum().item()) == 0
+            return {"workload": "BASELINE configs[2] at batch=%d device-resident blobs per call, one caller stream, %s" %
+                                (n, "c-kzg-4844 semantics on the Lagrange form: the quotient in evaluation form, no transform" if ckzg else "reference semantics"),
+                    "value": n * steps / el, "unit": "proofs/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern}
+        return run
+    leg("blob_proof_b1024", blob_proof_1024(False))
+
     def ckzg_commit():
         n = BLOBS_PER_GPU
         d_le = dev_bytes(B.synthetic_batch(0, n, big_endian=False))
@@ -447,6 +468,8 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                 "value": n * steps / el, "unit": "ops/s", "steps": steps, "warmup": 3, "ms_per_step": el / steps * 1e3, "kernels": kern}
     leg("commit_b1024_one_stream_after_twin", commit_after_two_streams)
     leg("ckzg_commit_b1024_lagrange", ckzg_commit_lagrange)
+    if "error" not in out["ckzg_commit_b1024_lagrange"]:
+        leg("ckzg_blob_proof_b1024_lagrange", blob_proof_1024(True))
     return out
 
 LINE_LIMIT = 8000            # bytes of the one stdout line (the driver keeps a bounded tail of stdout)
@@ -827,10 +850,9 @@ def main():
         extra["default_engine"]["setup_load_s_incl_table_build"] = t_load
         if rank == 0:
             extra["api_latency"] = api_latency_leg(K, B, ts, default_bits)
-        # (b) the low-memory fallback
-        ts.enable_direct_table(0)
-        extra["bucket_engine"] = engine_leg(0, "Pippenger buckets over the 9 MB fixed-base table (LWKZG_DIRECT_BITS=0, or no memory for a table)")
-        ts.enable_direct_table(default_bits)
+        # (b) the low-memory fallback runs LAST (below, after the config legs): every free of a table is memory the driver scrubs before
+        # the next large hipMalloc returns, and the bucket leg in this place cost the timed region's table two of them (7.8 s of
+        # direct_table_build_s in r05's first collection, 6.5 s of it hipMalloc waiting)
 
     # the engine of the timed region. Every rank builds its own table from the (broadcast) setup points, once, outside the
     # timed region; the seconds are reported per rank below.
@@ -936,6 +958,13 @@ def main():
     if args.op == "commit" and world == 1 and not args.no_config_legs and not args.no_extra_legs and args.mode == "reference":
         extra["configs"] = config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits)
 
+    timed_row_bytes = ts.direct_row_bytes() if direct_bits else None
+    if args.op == "commit" and not args.no_extra_legs:
+        # (b) the low-memory fallback; the table of the timed region is not rebuilt afterwards (nothing below needs it)
+        ts.enable_direct_table(0)
+        ts.set_mode(-1)      # (the config legs' last ones left the settings object in c-kzg mode; no table is left to move)
+        extra["bucket_engine"] = engine_leg(0, "Pippenger buckets over the 9 MB fixed-base table (LWKZG_DIRECT_BITS=0, or no memory for a table)")
+
     if rank == 0:
         total_blobs = n * world * args.steps
         value = total_blobs / elapsed
@@ -1006,7 +1035,7 @@ def main():
             "setup_load_breakdown_ms": load_breakdown.get("load"),
             "default_table_build_breakdown_ms": load_breakdown.get("last_table_build"),
             "msm_path": ("direct table, %d-bit windows, %d windows, %d-byte rows, %.0f GB resident" % (
-                direct_bits, nwin, ts.direct_row_bytes(), capi.direct_table_bytes(direct_bits, ts.direct_row_bytes()) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
+                direct_bits, nwin, timed_row_bytes, capi.direct_table_bytes(direct_bits, timed_row_bytes) / 1e9)) if direct_bits else "bucket (Pippenger, 13-bit signed windows, 9 MB table)",
             "engine_note": "the timed region runs on the widest direct table that fits (--direct-bits auto, an explicit lwkzg_enable_direct_table "
                            "call); `default_engine` is the same workload on the engine a plain load selects, `bucket_engine` on the low-memory fallback",
             "direct_table_build_s": t_table if direct_bits else None,

@@ -435,6 +435,7 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
     constexpr int kChunk = kBlobElems / kThreads;
     static_assert(kChunk == 16 && kThreads == 256, "the index arithmetic below is for 256 x 16");
     __shared__ Fr28 tree[2 * kThreads];   // heap order: node j has children 2j, 2j + 1; leaf of thread t = tree[kThreads + t]
+    __shared__ Fr28 sh_c;
     __shared__ int sh_m;
     __shared__ uint32_t sh_zero;
     const int t = threadIdx.x;
@@ -445,6 +446,17 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
     const Fr28 z = fr28_from_mont256(z_mont[blob]);   // (2, 1)
     const Fr28 one = fr28_const_one();
     if (t == 0) sh_m = -1;
+    // (z^4096 - 1) / 4096, Montgomery form, (2, 1): by ONE lane, of a wave that does not invert below. Left to every thread the compiler
+    // computes these thirteen products of workgroup-uniform values on the SCALAR unit, 19.5k scalar instructions per wave (rocprofv3 PMC,
+    // gpurun_out r05/pmc_evf: as many as two thirds of the kernel's vector instructions)
+    if (t == (int)(((blockIdx.x + 2u) & 3u) * 64u)) {
+        Fr28 zn = z;
+#pragma unroll
+        for (int j = 0; j < 10; j++) asm volatile("" : "+v"(zn.l[j]));   // (opaque, in vector registers: the chain below stays on the vector unit)
+#pragma unroll 1
+        for (int k = 0; k < 12; k++) zn = fr28_mul(zn, zn);
+        sh_c = LWK_FR28_MUL_CONST(fr28_sub(zn, one), NINV_M);
+    }
     __syncthreads();
 
     // (the three loops over the 16 elements are NOT unrolled: 100 products of 230 instructions would be three times the instruction cache;
@@ -533,12 +545,8 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
         acc = fr28_norm(acc);     // (32, 1)
         psum = fr28_norm(psum);   // (16, 1)
         evalform_block_sum2<kThreads>(tree, acc, psum, t);   // (8192, 1), (4096, 1)
-        Fr28 zn = z;
-#pragma unroll 1
-        for (int k = 0; k < 12; k++) zn = fr28_mul(zn, zn);
-        const Fr28 c = LWK_FR28_MUL_CONST(fr28_sub(zn, one), NINV_M);   // (z^4096 - 1) / 4096, Montgomery form, (2, 1)
         const Fr28 a = fr28_sub(fr28_mul(acc, z), LWK_FR28_MUL_CONST(psum, ONE));   // z sum p inv - sum p: (6, 3)
-        yc = fr28_canonical(fr28_mul(a, c));
+        yc = fr28_canonical(fr28_mul(a, sh_c));
     } else {
         __syncthreads();
         if ((int)i0 <= m && m < (int)(i0 + kChunk)) tree[0] = evalform_load(pin + 2 * (m - (int)i0));

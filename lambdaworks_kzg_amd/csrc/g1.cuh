@@ -261,7 +261,10 @@ LWK_HD G1Affine29 affine_to_29(const G1Affine &p) {
 // decompress_g1_point (/root/reference/src/compression.rs:62-103) WITHOUT the subgroup check, in the hot-loop
 // representation: 0 = (x, y) is the point, 1 = point at infinity, 2 = invalid (not flagged compressed, or x^3 + 4 is
 // not a square). want_greater = the ZCash sign bit (select_sqrt_value_from_third_bit).
-LWK_HD int g1_decompress29_nocheck(const uint8_t *in48, F29<2> &x, F29<2> &y, bool &want_greater) {
+// `root`: F29<2> -> its ((p + 1) / 4)-th power given the exponent's words (the default: f29_pow; k_decompress_points passes a chain
+// whose window table lives in LDS, sha256.hip)
+template <class Root>
+LWK_HD int g1_decompress29_nocheck_t(const uint8_t *in48, F29<2> &x, F29<2> &y, bool &want_greater, Root root) {
     uint8_t b[48];
     for (int k = 0; k < 48; k++) b[k] = in48[k];
     const uint8_t prefix = b[0] >> 5;
@@ -276,7 +279,7 @@ LWK_HD int g1_decompress29_nocheck(const uint8_t *in48, F29<2> &x, F29<2> &y, bo
     F29<2> y2 = (sqr(x) * x + f29_from_raw32(four)) * F29<1>::one();  // the product by R mod p reduces < 4p back to < 2p
     const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
                             0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
-    F29<2> r = f29_pow<12>(y2, e);  // y2^((p+1)/4)
+    F29<2> r = root(y2, e);  // y2^((p+1)/4)
     if (!(sqr(r) - y2).is_zero()) return 2;  // x^3 + 4 is not a square: not on the curve
     uint32_t ry[12], half[12], one[12] = {1};
     f29_to_raw32(ry, r);
@@ -288,6 +291,9 @@ LWK_HD int g1_decompress29_nocheck(const uint8_t *in48, F29<2> &x, F29<2> &y, bo
     const bool r_greater = !raw_geq<12>(half, ry);
     y = cneg(r, want_greater != r_greater) * F29<1>::one();  // back to < 2p
     return 0;
+}
+LWK_HD int g1_decompress29_nocheck(const uint8_t *in48, F29<2> &x, F29<2> &y, bool &want_greater) {
+    return g1_decompress29_nocheck_t(in48, x, y, want_greater, [](const F29<2> &a, const uint32_t *e) { return f29_pow<12>(a, e); });
 }
 
 // [k]P, k = NK little-endian 32-bit limbs (plain integer, not reduced); left-to-right double-and-add

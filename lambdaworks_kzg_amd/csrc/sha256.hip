@@ -583,13 +583,64 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
 // kind carries the sign bit in bit 8 between the two kernels (rc | want_greater << 8) and is final (0 / 1 / 2) after
 // the second; readers in between mask with 0xff.
 
+// The square root's chain for a lane that is alone on its SIMD (256 commitments are four waves): f29_pow's 4-bit windows with the products
+// INLINED (a call costs the lone wave ~40 instruction slots of moves, 475 times) and the 16-entry window table in LDS, [entry][limb][lane]
+// (the exponent is public: every lane reads the same entry, its own column; the table indexed by a run-time digit would otherwise live
+// in scratch, a memory round trip per window).
+__device__ __forceinline__ F29<2> sqrt_chain_lds(const F29<2> &a, const uint32_t *e, uint32_t (*tab)[14][64], int lane) {
+    typedef F29<2, true> Fi;
+    Fi t1;
+#pragma unroll
+    for (int j = 0; j < 14; j++) t1.l[j] = a.l[j];
+    t1 = t1 * F29<1, true>::one();
+    const Fi one = Fi::one();
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        tab[0][j][lane] = one.l[j];
+        tab[1][j][lane] = t1.l[j];
+    }
+    Fi cur = t1;
+#pragma unroll 1
+    for (int k = 2; k < 16; k++) {
+        cur = cur * t1;
+#pragma unroll
+        for (int j = 0; j < 14; j++) tab[k][j][lane] = cur.l[j];
+    }
+    Fi acc = one;
+    bool started = false;
+#pragma unroll 1
+    for (int w = 12 * 8 - 1; w >= 0; w--) {
+        const uint32_t d = (e[w >> 3] >> (4 * (w & 7))) & 15u;
+        if (started) {
+            acc = sqr(acc);
+            acc = sqr(acc);
+            acc = sqr(acc);
+            acc = sqr(acc);
+        }
+        if (d) {
+            Fi f;
+#pragma unroll
+            for (int j = 0; j < 14; j++) f.l[j] = tab[d][j][lane];
+            acc = started ? acc * f : f;
+            started = true;
+        }
+    }
+    F29<2> r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) r.l[j] = acc.l[j];
+    return r;
+}
+
 __global__ __launch_bounds__(64) void k_decompress_points(const uint8_t *__restrict__ in48, G1Affine29 *__restrict__ pts,
                                                           int32_t *__restrict__ kind, size_t n) {
+    __shared__ uint32_t tab[16][14][64];   // 56 KiB: two workgroups to a compute unit
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     F29<2> x = F29<2>::zero(), y = F29<2>::zero();
     bool want_greater = false;
-    const int rc = g1_decompress29_nocheck(in48 + 48 * i, x, y, want_greater);
+    const int lane = threadIdx.x;
+    const int rc = g1_decompress29_nocheck_t(in48 + 48 * i, x, y, want_greater,
+                                             [&](const F29<2> &a, const uint32_t *e) { return sqrt_chain_lds(a, e, tab, lane); });
     G1Affine29 aff;
     aff.x = rc == 0 ? x : F29<2>::zero();
     aff.y = rc == 0 ? y : F29<2>::zero();

@@ -68,6 +68,16 @@ python tools/small_batch_timing.py > $O/small_batch_timing.txt 2>&1
 LWKZG_COOP=0 python tools/small_batch_timing.py > $O/small_batch_timing_coop_off.txt 2>&1
 LWKZG_COOP=0 LWKZG_HOST_FINISH=0 python tools/single_blob_timing.py > $O/single_blob_timing_r04_arm.txt 2>&1
 LWKZG_MID_PROOF_PIPE=0 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256_unpiped.json python bench.py --op blob_proof --batch 256 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_line_blob_proof_b256_unpiped.json 2>> $O/bench_err.txt
+# c-kzg proofs: the quotient in evaluation form against r04's coefficient-form arm; the validation on quads against r04's kernel; a fresh process loading straight into the 16-bit table
+LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b1024_ckzg.json python bench.py --op blob_proof --batch 1024 --mode ckzg --no-cpu-baseline > $O/bench_line_blob_proof_b1024_ckzg.json 2>> $O/bench_err.txt
+LWKZG_CKZG_EVAL_PROOFS=0 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b1024_ckzg_coefficient_arm.json python bench.py --op blob_proof --batch 1024 --mode ckzg --no-cpu-baseline > $O/bench_line_blob_proof_b1024_ckzg_coefficient_arm.json 2>> $O/bench_err.txt
+LWKZG_VALIDATE_COOP=0 LWKZG_BENCH_DETAIL=$O/bench_detail_blob_proof_b256_validate_r04_arm.json python bench.py --op blob_proof --batch 256 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_line_blob_proof_b256_validate_r04_arm.json 2>> $O/bench_err.txt
+LWKZG_DIRECT_BITS=16 python tools/setup_load_timing.py > $O/setup_load_timing_16bit.txt 2>&1
+python tools/setup_load_timing.py > $O/setup_load_timing.txt 2>&1
+PK="python3 bench.py --op blob_proof --mode ckzg --batch 1024 --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_proof_ckzg -o kt -- $PK > $O/kt_proof_ckzg_line.json 2> $O/kt_proof_ckzg_err.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_ckzg_sq1 -o sq -- $PK > $O/pmc_ckzg_sq1_line.json 2> $O/pmc_ckzg_sq1_err.txt
+rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_ckzg_sq2 -o sq -- $PK > $O/pmc_ckzg_sq2_line.json 2> $O/pmc_ckzg_sq2_err.txt
 python tools/experiments/r05_host_cold.py > $O/host_cold.txt 2>&1
 tools/ubench_latency_bin > $O/ubench_latency.txt 2>&1
 python tools/host_api_timing.py > $O/host_api_timing.txt 2>&1

@@ -16,7 +16,10 @@ done
 for f in small_batch_timing small_batch_timing_coop_off single_blob_timing_r04_arm host_cold ubench_latency; do
   [ -s $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${TAG}_$f.txt
 done
-[ -s $O/bench_line_blob_proof_b256_unpiped.json ] && tail -1 $O/bench_line_blob_proof_b256_unpiped.json > $P/${TAG}_bench_line_blob_proof_b256_unpiped.json
+for f in bench_line_blob_proof_b256_unpiped bench_line_blob_proof_b1024_ckzg bench_line_blob_proof_b1024_ckzg_coefficient_arm bench_line_blob_proof_b256_validate_r04_arm; do
+  [ -s $O/$f.json ] && tail -1 $O/$f.json > $P/${TAG}_$f.json
+done
+for f in setup_load_timing setup_load_timing_16bit; do [ -s $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${TAG}_$f.txt; done
 [ -s $O/kt_line.json ] && tail -1 $O/kt_line.json > $P/${TAG}_bench_kernel_stats_run_line.json   # the line the profiled run itself printed
 for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
 grep -v "amdgpu.ids" $O/host_api_timing.txt > $P/${TAG}_host_api_timing.txt || true
@@ -26,7 +29,7 @@ tag = sys.argv[1]
 O = 'gpurun_out/final'
 def ours(rows, col):
     return [rows[0]] + [r for r in rows[1:] if 'lwk::' in r[col] or 'rocclr' in r[col]]
-for d, name in (('kt_single', 'single_blob_calls_kernel_stats'), ('kt', 'bench_kernel_stats'), ('kt_all', 'bench_all_legs_kernel_stats'), ('kt_cpp', 'compiler_scheduled_arm_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats')):
+for d, name in (('kt_single', 'single_blob_calls_kernel_stats'), ('kt', 'bench_kernel_stats'), ('kt_all', 'bench_all_legs_kernel_stats'), ('kt_cpp', 'compiler_scheduled_arm_kernel_stats'), ('kt_default', 'default_engine_kernel_stats'), ('kt_bucket', 'bucket_engine_kernel_stats'), ('kt_proof', 'blob_proof_b1024_kernel_stats'), ('kt_proof_ckzg', 'blob_proof_b1024_ckzg_kernel_stats')):
     f = '%s/%s/kt_kernel_stats.csv' % (O, d)
     if os.path.exists(f):
         rows = list(csv.reader(open(f)))
@@ -53,6 +56,7 @@ pmc(['fetch_bucket'], 'profiles/%s_pmc_bucket_fetch_size.csv' % tag)
 pmc(['write_bucket'], 'profiles/%s_pmc_bucket_write_size.csv' % tag)
 pmc(['fetch_default'], 'profiles/%s_pmc_default_engine_fetch_size.csv' % tag)
 pmc(['pmc_single_sq', 'pmc_single_grbm'], 'profiles/%s_pmc_single_blob_calls_sq_counters.csv' % tag)
+pmc(['pmc_ckzg_sq1', 'pmc_ckzg_sq2'], 'profiles/%s_pmc_blob_proof_b1024_ckzg_sq_counters.csv' % tag)
 PY
 python3 tools/pmc_summary.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv $TAG 1024 16 | grep -E "direct_acc|wrote"
 python3 tools/pmc_issue_summary.py k_direct_accumulate $P/${TAG}_issue_summary_compiler_scheduled_arm.json $O/pmc_cpp_sq1/sq_counter_collection.csv $O/pmc_cpp_sq2/sq_counter_collection.csv $O/pmc_cpp_grbm/grbm_counter_collection.csv > /dev/null
