@@ -547,7 +547,8 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
         if (e == hipSuccess) e = hipMalloc((void **)&c->table, (size_t)kTablePoints * sizeof(G1Affine29));
         if (e == hipSuccess) e = hipMalloc((void **)&c->tw_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr));
         if (e == hipSuccess) e = hipMalloc((void **)&c->tw_inv, (size_t)(kBlobElems / 2) * sizeof(Fr));
-        if (e == hipSuccess) e = hipMalloc((void **)&c->tw28_fwd, (size_t)(kBlobElems / 2) * sizeof(Fr28));
+        // (behind the 2048 forward twiddles: the 4096 domain points in element order, for the evaluation-form quotient)
+        if (e == hipSuccess) e = hipMalloc((void **)&c->tw28_fwd, (size_t)(kBlobElems / 2 + kBlobElems) * sizeof(Fr28));
         if (e == hipSuccess) e = hipMalloc((void **)&c->tw28_inv, (size_t)(kBlobElems / 2) * sizeof(Fr28));
     }
     if (e != hipSuccess) {
@@ -594,6 +595,7 @@ static C_KZG_RET ctx_finish_fft(Ctx *c) {
     launch_build_twiddles(c->tw_fwd, c->tw_inv, c->stream);
     launch_twiddles_to28(c->tw_fwd, c->tw28_fwd, c->stream);
     launch_twiddles_to28(c->tw_inv, c->tw28_inv, c->stream);
+    launch_roots_brp28(c->tw28_fwd, c->tw28_fwd + kBlobElems / 2, c->stream);
     const int n = kBlobElems;
     std::vector<Fr> h_f(n / 2), h_i(n / 2);
     LWK_HIP(hipMemcpyAsync(h_f.data(), c->tw_fwd, (n / 2) * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
@@ -832,7 +834,7 @@ static bool proof_in_evaluation_form(const Ctx *c, int mode) {
 // quotient (and y = p(z)) of n blobs whose scalars coefficients_stage left at `in`, in the form that function chose
 static void quotient_stage(Ctx *c, int mode, const uint32_t *in, const Fr *z, uint32_t *quot, uint8_t *y_out, int le, size_t n, hipStream_t st,
                            const uint32_t *only_if = nullptr) {
-    if (proof_in_evaluation_form(c, mode)) launch_eval_quotient_evalform(in, z, c->tw28_fwd, quot, y_out, le, n, st, only_if);
+    if (proof_in_evaluation_form(c, mode)) launch_eval_quotient_evalform(in, z, c->tw28_fwd + kBlobElems / 2, quot, y_out, le, n, st, only_if);
     else launch_eval_quotient(in, z, quot, y_out, le, n, st, only_if);
 }
 // the quotients in w.scalars2 (slots base ..) -> the form their MSM runs on; returns that form (true = Lagrange). The coefficients

@@ -386,11 +386,28 @@ __device__ __forceinline__ Fr28 fr28_const_one() {
     for (int i = 0; i < 10; i++) r.l[i] = R28::ONE[i];
     return r;
 }
-// w_i for i = 16 t + k, canonical Montgomery form: w^e with e = bitrev12(i); tw[j] = w^j for j < 2048, w^(j + 2048) = -w^j
-__device__ __forceinline__ Fr28 evalform_omega(const Fr28 *__restrict__ tw28, uint32_t i) {
+// roots[i] = w_i = w^bitrev12(i), canonical Montgomery form, for all 4096 i IN ELEMENT ORDER (k_roots_brp28 below writes the table once
+// per setup, behind the transform's 2048 twiddles): thread t of a workgroup works on the elements i = 256 k + t, so that the 64 lanes
+// of a wave read 64 CONSECUTIVE table entries, blob elements and quotient slots (2.5 KB / 2 KB per access instead of 64 cache lines)
+__global__ __launch_bounds__(256) void k_roots_brp28(const Fr28 *__restrict__ tw28, Fr28 *__restrict__ roots) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kBlobElems) return;
     const uint32_t e = __brev(i) >> 20;
-    const Fr28 w = tw28[e & (kBlobElems / 2 - 1)];
-    return e >= kBlobElems / 2 ? fr28_neg_canonical(w) : w;
+    const Fr28 w = tw28[e & (kBlobElems / 2 - 1)];   // tw[j] = w^j for j < 2048, w^(j + 2048) = -w^j
+    Fr28 r = w;
+    if (e >= kBlobElems / 2) {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            const uint32_t t = R28::MOD[j] - w.l[j] - borrow;
+            borrow = t >> 31;
+            r.l[j] = t & R28::MASK;
+        }
+    }
+    roots[i] = r;
+}
+void launch_roots_brp28(const Fr28 *tw28, Fr28 *roots, hipStream_t st) {
+    hipLaunchKernelGGL(k_roots_brp28, dim3(kBlobElems / 256), dim3(256), 0, st, tw28, roots);
 }
 __device__ __forceinline__ Fr28 evalform_load(const uint4 *__restrict__ p) {
     const uint4 lo = p[0], hi = p[1];
@@ -430,7 +447,7 @@ __device__ __forceinline__ void evalform_block_sum2(Fr28 *sh, Fr28 &a, Fr28 &b, 
 
 template <int kThreads>
 __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4 *__restrict__ evals_raw, const Fr *__restrict__ z_mont,
-                                                                     const Fr28 *__restrict__ tw28, uint4 *__restrict__ quot_raw,
+                                                                     const Fr28 *__restrict__ roots, uint4 *__restrict__ quot_raw,
                                                                      uint8_t *__restrict__ y_out, int le, const uint32_t *__restrict__ only_if) {
     constexpr int kChunk = kBlobElems / kThreads;
     static_assert(kChunk == 16 && kThreads == 256, "the index arithmetic below is for 256 x 16");
@@ -441,8 +458,8 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
     const int t = threadIdx.x;
     const size_t blob = blockIdx.x;
     if (only_if && !only_if[blob]) return;
-    const uint4 *pin = evals_raw + (blob * kBlobElems + (size_t)t * kChunk) * 2;
-    const uint32_t i0 = (uint32_t)t * kChunk;
+    // element k of this thread is i = 256 k + t (see k_roots_brp28)
+    const uint4 *pin = evals_raw + (blob * kBlobElems + (size_t)t) * 2;
     const Fr28 z = fr28_from_mont256(z_mont[blob]);   // (2, 1)
     const Fr28 one = fr28_const_one();
     if (t == 0) sh_m = -1;
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
     auto build = [&](const int m_) -> bool {
 #pragma unroll 1
         for (int k = 0; k < kChunk; k++) {   // d_k = z - w_k: (6, 3)
-            const Fr28 d = (int)(i0 + k) == m_ ? one : fr28_sub(z, evalform_omega(tw28, i0 + k));
+            const Fr28 d = k * kThreads + t == m_ ? one : fr28_sub(z, roots[k * kThreads + t]);
             pre[k] = k == 0 ? d : fr28_mul(pre[k - 1], d);   // (2, 1) x (6, 3)
         }
         tree[kThreads + t] = pre[kChunk - 1];
@@ -496,11 +513,11 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
         const Fr28 zc = fr28_canonical(z);
 #pragma unroll 1
         for (int k = 0; k < kChunk; k++) {
-            const Fr28 w = evalform_omega(tw28, i0 + k);
+            const Fr28 w = roots[k * kThreads + t];
             uint32_t diff = 0;
 #pragma unroll
             for (int j = 0; j < 10; j++) diff |= w.l[j] ^ zc.l[j];
-            if (!diff) sh_m = (int)(i0 + k);
+            if (!diff) sh_m = k * kThreads + t;
         }
         __syncthreads();
         m = sh_m;
@@ -526,12 +543,12 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
         Fr28 inv_k = run;
         if (k > 0) {
             inv_k = fr28_mul(run, pre[k - 1]);
-            const Fr28 d = (int)(i0 + k) == m ? one : fr28_sub(z, evalform_omega(tw28, i0 + k));
+            const Fr28 d = k * kThreads + t == m ? one : fr28_sub(z, roots[k * kThreads + t]);
             run = fr28_mul(run, d);
         }
         pre[k] = inv_k;
         if (m < 0) {   // (uniform; on the domain y is p_m and the sums are not needed)
-            const Fr28 pk = evalform_load(pin + 2 * k);
+            const Fr28 pk = evalform_load(pin + 2 * k * kThreads);
             acc = fr28_add(acc, fr28_mul(pk, inv_k));   // (2, 1) each
             psum = fr28_add(psum, pk);                  // (1, 1) each
             if (k == kChunk / 2) {                      // (8 x 2 units of limb at most between ripples)
@@ -549,40 +566,38 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
         yc = fr28_canonical(fr28_mul(a, sh_c));
     } else {
         __syncthreads();
-        if ((int)i0 <= m && m < (int)(i0 + kChunk)) tree[0] = evalform_load(pin + 2 * (m - (int)i0));
+        if ((m & (kThreads - 1)) == t) tree[0] = evalform_load(pin + 2 * (m - t));
         __syncthreads();
         yc = tree[0];   // p_m
     }
-    uint4 *qout = quot_raw + (blob * kBlobElems + (size_t)t * kChunk) * 2;
+    uint4 *qout = quot_raw + (blob * kBlobElems + (size_t)t) * 2;
     Fr28 part;   // z on the domain: sum of q_i w_i over this thread's i != m
 #pragma unroll
     for (int j = 0; j < 10; j++) part.l[j] = 0;
 #pragma unroll 1
     for (int k = 0; k < kChunk; k++) {
-        const Fr28 q = fr28_canonical(fr28_mul(fr28_sub(yc, evalform_load(pin + 2 * k)), pre[k]));   // (6, 3) x (2, 1)
-        if ((int)(i0 + k) != m) {
+        const Fr28 q = fr28_canonical(fr28_mul(fr28_sub(yc, evalform_load(pin + 2 * k * kThreads)), pre[k]));   // (6, 3) x (2, 1)
+        if (k * kThreads + t != m) {
             uint32_t wd[8];
             fr28_unpack(wd, q);
-            qout[2 * k] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-            qout[2 * k + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+            qout[2 * k * kThreads] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+            qout[2 * k * kThreads + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
             if (m >= 0) {
-                part = fr28_add(part, fr28_mul(q, evalform_omega(tw28, i0 + k)));
+                part = fr28_add(part, fr28_mul(q, roots[k * kThreads + t]));
                 if (k == kChunk / 2) part = fr28_norm(part);
             }
         }
     }
     if (m >= 0) {   // (uniform)
         const Fr28 sum = evalform_block_sum<kThreads>(tree, fr28_norm(part), t);
-        if ((int)i0 <= m && m < (int)(i0 + kChunk)) {
-            const uint32_t e = __brev((uint32_t)m) >> 20, j = (kBlobElems - e) & (kBlobElems - 1);   // 1 / w^e = w^(4096 - e)
-            const Fr28 tj = tw28[j & (kBlobElems / 2 - 1)];
-            const Fr28 winv = j >= kBlobElems / 2 ? fr28_neg_canonical(tj) : tj;
+        if ((m & (kThreads - 1)) == t) {
+            const uint32_t e = __brev((uint32_t)m) >> 20, j = (kBlobElems - e) & (kBlobElems - 1);   // 1 / w^e = w^(4096 - e): the element whose exponent that is
+            const Fr28 winv = roots[__brev(j) >> 20];
             const Fr28 qm = fr28_neg_canonical(fr28_canonical(fr28_mul(sum, winv)));
             uint32_t wd[8];
             fr28_unpack(wd, qm);
-            const int k = m - (int)i0;
-            qout[2 * k] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-            qout[2 * k + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+            qout[2 * (m - t)] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+            qout[2 * (m - t) + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
         }
     }
     if (t == 0 && y_out) {
@@ -593,10 +608,10 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
     }
 }
 
-void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, const Fr28 *tw28_fwd, uint32_t *quot_raw, uint8_t *y_out, int le,
+void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, const Fr28 *roots_brp28, uint32_t *quot_raw, uint8_t *y_out, int le,
                                    size_t n_blobs, hipStream_t st, const uint32_t *only_if) {
     ProfScope p(only_if ? "k_eval_quotient_evalform_redo" : "k_eval_quotient_evalform", st);
-    hipLaunchKernelGGL(k_eval_quotient_evalform<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)evals_raw, z_mont, tw28_fwd,
+    hipLaunchKernelGGL(k_eval_quotient_evalform<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)evals_raw, z_mont, roots_brp28,
                        (uint4 *)quot_raw, y_out, le, only_if);
 }
 

@@ -112,7 +112,9 @@ void launch_fr_mont_to_bytes(const Fr *in, uint8_t *out, int le, size_t n, hipSt
 void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
                           size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
 // the same in evaluation form (c-kzg mode on the Lagrange form): evaluations in, the quotient's evaluations out, y = p(z) by the barycentric formula
-void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, const Fr28 *tw28_fwd, uint32_t *quot_raw, uint8_t *y_out, int le,
+// roots_brp28: the 4096 domain points in element order (launch_roots_brp28 writes them from the transform's twiddles, once per setup)
+void launch_roots_brp28(const Fr28 *tw28_fwd, Fr28 *roots_brp28, hipStream_t st);
+void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, const Fr28 *roots_brp28, uint32_t *quot_raw, uint8_t *y_out, int le,
                                    size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
 // flags[i] = (a[48 i ..] != b[48 i ..])
 void launch_flag_differs48(const uint8_t *a, const uint8_t *b, uint32_t *flags, size_t n, hipStream_t st);
