@@ -311,14 +311,23 @@ static size_t mid_proof_host_limit() {
 // (default 2000; measured: up to a second of idleness costs the first two calls 0.2 ms, tools/experiments/r05_host_cold.py), make the
 // call take the GPU kernel this once -- and wake the threads on the side, from a host function, so that the NEXT call finds them warm
 // (a cold burst of host-assisted calls ran at 30.7k proofs/s where the GPU path does 41.5k).
+static std::atomic<int64_t> g_wake_requested_ns{0};
+static void host_warm_fn(void *);
 static bool host_assist_warm() {
     static const int64_t window_ns = [] {
         const char *e = getenv("LWKZG_HOST_WARM_MS");
         const long ms = e ? atol(e) : 2000;
         return (int64_t)(ms < 0 ? 0 : ms) * 1000000;
     }();
-    const int64_t last = host_last_active_ns();
-    return last != 0 && host_now_ns() - last <= window_ns;
+    const int64_t last = host_last_active_ns(), woken = g_wake_requested_ns.load(std::memory_order_acquire), now = host_now_ns();
+    // (a wake-up that is on its way counts: the calls of a burst are enqueued within microseconds of each other, before the first one's
+    // wake-up has run, and their host functions only run after the first call's GPU work -- milliseconds later, on threads that are awake)
+    return (last != 0 && now - last <= window_ns) || (woken != 0 && now - woken <= window_ns);
+}
+// enqueue the wake-up of the host threads on a stream the call does not wait for
+static void launch_host_wake(Ctx *c) {
+    g_wake_requested_ns.store(host_now_ns(), std::memory_order_release);
+    if (hipLaunchHostFunc(c->aux[1], host_warm_fn, nullptr) != hipSuccess) (void)hipGetLastError();
 }
 static void host_warm_fn(void *) {
     try {
@@ -990,8 +999,10 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
         launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream, longcall ? w.val_pts_long : w.val_pts,
                                     longcall ? w.val_kind_long : w.val_kind, longcall ? w.val_verdict_long : w.val_verdict);
-        if (hipLaunchHostFunc(c->vstream, host_warm_fn, nullptr) != hipSuccess) (void)hipGetLastError();
         LWK_HIP(hipEventRecord(c->ev_join[0], c->vstream));
+        // (the wake-up on a stream this call does not wait for: on the validation's stream, in front of the join event, the first call of a
+        // process paid for the creation of the thread pool)
+        launch_host_wake(c);
         launch_challenge(blobs, comm48, z, le, n, st);
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge(blobs, canon, z, le, n, st, comm48);
@@ -1130,7 +1141,7 @@ C_KZG_RET commit_and_prove_batch_device(Ctx *c, uint8_t *comm_out48, uint8_t *pr
     // mid-size calls on a settings object whose other context is idle: the commitment-free part of the hashes on the host threads,
     // chunk by chunk beside the copy out (as blob_proof_batch_device does for whole hashes), instead of the 3.2 ms kernel beside the MSM
     const bool host_cold = n <= mid_proof_host_limit() && !peer_busy(c) && !host_assist_warm();
-    if (host_cold && hipLaunchHostFunc(c->vstream, host_warm_fn, nullptr) != hipSuccess) (void)hipGetLastError();   // (the GPU kernel this once)
+    if (host_cold) launch_host_wake(c);   // (the GPU kernel this once; the wake-up on a stream this call does not wait for)
     const bool host_mid = !host_cold && n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n);
     if (host_mid) {
         SmallProofHost &h = c->sph;
@@ -2769,6 +2780,7 @@ C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 
 // everything a device-resident call of up to max_batch blobs would otherwise allocate or synchronise for on first use: the workspace,
 // the pinned staging of the host-assisted challenge paths (once, at its final size), and -- for settings that answer in c-kzg mode --
 // the Lagrange form of the setup
+static void host_noop_fn(void *) {}
 static C_KZG_RET reserve_ctx(Ctx *c, size_t max_batch) {
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
@@ -2783,6 +2795,11 @@ static C_KZG_RET reserve_ctx(Ctx *c, size_t max_batch) {
             memset(h.dig, 0, h.cap * 32);
         }
         host_pool_warm();   // the host threads exist and have run once
+        // the runtime's own first-use costs of a host function on each helper stream (its callback machinery: the first host-assisted
+        // call of a process took ~6 ms longer than the second, gpurun_out r05/gpu23) are paid here too
+        for (hipStream_t hs : {c->aux[0], c->aux[1], c->vstream})
+            if (hipLaunchHostFunc(hs, host_noop_fn, nullptr) != hipSuccess) (void)hipGetLastError();
+        for (hipStream_t hs : {c->aux[0], c->aux[1], c->vstream}) (void)hipStreamSynchronize(hs);
     }
     return C_KZG_OK;
 }
