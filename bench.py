@@ -280,9 +280,9 @@ def config_legs(K, capi, D, B, ts, dev, torch, np, direct_bits):
                 K.compute_blob_kzg_proof_batch_device(outs[i].data_ptr(), d_blobs.data_ptr(), d_comm.data_ptr(), nb, ts,
                                                       streams[i].cuda_stream if streams else stream, stats[i].data_ptr())
             # cold: the leg's first three calls, no warm-up at all (whatever state the host threads are in: the library takes the GPU's
-            # hash kernel while they are cold and wakes them on the side); steady: twenty calls after three untimed ones
+            # hash kernel while they are cold and wakes them on the side); steady: forty calls after three untimed ones
             cold_el, _ = region(step, 3, 0)
-            steps = 20
+            steps = 40     # (r05: 20 -> 40; a process pays one call of ~10 ms somewhere among its first host-assisted calls, profiles/r05_experiments.md section 8)
             el, kern = region(step, steps, 3)
             assert all(int(x.abs().sum().item()) == 0 for x in stats) and all(torch.equal(o, outs[0]) for o in outs)
             return {"workload": "BASELINE configs[2]: compute_blob_kzg_proof, batch=%d device-resident blobs per call, %d caller stream%s"

@@ -840,7 +840,7 @@ static bool proof_in_evaluation_form(const Ctx *c, int mode) {
     static const bool on = !(getenv("LWKZG_CKZG_EVAL_PROOFS") && atoi(getenv("LWKZG_CKZG_EVAL_PROOFS")) == 0);
     return on && mode == LWKZG_MODE_CKZG && c->lag.ready && (c->lag.direct_table || !c->direct_table);
 }
-// quotient (and y = p(z)) of n blobs whose scalars coefficients_stage left at `in`, in the form that function chose
+// quotient (and y = p(z)) of n blobs whose scalars coefficients_stage left at `in`, in the form that function chose; quot = nullptr: y only
 static void quotient_stage(Ctx *c, int mode, const uint32_t *in, const Fr *z, uint32_t *quot, uint8_t *y_out, int le, size_t n, hipStream_t st,
                            const uint32_t *only_if = nullptr) {
     if (proof_in_evaluation_form(c, mode)) launch_eval_quotient_evalform(in, z, c->tw28_fwd + kBlobElems / 2, quot, y_out, le, n, st, only_if);
@@ -1358,7 +1358,7 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
             launch_challenge(w.blobs + base * (size_t)kBlobBytes, vb.canon_dev + 48 * off, d_z, le, m, sk);
         }
-        quotient_stage(c, mode, w.scalars + base * (size_t)kBlobElems * 8, d_z, w.scalars2 + base * (size_t)kBlobElems * 8, d_yb, le, m,
+        quotient_stage(c, mode, w.scalars + base * (size_t)kBlobElems * 8, d_z, nullptr /* y only */, d_yb, le, m,
                              sk);
         launch_fr_mont_to_bytes(d_z, d_zb, le, m, sk);
         LWK_HIP(hipMemcpyAsync(z32 + 32 * off, d_zb, m * 32, hipMemcpyDeviceToHost, sk));
@@ -1527,7 +1527,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             if (host_validate) LWK_HIP(hipMemcpyAsync(w.canon48, canon_c + 48 * off, m * 48, hipMemcpyHostToDevice, st));
             launch_challenge(w.blobs, w.canon48, w.z, le, m, st);
         }
-        quotient_stage(c, mode, w.scalars, w.z, w.scalars2, w.ybytes, le, m, st);
+        quotient_stage(c, mode, w.scalars, w.z, nullptr /* a verification wants y = p(z) only */, w.ybytes, le, m, st);
         launch_fr_mont_to_bytes(w.z, w.zbytes, le, m, st);
         LWK_HIP(hipMemcpyAsync(z32 + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
         LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
@@ -1607,7 +1607,7 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     for (size_t off = 0; off < n; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, vb.status_all + off, st);
-        quotient_stage(c, mode, w.scalars, z + off, w.scalars2, vb.d_r + 32 * off, le, m, st);
+        quotient_stage(c, mode, w.scalars, z + off, nullptr /* y only */, vb.d_r + 32 * off, le, m, st);
         launch_fr_mont_to_bytes(z + off, vb.d_rz + 32 * off, le, m, st);
     }
     LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));

@@ -312,6 +312,16 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient(const uint4 *__restr
         __syncthreads();
     }
     // v == H_t
+    if (!quot_raw) {   // only y = p(z) is wanted (batch verification): it is thread 0's H
+        if (t == 0 && y_out) {
+            const Fr28 yv = fr28_canonical(LWK_FR28_MUL_CONST(v, ONE));
+            uint32_t w[8];
+            fr28_unpack(w, yv);
+            uint8_t *yo = y_out + 32 * blob;
+            if (le) raw_to_le<8>(yo, w); else raw_to_be<8>(yo, w);
+        }
+        return;
+    }
     Fr28 acc;
     if (t + 1 < kThreads) {
         acc = fr28_canonical(LWK_FR28_MUL_CONST(sh_v[t + 1], ONE));   // (up to 3r + 10 x 2r with lazy limbs: one product by 2^280 mod r brings it under 2r)
@@ -569,6 +579,15 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
         if ((m & (kThreads - 1)) == t) tree[0] = evalform_load(pin + 2 * (m - t));
         __syncthreads();
         yc = tree[0];   // p_m
+    }
+    if (!quot_raw) {   // only y = p(z) is wanted (batch verification)
+        if (t == 0 && y_out) {
+            uint32_t wd[8];
+            fr28_unpack(wd, yc);
+            uint8_t *yo = y_out + 32 * blob;
+            if (le) raw_to_le<8>(yo, wd); else raw_to_be<8>(yo, wd);
+        }
+        return;
     }
     uint4 *qout = quot_raw + (blob * kBlobElems + (size_t)t) * 2;
     Fr28 part;   // z on the domain: sum of q_i w_i over this thread's i != m

@@ -109,6 +109,7 @@ void launch_fr_mont_to_bytes(const Fr *in, uint8_t *out, int le, size_t n, hipSt
 // /root/reference/src/lib.rs:320,329,389,394). coeffs_raw/quot_raw: canonical limbs. y_out: 32 bytes,
 // big-endian (le = 0) or little-endian (le = 1); may be NULL.
 // only_if (optional): one word per blob; blobs whose word is zero are left as they are (a second pass over a few blobs)
+// quot_raw = NULL: only y is computed (batch verification: a third of the products less)
 void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t *quot_raw, uint8_t *y_out, int le,
                           size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
 // the same in evaluation form (c-kzg mode on the Lagrange form): evaluations in, the quotient's evaluations out, y = p(z) by the barycentric formula
