@@ -124,6 +124,46 @@ def test_equal_or_opposite_operands_raise_the_trouble_mask(which):
         assert (x * pow(zz, -1, P) % P, y * pow(zzz, -1, P) % P) == G.ec_add(As[q], Bs[q])
 
 
+def test_trouble_in_every_quad_position():
+    """P = +-Q in EVERY lane position. Sixteen runs: P = Q on quad q, P = -Q on quad q + 5, quad q + 9 left out of the
+    addition's mask (it keeps its point and can raise nothing, although its operands are equal): the trouble mask is exactly the two
+    lane-0 bits, every other quad's sum is right"""
+    import gen_coop_asm as C
+    import gen_direct_asm as G
+    P = G.P
+    rnd = random.Random(88)
+    prog = _add_prog(C, G)
+    for q0 in range(16):
+        qe, qo, qm = q0, (q0 + 5) % 16, (q0 + 9) % 16
+        addm = ((1 << 64) - 1) & ~(0xF << (4 * qm))
+        sim = C.WaveSim(prog, [addm], {}, lambda a, n: None)
+        As, Bs = [], []
+        for q in range(16):
+            a = G.ec_mul(rnd.randrange(2, R), G.G1)
+            b = G.ec_mul(rnd.randrange(2, R), G.G1)
+            if q in (qe, qm):
+                b = a
+            if q == qo:
+                b = (a[0], (-a[1]) % P)
+            As.append(a)
+            Bs.append(b)
+            ca, cb = _coords(G, rnd, a, q == qe), _coords(G, rnd, b, q == qo)
+            for c in range(4):
+                for i in range(14):
+                    sim.vr[C.HA[i]][4 * q + c] = ca[c][i]
+                    sim.vr[C.HB[i]][4 * q + c] = cb[c][i]
+        sim.run()
+        trouble = sim.sr[C.sTROUBLE[0]] | (sim.sr[C.sTROUBLE[1]] << 32)
+        assert trouble == (1 << (4 * qe)) | (1 << (4 * qo)), (q0, hex(trouble))
+        for q in range(16):
+            if q in (qe, qo):
+                continue
+            co = [[int(sim.vr[C.HA[i]][4 * q + c]) for i in range(14)] for c in range(4)]
+            x, y, zz, zzz = (G.from_mont_limbs(l) for l in co)
+            want = As[q] if q == qm else G.ec_add(As[q], Bs[q])
+            assert (x * pow(zz, -1, P) % P, y * pow(zzz, -1, P) % P) == want, (q0, q)
+
+
 @pytest.mark.parametrize("kw,order", [
     (dict(seed=1, c=4, nw=4, wtop=3, log_points=4, rpq=2), "shuffle"),                    # 2 waves, one hand-off
     (dict(seed=2, c=5, nw=3, wtop=4, log_points=5, rpq=2), "reverse"),                    # an odd window count: quads with one row
