@@ -1604,11 +1604,16 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     launch_challenge(d_blobs, vb.canon_dev, z, le, n, st, d_comm);  // only the blobs whose commitment bytes were not canonical
     // chunk by chunk with no host round trip in between: y and z bytes of ALL blobs collect in the linear combinations' scalar
     // buffers (idle until lincomb3), the parser's verdicts beside the validation's
-    for (size_t off = 0; off < n; off += kMaxChunk) {
-        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, vb.status_all + off, st);
-        quotient_stage(c, mode, w.scalars, z + off, nullptr /* y only */, vb.d_r + 32 * off, le, m, st);
-        launch_fr_mont_to_bytes(z + off, vb.d_rz + 32 * off, le, m, st);
+    if (mode == LWKZG_MODE_REFERENCE) {   // the blobs are already on the device and a reference-mode parse cannot fail: one launch reads them as they are
+        launch_eval_y_from_blobs_be(d_blobs, z, vb.d_r, n, st);
+        launch_fr_mont_to_bytes(z, vb.d_rz, le, n, st);
+    } else {
+        for (size_t off = 0; off < n; off += kMaxChunk) {
+            const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+            coefficients_stage(c, d_blobs + off * (size_t)kBlobBytes, m, mode, vb.status_all + off, st);
+            quotient_stage(c, mode, w.scalars, z + off, nullptr /* y only */, vb.d_r + 32 * off, le, m, st);
+            launch_fr_mont_to_bytes(z + off, vb.d_rz + 32 * off, le, m, st);
+        }
     }
     LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
     LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));

@@ -267,7 +267,7 @@ __device__ __forceinline__ Fr28 fr28_canonical_lazy(const Fr28 &a) {
 template <int kThreads>
 __global__ __launch_bounds__(kThreads) void k_eval_quotient(const uint4 *__restrict__ coeffs_raw, const Fr *__restrict__ z_mont,
                                                             uint4 *__restrict__ quot_raw, uint8_t *__restrict__ y_out, int le,
-                                                            const uint32_t *__restrict__ only_if) {
+                                                            const uint32_t *__restrict__ only_if, int from_blob_be) {
     constexpr int kChunk = kBlobElems / kThreads;
     __shared__ Fr28 sh_m[kThreads];
     __shared__ Fr28 sh_v[kThreads];
@@ -281,8 +281,21 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient(const uint4 *__restr
 #pragma unroll
     for (int k = 0; k < kChunk; k++) {
         const uint4 lo = cin[2 * k], hi = cin[2 * k + 1];
-        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        c[k] = fr28_pack(w);  // raw, canonical
+        if (from_blob_be) {   // `coeffs_raw` is the reference-mode BLOB itself: big-endian elements, reduced mod r as k_parse_be_reduce does (2^256 < 3r)
+            uint32_t sw[8] = {__builtin_bswap32(hi.w), __builtin_bswap32(hi.z), __builtin_bswap32(hi.y), __builtin_bswap32(hi.x),
+                              __builtin_bswap32(lo.w), __builtin_bswap32(lo.z), __builtin_bswap32(lo.y), __builtin_bswap32(lo.x)};
+#pragma unroll
+            for (int rep = 0; rep < 2; rep++) {
+                uint32_t d[8];
+                const uint32_t br = raw_sub<8>(d, sw, FrParams::MOD);
+#pragma unroll
+                for (int j = 0; j < 8; j++) sw[j] = br ? sw[j] : d[j];
+            }
+            c[k] = fr28_pack(sw);
+        } else {
+            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            c[k] = fr28_pack(w);  // raw, canonical
+        }
     }
     Fr28 L = c[kChunk - 1];
 #pragma unroll
@@ -360,7 +373,15 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
     // (512 and 1024 lanes per blob -- a chain of 37 / 29 products instead of 51 -- measured SLOWER for one blob, 0.061 / 0.077 ms against 0.054:
     // the barriers of 8 / 16 waves cost more than the shorter chain saves; gpurun_out r05)
     hipLaunchKernelGGL(k_eval_quotient<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)coeffs_raw, z_mont, (uint4 *)quot_raw,
-                       y_out, le, only_if);
+                       y_out, le, only_if, 0);
+}
+
+// y = p(z) of n reference-mode blobs straight from their bytes (big-endian coefficients), no workspace: the evaluation of a
+// device-resident batch verification as ONE launch (r05; it was a parse and an evaluation per chunk of 1024)
+void launch_eval_y_from_blobs_be(const uint8_t *blobs, const Fr *z_mont, uint8_t *y_out, size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_eval_quotient_from_blobs", st);
+    hipLaunchKernelGGL(k_eval_quotient<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)blobs, z_mont, (uint4 *)nullptr, y_out, 0,
+                       (const uint32_t *)nullptr, 1);
 }
 
 // ---- the quotient in EVALUATION form (r05) --------------------------------------------------------------------
