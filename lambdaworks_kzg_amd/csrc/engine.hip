@@ -1607,6 +1607,9 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     if (mode == LWKZG_MODE_REFERENCE) {   // the blobs are already on the device and a reference-mode parse cannot fail: one launch reads them as they are
         launch_eval_y_from_blobs_be(d_blobs, z, vb.d_r, n, st);
         launch_fr_mont_to_bytes(z, vb.d_rz, le, n, st);
+    } else if (proof_in_evaluation_form(c, mode)) {   // c-kzg on the Lagrange form: the blob's elements ARE the evaluations; range check in the same launch
+        launch_eval_y_from_blobs_evalform(d_blobs, z, c->tw28_fwd + kBlobElems / 2, vb.d_r, vb.status_all, n, st);
+        launch_fr_mont_to_bytes(z, vb.d_rz, le, n, st);
     } else {
         for (size_t off = 0; off < n; off += kMaxChunk) {
             const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;

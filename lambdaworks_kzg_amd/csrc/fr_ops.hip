@@ -479,7 +479,8 @@ __device__ __forceinline__ void evalform_block_sum2(Fr28 *sh, Fr28 &a, Fr28 &b, 
 template <int kThreads>
 __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4 *__restrict__ evals_raw, const Fr *__restrict__ z_mont,
                                                                      const Fr28 *__restrict__ roots, uint4 *__restrict__ quot_raw,
-                                                                     uint8_t *__restrict__ y_out, int le, const uint32_t *__restrict__ only_if) {
+                                                                     uint8_t *__restrict__ y_out, int le, const uint32_t *__restrict__ only_if,
+                                                                     int32_t *__restrict__ status) {
     constexpr int kChunk = kBlobElems / kThreads;
     static_assert(kChunk == 16 && kThreads == 256, "the index arithmetic below is for 256 x 16");
     __shared__ Fr28 tree[2 * kThreads];   // heap order: node j has children 2j, 2j + 1; leaf of thread t = tree[kThreads + t]
@@ -491,6 +492,17 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient_evalform(const uint4
     if (only_if && !only_if[blob]) return;
     // element k of this thread is i = 256 k + t (see k_roots_brp28)
     const uint4 *pin = evals_raw + (blob * kBlobElems + (size_t)t) * 2;
+    if (status) {   // `evals_raw` is the c-kzg BLOB itself (its canonical little-endian elements are the evaluations): the front end's range check
+                    // (k_copy_le_check's, when the blob goes through the workspace) is made here -- an element >= r: BADARGS for the blob
+        bool bad = false;
+#pragma unroll 4
+        for (int k = 0; k < kChunk; k++) {
+            const uint4 lo = pin[2 * k * kThreads], hi = pin[2 * k * kThreads + 1];
+            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            bad = bad || raw_geq<8>(w, FrParams::MOD);
+        }
+        if (bad) status[blob] = kStatusBadArgs;   // (benign race: same value)
+    }
     const Fr28 z = fr28_from_mont256(z_mont[blob]);   // (2, 1)
     const Fr28 one = fr28_const_one();
     if (t == 0) sh_m = -1;
@@ -652,7 +664,16 @@ void launch_eval_quotient_evalform(const uint32_t *evals_raw, const Fr *z_mont, 
                                    size_t n_blobs, hipStream_t st, const uint32_t *only_if) {
     ProfScope p(only_if ? "k_eval_quotient_evalform_redo" : "k_eval_quotient_evalform", st);
     hipLaunchKernelGGL(k_eval_quotient_evalform<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)evals_raw, z_mont, roots_brp28,
-                       (uint4 *)quot_raw, y_out, le, only_if);
+                       (uint4 *)quot_raw, y_out, le, only_if, (int32_t *)nullptr);
+}
+
+// y = p(z) of n c-kzg-mode blobs straight from their bytes (little-endian evaluations; an element >= r: status[blob] = BADARGS), no workspace,
+// any number in one launch: the evaluation of a device-resident batch verification on the Lagrange form
+void launch_eval_y_from_blobs_evalform(const uint8_t *blobs, const Fr *z_mont, const Fr28 *roots_brp28, uint8_t *y_out, int32_t *status,
+                                       size_t n_blobs, hipStream_t st) {
+    ProfScope p("k_eval_quotient_evalform_from_blobs", st);
+    hipLaunchKernelGGL(k_eval_quotient_evalform<256>, dim3((unsigned)n_blobs), dim3(256), 0, st, (const uint4 *)blobs, z_mont, roots_brp28,
+                       (uint4 *)nullptr, y_out, 1, (const uint32_t *)nullptr, status);
 }
 
 // flags[i] = the 48 bytes at a + 48 i differ from those at b + 48 i (a commitment whose canonical encoding is not what the caller sent)

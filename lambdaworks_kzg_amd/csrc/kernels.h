@@ -114,6 +114,8 @@ void launch_eval_quotient(const uint32_t *coeffs_raw, const Fr *z_mont, uint32_t
                           size_t n_blobs, hipStream_t st, const uint32_t *only_if = nullptr);
 // y = p(z) of reference-mode blobs straight from their bytes, any number in one launch (batch verification)
 void launch_eval_y_from_blobs_be(const uint8_t *blobs, const Fr *z_mont, uint8_t *y_out, size_t n_blobs, hipStream_t st);
+void launch_eval_y_from_blobs_evalform(const uint8_t *blobs, const Fr *z_mont, const Fr28 *roots_brp28, uint8_t *y_out, int32_t *status,
+                                       size_t n_blobs, hipStream_t st);   // c-kzg mode: little-endian evaluations, range-checked
 // the same in evaluation form (c-kzg mode on the Lagrange form): evaluations in, the quotient's evaluations out, y = p(z) by the barycentric formula
 // roots_brp28: the 4096 domain points in element order (launch_roots_brp28 writes them from the transform's twiddles, once per setup)
 void launch_roots_brp28(const Fr28 *tw28_fwd, Fr28 *roots_brp28, hipStream_t st);

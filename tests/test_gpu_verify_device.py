@@ -93,6 +93,34 @@ def test_device_batches_honest_and_tampered(K, gpu_setup, oracle, n):
         assert e.value.rc == K.C_KZG_ERROR
 
 
+@pytest.mark.parametrize("n", [3, 300, 1500])
+def test_ckzg_device_batches_evaluate_straight_from_the_blobs(K, gpu_setup, oracle, n):
+    """r05, c-kzg mode on the Lagrange form: the device form evaluates y_i = p_i(z_i) of ALL blobs in one launch that reads the blobs'
+    little-endian evaluations as they stand (k_eval_quotient_evalform without a quotient, the front end's range check inside it). Honest
+    batches verify in both forms, a swapped blob does not, and ONE element >= r anywhere in the batch is BADARGS, not a verdict"""
+    import torch
+    K.set_mode(K.MODE_CKZG)
+    try:
+        rnd = random.Random(7100 + n)
+        data = B.synthetic_batch(53000 + n, n, big_endian=False)
+        cj = b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup))
+        pj = b"".join(K.compute_blob_kzg_proof_batch(data, cj, gpu_setup))
+        assert _verify_dev(K, torch, data, cj, pj, n, gpu_setup) is True
+        assert K.verify_blob_kzg_proof_batch(data, cj, pj, n, gpu_setup) is True
+        k = rnd.randrange(n)
+        swapped = data[:k * B.BYTES_PER_BLOB] + B.synthetic_blob(99200 + n, big_endian=False) + data[(k + 1) * B.BYTES_PER_BLOB:]
+        assert _verify_dev(K, torch, swapped, cj, pj, n, gpu_setup) is False
+        for where in (0, n // 2, n - 1):
+            e_at = rnd.randrange(4096)
+            off = where * B.BYTES_PER_BLOB + 32 * e_at
+            bad = data[:off] + R.to_bytes(32, "little") + data[off + 32:]
+            with pytest.raises(K.KzgError) as e:
+                _verify_dev(K, torch, bad, cj, pj, n, gpu_setup)
+            assert e.value.rc == K.C_KZG_BADARGS, (where, e_at)
+    finally:
+        K.set_mode(K.MODE_REFERENCE)
+
+
 def test_noncanonical_infinity_encoding_is_rehashed_on_the_device(K, gpu_setup):
     """a valid commitment in a non-canonical encoding (infinity with stray bits, for the zero blob) among honest ones: the challenge of
     that blob is taken again over the canonical bytes, as the host form does"""
