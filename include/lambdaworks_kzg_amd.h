@@ -370,6 +370,10 @@ size_t lwkzg_profile_report(char *buf, size_t cap);
  * build kernels after the last allocation returned; returns bytes needed (incl. NUL). The allocations return in a millisecond on idle memory
  * and wait ~25 ms per GB for the driver's scrub of memory released shortly before (tools/alloc_pieces.hip). */
 size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap);
+/* JSON: the environment knobs in effect for this process -- read ONCE, in one place (csrc/knobs.h). "operational" and "experimental"
+ * list the variable names; experiment knobs (A/B arms of measurements) are honoured only with LWKZG_EXPERIMENTAL=1 and are otherwise
+ * ignored (reported under LWKZG_VERBOSE). Returns bytes needed (incl. NUL). INTEGRATION.md section 5 documents the operational ones. */
+size_t lwkzg_knob_report(char *buf, size_t cap);
 /* First use of the HIP runtime by this process (device context + this library's code object), so that a caller can pay
  * and time it apart from its first real call. 0, or -1 without a GPU. */
 int lwkzg_runtime_init(void);

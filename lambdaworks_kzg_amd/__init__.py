@@ -9,7 +9,8 @@ from .capi import (  # noqa: F401
     FIELD_ELEMENTS_PER_BLOB, MODE_CKZG, MODE_REFERENCE, KzgError, KZGSettings, TrustedSetup,
     blob_to_kzg_commitment, blob_to_kzg_commitment_batch, blob_to_kzg_commitment_batch_device, commit_and_prove_batch_device,
     compute_blob_kzg_proof, compute_blob_kzg_proof_batch, compute_blob_kzg_proof_batch_device,
-    compute_kzg_proof, compute_kzg_proof_batch, get_mode, lib, set_device, set_mode,
+    compute_kzg_proof, compute_kzg_proof_batch, get_mode, knob_report, lib, set_device, set_mode,
+    VerifyShard, verify_shards_finish,
     verify_blob_kzg_proof, verify_blob_kzg_proof_batch, verify_blob_kzg_proof_batch_device, verify_kzg_proof,
 )
 

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_table_forms", "lwkzg_enable_direct_table_forms", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
-    "lwkzg_timing_report", "lwkzg_runtime_init",
+    "lwkzg_timing_report", "lwkzg_runtime_init", "lwkzg_knob_report",
     "lwkzg_multi_load", "lwkzg_multi_load_file", "lwkzg_multi_free", "lwkzg_multi_device_count", "lwkzg_multi_device", "lwkzg_multi_settings",
     "lwkzg_multi_set_mode", "lwkzg_multi_enable_direct_table", "lwkzg_multi_blob_to_kzg_commitment_batch",
     "lwkzg_multi_compute_blob_kzg_proof_batch", "lwkzg_multi_compute_kzg_proof_batch", "lwkzg_multi_verify_blob_kzg_proof_batch",
@@ -88,6 +88,8 @@ def lib():
     l.lwkzg_set_mode.argtypes = [ci]
     l.lwkzg_timing_report.argtypes = [ps, C.c_char_p, sz]
     l.lwkzg_timing_report.restype = sz
+    l.lwkzg_knob_report.argtypes = [C.c_char_p, sz]
+    l.lwkzg_knob_report.restype = sz
     l.lwkzg_settings_set_mode.argtypes = [ps, ci]
     l.lwkzg_settings_get_mode.argtypes = [ps]
     l.lwkzg_blob_to_kzg_commitment_batch.argtypes = [C.c_char_p, C.c_char_p, sz, ps, C.POINTER(sz)]
@@ -197,6 +199,14 @@ def set_mode(mode):
 
 def get_mode():
     return lib().lwkzg_get_mode()
+
+
+def knob_report():
+    """the environment knobs in effect for this process (lwkzg_knob_report; csrc/knobs.h reads them once, in one place)"""
+    n = lib().lwkzg_knob_report(None, 0)
+    buf = C.create_string_buffer(n)
+    lib().lwkzg_knob_report(buf, n)
+    return json.loads(buf.value.decode())
 
 
 def clock_probe_mhz():

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <chrono>
 #include "kernels.h"
+#include "knobs.h"
 
 namespace lwk {
 
@@ -552,37 +553,19 @@ __global__ __launch_bounds__(256) void k_coop_msm_asm(const uint64_t *__restrict
 }
 
 // LWKZG_COOP=0 switches the cooperative kernel off; LWKZG_COOP_MAX = the largest batch it takes (default 8);
-static int coop_max_blobs() {
-    static const int v = [] {
-        const char *e = getenv("LWKZG_COOP");
-        if (e && atoi(e) == 0) return 0;
-        const char *m = getenv("LWKZG_COOP_MAX");
-        return m ? atoi(m) : 8;
-    }();
-    return v;
-}
+static int coop_max_blobs() { return knobs().coop == 0 ? 0 : knobs().coop_max; }   // (experiment knobs; coop_max is clamped to 1..8)
 // rows a quad adds before the tree. A blob is 256 waves per group of `rpq` windows; the chip has 1024 SIMDs and a wave that shares
 // its SIMD takes twice as long, so the launch aims at 1024 waves in all: four window groups for one blob (16 windows: 4 rows per
 // quad, 20: 5), two for two blobs, one from four blobs on. LWKZG_COOP_RPQ overrides (experiments).
 static int coop_rows_per_quad(int nw, size_t n_blobs) {
-    static const int env = [] {
-        const char *e = getenv("LWKZG_COOP_RPQ");
-        const int r = e ? atoi(e) : 0;
-        return r < 0 ? 0 : r > 32 ? 32 : r;
-    }();
+    const int env = knobs().coop_rpq < 0 ? 0 : knobs().coop_rpq > 32 ? 32 : knobs().coop_rpq;
     if (env) return env;
     const int groups = n_blobs >= 4 ? 1 : (int)(4 / n_blobs);
     return (nw + groups - 1) / groups;
 }
 
 // LWKZG_DIRECT_ASM=0 keeps every launch on the compiler-scheduled kernel (the A/B arm)
-static bool direct_asm_enabled() {
-    static const bool on = [] {
-        const char *e = getenv("LWKZG_DIRECT_ASM");
-        return !(e && atoi(e) == 0);
-    }();
-    return on;
-}
+static bool direct_asm_enabled() { return knobs().direct_asm; }
 
 template <int CT>
 static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw,
@@ -593,7 +576,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
     // to aim for: 512 (two per compute unit, one round) when the kernel has the chip alone; 2048 when the settings
     // object runs two overlapping pipelines (engine.hip: pick_ctx), where workgroups of a quarter of the length keep the
     // tail short although another call's waves take compute-unit slots away (60k instead of 53k proofs/s at 256 blobs)
-    static const int kFillEnv = getenv("LWKZG_DIRECT_FILL") ? atoi(getenv("LWKZG_DIRECT_FILL")) : 0;
+    const int kFillEnv = knobs().direct_fill;
     const int kFill = kFillEnv ? kFillEnv : fill ? fill : 512;
     if ((int)n_blobs <= coop_max_blobs() && !fill) {
         // the cooperative kernel; `lane_scratch` takes the hand-off sums, the words behind the redo flags the hand-off counters
@@ -654,7 +637,7 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
         {
             ProfScope p("k_direct_fold_lanes", st);
             const int n_units = (int)n_blobs * blocks_per_blob;
-            static const bool fold_asm = !(getenv("LWKZG_FOLD_ASM") && atoi(getenv("LWKZG_FOLD_ASM")) == 0);
+            const bool fold_asm = knobs().fold_asm;
             if (fold_asm) {
                 if (n_units >= 1024 && !fill)   // a chip's worth of units and nobody beside us: one wave per SIMD
                     hipLaunchKernelGGL(k_direct_fold_lanes_asm_alone, dim3((unsigned)n_units), dim3(64), 0, st, (const uint32_t *)lane_scratch,

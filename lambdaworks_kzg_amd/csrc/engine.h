@@ -90,6 +90,7 @@ struct Workspace {
 // device-side scratch of one batch verification (points kept between its two GPU phases). The memory belongs to the
 // context (grow-only: hipMalloc / hipFree cost more than the kernels at small n); `hold` keeps other verifications
 // of the same settings object out until this one is done with it.
+constexpr size_t kVerifyApartMax = 8192;   // blobs: up to here the challenge hash leaves half the compute units free (64 blobs per workgroup)
 struct VerifyBuffers {
     G1Affine29 *pts_c = nullptr, *pts_p = nullptr;
     G1Affine29 *mult_c = nullptr, *mult_p = nullptr;  // [2^32]P, [2^64]P, [2^96]P of every point (3 n entries each)
@@ -101,6 +102,17 @@ struct VerifyBuffers {
     uint8_t *d_r = nullptr, *d_rz = nullptr, *d_aff = nullptr;
     G1Xyzz29 *d_part = nullptr;
     int32_t *d_inf = nullptr;
+    // r06, vmsm.hip: the rows [2^(8 j)]P / [2^(8 j)](-phi(P)) of both point sets (32 n each), the build's scratch, the split scalars,
+    // the slices' and the buckets' sums, the powers of r -- ONE allocation (vm_base) carved up -- and a pinned block on the host:
+    // the powers on their way up, the three affine sums and their infinity flags on their way down
+    uint8_t *vm_base = nullptr;
+    G1Affine29 *tab_p = nullptr, *tab_c = nullptr;
+    G1Xyzz29 *vm_tmp = nullptr, *vm_partial = nullptr, *vm_bsum = nullptr;
+    F29<2> *vm_pre = nullptr;
+    uint32_t *sc_a = nullptr, *sc_b = nullptr;
+    Fr *vm_pw = nullptr;
+    uint8_t *h_pin = nullptr;       // hipHostMalloc: 33 Fr | 3 x 96 bytes | 3 x int32
+    hipEvent_t vm_done = nullptr;   // recorded behind the results' copy (vmsm_begin), waited for by vmsm_finish
     // small batches validated on the host threads keep their points here instead (n commitments, then n proofs; kind 0 =
     // affine point, 1 = infinity) and the linear combinations run on the host threads too (verify.hip)
     std::vector<G1Affine29> h_aff;
@@ -282,6 +294,12 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
                                 uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, hipStream_t caller);
 C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n,
                                uint8_t sums[3][96], int infs[3]);
+// r06: the same three sums from r alone (vmsm.hip). pw33: r^(2^k), k = 0..31, then r^first, Montgomery form. vmsm_begin only
+// enqueues (scalars, buckets, sums, the copy of the results into pinned memory) and returns; vmsm_finish waits and hands over the
+// sums -- the host computes sum r^i y_i and [that]G in between. vmsm_ready: this verification has rows on the device.
+bool vmsm_ready(const VerifyBuffers &vb);
+C_KZG_RET vmsm_begin(Ctx *c, VerifyBuffers &vb, const Fr *pw33, int le, size_t n);
+C_KZG_RET vmsm_finish(Ctx *c, VerifyBuffers &vb, uint8_t sums[3][96], int infs[3]);
 
 // host-side decompress_g1_point + subgroup check + recompression (verify.hip): 0 = affine, 1 = infinity, 2 = invalid
 // (canon48 zeroed); for the few-points paths where a 2 ms validation kernel is the wrong tool

@@ -4,6 +4,7 @@
 // trusted setup owns: the affine SRS points, the 20-window fixed-base table, the NTT twiddles, a
 // stream, and a grow-only workspace sized for up to kMaxChunk blobs per launch set.
 #include "engine.h"
+#include "knobs.h"
 #include "hostfp.h"
 
 #include <stdarg.h>
@@ -30,7 +31,7 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
-    if (getenv("LWKZG_VERBOSE")) fprintf(stderr, "[lambdaworks_kzg_amd] %s\n", g_err);
+    if (knobs().verbose) fprintf(stderr, "[lambdaworks_kzg_amd] %s\n", g_err);
 }
 const char *get_error() { return g_err; }
 
@@ -249,12 +250,8 @@ static void sph_free(SmallProofHost &h) {
 // takes 3.6, at 64 both 2.25, at 16 this one 1.2 against 1.8; gpurun_out r05/gpu14); r04's table, when the default was 128 (default engine, same box, ms per call with / without: 1 blob 0.80 / 3.62, 16: 0.87 / 3.61, 64: 1.96 / 4.29,
 // 128: 3.41 / 5.05, 256: 6.43 / 6.68 -- beyond that the copy out and the host threads cost what the GPU chains did; gpurun_out r04c).
 static size_t small_proof_host_limit() {
-    static const size_t v = [] {
-        const char *e = getenv("LWKZG_SMALL_PROOF_HOST");
-        long x = e ? atol(e) : 64;
-        return (size_t)(x < 0 ? 0 : x > (long)kMaxChunk ? (long)kMaxChunk : x);
-    }();
-    return v;
+    const size_t x = knobs().small_proof_host;
+    return x > kMaxChunk ? kMaxChunk : x;
 }
 
 // at_reserve: called from lwkzg_reserve* (the place to pay for pinned memory). From inside a call (at_reserve = false) the staging
@@ -290,20 +287,12 @@ static bool sph_reserve(Ctx *c, size_t n, bool at_reserve = false) {
 // on its way -- and beside the GPU's commitment validation (which stays on the GPU: 2 ms whatever the batch, where the host would need
 // 0.2 ms per point per thread). 256 blobs: the challenges in ~1.6 ms instead of the hash kernel's flat 3.2.
 static size_t mid_proof_chunks() {   // experiment knob: host functions (= chunks) per mid-size call, 1 .. SmallProofHost::kChunks
-    static const size_t v = [] {
-        const char *e = getenv("LWKZG_MID_PROOF_CHUNKS");
-        long x = e ? atol(e) : 4;
-        return (size_t)(x < 1 ? 1 : x > SmallProofHost::kChunks ? SmallProofHost::kChunks : x);
-    }();
-    return v;
+    const size_t x = knobs().mid_proof_chunks;
+    return x < 1 ? 1 : x > (size_t)SmallProofHost::kChunks ? (size_t)SmallProofHost::kChunks : x;
 }
 static size_t mid_proof_host_limit() {
-    static const size_t v = [] {
-        const char *e = getenv("LWKZG_MID_PROOF_HOST");
-        long x = e ? atol(e) : 384;
-        return (size_t)(x < 0 ? 0 : x > (long)kMaxChunk ? (long)kMaxChunk : x);
-    }();
-    return v;
+    const size_t x = knobs().mid_proof_host;
+    return x > kMaxChunk ? kMaxChunk : x;
 }
 
 // Are the host threads warm? The mid-size host-assisted challenge (hashing on the host threads, pipelined with the copy out) beats
@@ -314,11 +303,7 @@ static size_t mid_proof_host_limit() {
 static std::atomic<int64_t> g_wake_requested_ns{0};
 static void host_warm_fn(void *);
 static bool host_assist_warm() {
-    static const int64_t window_ns = [] {
-        const char *e = getenv("LWKZG_HOST_WARM_MS");
-        const long ms = e ? atol(e) : 2000;
-        return (int64_t)(ms < 0 ? 0 : ms) * 1000000;
-    }();
+    const int64_t window_ns = (int64_t)(knobs().host_warm_ms < 0 ? 0 : knobs().host_warm_ms) * 1000000;
     const int64_t last = host_last_active_ns(), woken = g_wake_requested_ns.load(std::memory_order_acquire), now = host_now_ns();
     // (a wake-up that is on its way counts: the calls of a burst are enqueued within microseconds of each other, before the first one's
     // wake-up has run, and their host functions only run after the first call's GPU work -- milliseconds later, on threads that are awake)
@@ -579,8 +564,7 @@ static C_KZG_RET ctx_new(Ctx **out, const Ctx *twin_of = nullptr) {
 // a stream that used this context last stay here (stream order is all the synchronisation they need); a call on another
 // stream goes to the twin while this context's workspace is still busy, so that the two calls overlap on the GPU.
 static bool twin_off() {
-    static const bool off = getenv("LWKZG_TWIN") && atoi(getenv("LWKZG_TWIN")) == 0;
-    return off;
+    return !knobs().twin;
 }
 
 static Ctx *pick_ctx(Ctx *c, hipStream_t st) {
@@ -767,12 +751,8 @@ static void msm_stages(Ctx *c, const uint32_t *scalars_raw, uint8_t *out48, size
 // (224 bytes each) instead of the 48 compressed bytes and finish here. Same bytes: x = X / ZZ, y = Y / ZZZ, compress_g1_point
 // (/root/reference/src/compression.rs:33-60) through g1.cuh's g1_compress_affine.
 static size_t host_finish_limit() {
-    static const size_t v = [] {
-        const char *e = getenv("LWKZG_HOST_FINISH");
-        const long x = e ? atol(e) : 8;
-        return (size_t)(x < 0 ? 0 : x > (long)kCombineMaxBatch ? (long)kCombineMaxBatch : x);
-    }();
-    return v;
+    const size_t x = knobs().host_finish;
+    return x > kCombineMaxBatch ? kCombineMaxBatch : x;
 }
 
 // the integer of a hot-loop field value (14 limbs of 28 bits, value < 16p) reduced into [0, p)
@@ -837,8 +817,7 @@ static bool proof_on_lagrange(const Ctx *c, int mode) {
 // inversion per blob, no transform in front of the quotient and none behind it. LWKZG_CKZG_EVAL_PROOFS=0 is the A/B arm (the inverse
 // transform, Horner / Ruffini, and a forward transform where the Lagrange table is the only one).
 static bool proof_in_evaluation_form(const Ctx *c, int mode) {
-    static const bool on = !(getenv("LWKZG_CKZG_EVAL_PROOFS") && atoi(getenv("LWKZG_CKZG_EVAL_PROOFS")) == 0);
-    return on && mode == LWKZG_MODE_CKZG && c->lag.ready && (c->lag.direct_table || !c->direct_table);
+    return knobs().ckzg_eval_proofs && mode == LWKZG_MODE_CKZG && c->lag.ready && (c->lag.direct_table || !c->direct_table);
 }
 // quotient (and y = p(z)) of n blobs whose scalars coefficients_stage left at `in`, in the form that function chose; quot = nullptr: y only
 static void quotient_stage(Ctx *c, int mode, const uint32_t *in, const Fr *z, uint32_t *quot, uint8_t *y_out, int le, size_t n, hipStream_t st,
@@ -879,11 +858,7 @@ static bool coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode,
 // sub-batches per launch set. The bucket path gains from two (its sort / reduce / inversion tails hide behind the
 // other half's accumulation); the direct path has no such tails and runs as one launch.
 static int split_ways(bool direct) {
-    static const int v = [] {
-        const char *e = getenv("LWKZG_SPLIT");
-        int x = e ? atoi(e) : 0;
-        return x < 0 ? 0 : x > kMaxSplit ? kMaxSplit : x;
-    }();
+    const int v = knobs().split < 0 ? 0 : knobs().split > kMaxSplit ? kMaxSplit : knobs().split;
     return v ? v : (direct ? 1 : 2);
 }
 
@@ -1019,9 +994,9 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         // bytes, and once the validation's canonical bytes exist a blob whose bytes were NOT canonical (a valid point in an exotic
         // encoding: infinity with stray bits) gets its challenge, quotient and MSM again in a second pass that exits at its first
         // instruction for every other blob. 256 blobs: hash 2.1 ms -> MSM 2.3 ms in series becomes 1.05 -> 1.2 || 1.05 -> 1.2.
-        static const bool pipe_on = !(getenv("LWKZG_MID_PROOF_PIPE") && atoi(getenv("LWKZG_MID_PROOF_PIPE")) == 0);
+        const bool pipe_on = knobs().mid_proof_pipe;
         const size_t chunks = (n + ((n + mid_proof_chunks() - 1) / mid_proof_chunks()) - 1) / ((n + mid_proof_chunks() - 1) / mid_proof_chunks());
-        static const size_t pipe_min = getenv("LWKZG_MID_PROOF_PIPE_MIN") ? (size_t)atol(getenv("LWKZG_MID_PROOF_PIPE_MIN")) : 192;   // (128 blobs: 3.3 ms pipelined, 2.9 not)
+        const size_t pipe_min = knobs().mid_proof_pipe_min;   // (128 blobs: 3.3 ms pipelined, 2.9 not)
         const bool evf = proof_in_evaluation_form(c, mode);   // (then the quotient's MSM runs on the Lagrange form's table)
         const bool piped = pipe_on && (evf ? c->lag.direct_table != nullptr : c->direct_table && !proof_on_lagrange(c, mode)) && n >= pipe_min &&
                            chunks >= 2 && chunks % 2 == 0 && n <= kMaxChunk;
@@ -1044,7 +1019,7 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
             const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
             // sub-batches of whole chunks, alternating between the call's stream and a second one: a sub-batch's quotient and MSM start
             // when ITS chunks are hashed, and its latency-shaped folds run beside the next sub-batch's accumulation
-            static const size_t parts_env = getenv("LWKZG_MID_PROOF_PARTS") ? (size_t)atoi(getenv("LWKZG_MID_PROOF_PARTS")) : 0;
+            const size_t parts_env = knobs().mid_proof_parts;
             // (four measured best at 256 while the validation took 2 ms; with 1.1 ms of it two win there, 61.9k against 59.7k proofs/s; at 384 four: 66.0k against 63.7k)
             size_t parts = parts_env ? parts_env : (n >= 320 ? 4 : 2);
             while (parts > 1 && chunks % parts) parts--;
@@ -1095,7 +1070,7 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
     Ctx *pr = c->primary;
     // (up to half a chunk: there the MSM is about as long as the hash and the two pipelines would phase-lock; a longer
     // MSM covers the other call's hash by itself, and taking turns only adds bubbles -- 81k against 90k proofs/s at 1024)
-    static const int hs_env = getenv("LWKZG_HEAVY_SERIAL") ? atoi(getenv("LWKZG_HEAVY_SERIAL")) : -1;
+    const int hs_env = knobs().heavy_serial;
     const bool heavy_serial = hs_env >= 0 ? hs_env != 0 : n <= kMaxChunk / 2;
     if (heavy_serial) {
         std::lock_guard<std::mutex> hk(pr->heavy_mu);
@@ -1228,6 +1203,20 @@ void verify_buffers_free(VerifyBuffers &v) {
     dev_free(v.d_aff);
     dev_free(v.d_part);
     dev_free(v.d_inf);
+    dev_free(v.vm_base);
+    v.tab_p = v.tab_c = nullptr;
+    v.vm_tmp = v.vm_partial = v.vm_bsum = nullptr;
+    v.vm_pre = nullptr;
+    v.sc_a = v.sc_b = nullptr;
+    v.vm_pw = nullptr;
+    if (v.h_pin) {
+        (void)hipHostFree(v.h_pin);
+        v.h_pin = nullptr;
+    }
+    if (v.vm_done) {
+        (void)hipEventDestroy(v.vm_done);
+        v.vm_done = nullptr;
+    }
 }
 
 static void vs_free(Ctx *c) {
@@ -1250,6 +1239,29 @@ static C_KZG_RET verify_buffers_alloc(VerifyBuffers &v, size_t cap) {
               hipMalloc((void **)&v.d_rz, cap * 32) == hipSuccess &&
               hipMalloc((void **)&v.d_part, (3 * nblk + 3) * sizeof(G1Xyzz29)) == hipSuccess &&
               hipMalloc((void **)&v.d_aff, 3 * 96) == hipSuccess && hipMalloc((void **)&v.d_inf, 3 * 4) == hipSuccess;
+    // vmsm.hip's scratch: one allocation, 256-byte aligned pieces
+    if (ok) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t b_tab = up((size_t)kVmsmRows * cap * sizeof(G1Affine29)), b_tmp = up((size_t)kVmsmSteps * 2 * cap * sizeof(G1Xyzz29)),
+                     b_pre = up((size_t)kVmsmSteps * 2 * cap * sizeof(F29<2>)), b_sc = up(32 * cap),
+                     b_part = up(3 * vmsm_max_slices(cap) * 256 * sizeof(G1Xyzz29)), b_bsum = up(3 * 256 * sizeof(G1Xyzz29)),
+                     b_pw = up(33 * sizeof(Fr));
+        ok = hipMalloc((void **)&v.vm_base, 2 * b_tab + b_tmp + b_pre + 2 * b_sc + b_part + b_bsum + b_pw) == hipSuccess &&
+             hipHostMalloc((void **)&v.h_pin, kVmsmPinBytes, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&v.vm_done, hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            uint8_t *p = v.vm_base;
+            v.tab_p = (G1Affine29 *)p; p += b_tab;
+            v.tab_c = (G1Affine29 *)p; p += b_tab;
+            v.vm_tmp = (G1Xyzz29 *)p; p += b_tmp;
+            v.vm_pre = (F29<2> *)p; p += b_pre;
+            v.sc_a = (uint32_t *)p; p += b_sc;
+            v.sc_b = (uint32_t *)p; p += b_sc;
+            v.vm_partial = (G1Xyzz29 *)p; p += b_part;
+            v.vm_bsum = (G1Xyzz29 *)p; p += b_bsum;
+            v.vm_pw = (Fr *)p;
+        }
+    }
     if (!ok) {
         (void)hipGetLastError();
         verify_buffers_free(v);
@@ -1257,6 +1269,26 @@ static C_KZG_RET verify_buffers_alloc(VerifyBuffers &v, size_t cap) {
         return C_KZG_MALLOC;
     }
     return C_KZG_OK;
+}
+
+// a verification that runs on the context's scratch (under verify_mu) sees it through its own VerifyBuffers
+static void verify_buffers_lend(VerifyBuffers &vb, const VerifyBuffers &v) {
+    vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
+    vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
+    vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
+    vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all; vb.verdict_c = v.verdict_c; vb.verdict_p = v.verdict_p;
+    vb.vm_base = nullptr;   // (not this object's to free)
+    vb.tab_p = v.tab_p; vb.tab_c = v.tab_c; vb.vm_tmp = v.vm_tmp; vb.vm_pre = v.vm_pre; vb.sc_a = v.sc_a; vb.sc_b = v.sc_b;
+    vb.vm_partial = v.vm_partial; vb.vm_bsum = v.vm_bsum; vb.vm_pw = v.vm_pw; vb.h_pin = v.h_pin; vb.vm_done = v.vm_done;
+}
+
+// the rows of both point sets for the linear combinations, on `st` (needs the decompressed points, not the subgroup verdicts):
+// vmsm.hip's 32 byte-spaced rows per point, or (LWKZG_VERIFY_MSM=0) r05's three 32-bit-spaced multiples
+static void launch_verify_rows(VerifyBuffers &vb, size_t n, hipStream_t st, bool apart) {
+    if (knobs().verify_msm)
+        launch_vmsm_multiples2(vb.pts_p, vb.kind_p, vb.tab_p, vb.pts_c, vb.kind_c, vb.tab_c, vb.vm_tmp, vb.vm_pre, n, st, apart);
+    else
+        launch_point_multiples2(vb.pts_p, vb.kind_p, vb.mult_p, vb.pts_c, vb.kind_c, vb.mult_c, n, st);
 }
 
 // grow-only verify scratch for n blobs; the caller holds verify_mu
@@ -1296,10 +1328,11 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
     LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
     LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, n * 48, hipMemcpyHostToDevice, sv));
     launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p, vb.verdict_p);
-    launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);  // for the linear combinations; needs no scalar
-    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c, vb.verdict_c);
-    launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, st);
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 2], st));
+    LWK_HIP(hipStreamWaitEvent(sv, c->ev_join[kMaxSplit - 2], 0));
+    launch_verify_rows(vb, n, sv, false);  // for the linear combinations; needs the points of both sets and no scalar
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));
     // the canonical bytes come back the first time the host needs them: a device-to-host copy into pageable memory
     // blocks this thread until the stream has reached it, and the first slices should be on their way by then
@@ -1361,6 +1394,7 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         quotient_stage(c, mode, w.scalars + base * (size_t)kBlobElems * 8, d_z, nullptr /* y only */, d_yb, le, m,
                              sk);
         launch_fr_mont_to_bytes(d_z, d_zb, le, m, sk);
+        LWK_HIP(hipMemcpyAsync(vb.d_rz + 32 * off, d_zb, m * 32, hipMemcpyDeviceToDevice, sk));  // for k_vmsm_scalars
         LWK_HIP(hipMemcpyAsync(z32 + 32 * off, d_zb, m * 32, hipMemcpyDeviceToHost, sk));
         LWK_HIP(hipMemcpyAsync(y32 + 32 * off, d_yb, m * 32, hipMemcpyDeviceToHost, sk));
         return first_status(c, w.status + base, m, sk);
@@ -1428,11 +1462,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
     } else {
         C_KZG_RET rcv = vs_reserve(c, n);
         if (rcv != C_KZG_OK) return rcv;
-        const VerifyBuffers &v = c->vs;
-        vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
-        vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
-        vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
-        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all; vb.verdict_c = v.verdict_c; vb.verdict_p = v.verdict_p;
+        verify_buffers_lend(vb, c->vs);
     }
     if (n > kMaxChunk && proofs48 && !trusted_canon_c)  // up to one chunk the single pass below is ~1 ms shorter
         return verify_prepare_long(c, blobs, comm48, proofs48, n, mode, z32, y32, canon_c, canon_p, vb);
@@ -1477,7 +1507,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             LWK_HIP(hipEventRecord(c->ev_join[1], sc));
             LWK_HIP(hipStreamWaitEvent(sm, c->ev_join[4], 0));
             LWK_HIP(hipStreamWaitEvent(sm, c->ev_join[5], 0));
-            launch_point_multiples2(vb.pts_p, vb.kind_p, vb.mult_p, vb.pts_c, vb.kind_c, vb.mult_c, m, sm);
+            launch_verify_rows(vb, m, sm, false);
             LWK_HIP(hipEventRecord(c->ev_join[2], sm));
         }
         LWK_HIP(hipMemcpyAsync(w.blobs, hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, st));
@@ -1529,6 +1559,8 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         }
         quotient_stage(c, mode, w.scalars, w.z, nullptr /* a verification wants y = p(z) only */, w.ybytes, le, m, st);
         launch_fr_mont_to_bytes(w.z, w.zbytes, le, m, st);
+        if (proofs48 && !host_validate)  // k_vmsm_scalars reads the z bytes where the device-resident form leaves them
+            LWK_HIP(hipMemcpyAsync(vb.d_rz + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToDevice, st));
         LWK_HIP(hipMemcpyAsync(z32 + 32 * off, w.zbytes, m * 32, hipMemcpyDeviceToHost, st));
         LWK_HIP(hipMemcpyAsync(y32 + 32 * off, w.ybytes, m * 32, hipMemcpyDeviceToHost, st));
         rc = first_status(c, w.status, m, st);
@@ -1576,11 +1608,7 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     } else {
         C_KZG_RET rcv = vs_reserve(c, n);
         if (rcv != C_KZG_OK) return rcv;
-        const VerifyBuffers &v = c->vs;
-        vb.mult_c = v.mult_c; vb.mult_p = v.mult_p;
-        vb.pts_c = v.pts_c; vb.pts_p = v.pts_p; vb.kind_c = v.kind_c; vb.kind_p = v.kind_p; vb.proof_in = v.proof_in;
-        vb.d_r = v.d_r; vb.d_rz = v.d_rz; vb.d_aff = v.d_aff; vb.d_part = v.d_part; vb.d_inf = v.d_inf;
-        vb.comm_in = v.comm_in; vb.canon_dev = v.canon_dev; vb.status_all = v.status_all; vb.verdict_c = v.verdict_c; vb.verdict_p = v.verdict_p;
+        verify_buffers_lend(vb, c->vs);
     }
     C_KZG_RET rc = ctx_reserve(c, n < kMaxChunk ? n : kMaxChunk);
     if (rc != C_KZG_OK) return rc;
@@ -1591,13 +1619,32 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     LWK_HIP(hipEventRecord(c->ev_fork, st));
     LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
     LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
-    launch_validate_commitments(d_proofs, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p, vb.verdict_p);
-    launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);
-    LWK_HIP(hipEventRecord(c->ev_join[0], sv));
-    launch_validate_commitments(d_comm, vb.canon_dev, vb.status_all, bad, n, sc, vb.pts_c, vb.kind_c, vb.verdict_c);
-    launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, sc);
-    LWK_HIP(hipEventRecord(c->ev_join[1], sc));
-    launch_challenge(d_blobs, d_comm, z, le, n, st);
+    // Beside the hash (64 blobs per workgroup, one workgroup per compute unit: 3.2 ms whatever n is) the validation and the rows of the
+    // linear combinations are latency chains of a few hundred waves, and r05 lost 2 ms to where the dispatcher put them: on the hash's
+    // own compute units, four of its waves per SIMD-quad at a raised priority (k_decompress_points 0.43 -> 1.3 ms, k_subgroup_coop_asm
+    // 0.67 -> 1.8 ms; profiles/r06_verify_b4096_device_timeline_r05_code.txt). `apart`: every such launch carries an LDS footprint that
+    // cannot share a compute unit with a hash workgroup (or with each other), as long as the hash leaves half the chip free.
+    const bool apart = n <= kVerifyApartMax;
+    const bool fused = knobs().verify_fused || knobs().verify_msm;
+    if (knobs().verify_order) launch_challenge(d_blobs, d_comm, z, le, n, st);   // experiment: the hash submitted first
+    if (fused) {   // r06: ONE launch per kernel over both point sets; the rows start as soon as the points are decompressed
+        launch_decompress_points2(d_proofs, vb.pts_p, vb.kind_p, d_comm, vb.pts_c, vb.kind_c, n, sv, apart);
+        LWK_HIP(hipEventRecord(c->ev_join[2], sv));
+        launch_subgroup_canon2(vb.pts_p, vb.kind_p, vb.canon_dev + 48 * n, vb.verdict_p, vb.pts_c, vb.kind_c, vb.canon_dev, vb.verdict_c,
+                               vb.status_all, bad, n, sv, apart);
+        LWK_HIP(hipEventRecord(c->ev_join[0], sv));
+        LWK_HIP(hipStreamWaitEvent(sc, c->ev_join[2], 0));
+        launch_verify_rows(vb, n, sc, apart);
+        LWK_HIP(hipEventRecord(c->ev_join[1], sc));
+    } else {       // r05's arrangement (LWKZG_VERIFY_FUSED=0 with LWKZG_VERIFY_MSM=0): a side stream per point set
+        launch_validate_commitments(d_proofs, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p, vb.verdict_p);
+        launch_point_multiples(vb.pts_p, vb.kind_p, vb.mult_p, n, sv);
+        LWK_HIP(hipEventRecord(c->ev_join[0], sv));
+        launch_validate_commitments(d_comm, vb.canon_dev, vb.status_all, bad, n, sc, vb.pts_c, vb.kind_c, vb.verdict_c);
+        launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, sc);
+        LWK_HIP(hipEventRecord(c->ev_join[1], sc));
+    }
+    if (!knobs().verify_order) launch_challenge(d_blobs, d_comm, z, le, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
     drain.armed = false;  // both side streams are joined into the main stream from here on
@@ -1664,6 +1711,45 @@ C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, c
     return C_KZG_OK;
 }
 
+bool vmsm_ready(const VerifyBuffers &vb) { return knobs().verify_msm && vb.tab_p && vb.h_pin && vb.vm_done; }
+
+// The three sums from r alone (vmsm.hip): everything is enqueued on the context's stream and the results travel to the pinned block by
+// themselves; the caller (verify.hip: shard_partial) computes its host share meanwhile and collects with vmsm_finish.
+C_KZG_RET vmsm_begin(Ctx *c, VerifyBuffers &vb, const Fr *pw33, int le, size_t n) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    LWK_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (!(vb.hold.owns_lock() || vb.owned) || !vmsm_ready(vb) || !vb.d_rz) {
+        set_error("vmsm_begin: called without a prepared verification");
+        return C_KZG_ERROR;
+    }
+    memcpy(vb.h_pin, pw33, 33 * sizeof(Fr));
+    LWK_HIP(hipMemcpyAsync(vb.vm_pw, vb.h_pin, 33 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    launch_vmsm_scalars(vb.d_rz, le, vb.vm_pw, vb.sc_a, vb.sc_b, n, st);
+    launch_vmsm_accumulate(vb.sc_a, vb.sc_b, vb.tab_p, vb.kind_p, vb.tab_c, vb.kind_c, vb.vm_partial, n, st);
+    launch_vmsm_reduce(vb.vm_partial, vb.vm_bsum, vb.d_aff, vb.d_inf, n, st);
+    LWK_HIP(hipMemcpyAsync(vb.h_pin + 33 * sizeof(Fr), vb.d_aff, 3 * 96, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(vb.h_pin + 33 * sizeof(Fr) + 3 * 96, vb.d_inf, 3 * 4, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipEventRecord(vb.vm_done, st));
+    return C_KZG_OK;
+}
+
+C_KZG_RET vmsm_finish(Ctx *c, VerifyBuffers &vb, uint8_t sums[3][96], int infs[3]) {
+    LWK_HIP(hipSetDevice(c->device));
+    if (hipEventSynchronize(vb.vm_done) != hipSuccess) {
+        set_error("vmsm_finish: device work failed: %s", hipGetErrorString(hipGetLastError()));
+        return C_KZG_ERROR;
+    }
+    const uint8_t *res = vb.h_pin + 33 * sizeof(Fr);
+    for (int k = 0; k < 3; k++) {
+        memcpy(sums[k], res + 96 * k, 96);
+        int32_t f;
+        memcpy(&f, res + 3 * 96 + 4 * k, 4);
+        infs[k] = f;
+    }
+    return C_KZG_OK;
+}
+
 }  // namespace lwk
 
 // =================================================================================================
@@ -1679,9 +1765,7 @@ static std::atomic<int> g_mode{-1};
 static int mode_now() {
     int m = g_mode.load(std::memory_order_relaxed);
     if (m < 0) {
-        const char *e = getenv("LWKZG_MODE");
-        m = (e && (!strcmp(e, "ckzg") || !strcmp(e, "c") || !strcmp(e, "C") || !strcmp(e, "1"))) ? LWKZG_MODE_CKZG
-                                                                                                 : LWKZG_MODE_REFERENCE;
+        m = knobs().mode ? LWKZG_MODE_CKZG : LWKZG_MODE_REFERENCE;   // LWKZG_MODE
         int expect = -1;
         if (!g_mode.compare_exchange_strong(expect, m)) m = expect;
     }
@@ -2111,7 +2195,7 @@ static C_KZG_RET map_rc(C_KZG_RET rc, int mode) {
 // on a direct table 11.9 instead of 12.8 ms, 85.7k instead of 80.2k ops/s through the host ABI). On the bucket engine a
 // batch of a whole chunk or more keeps whole slices: its small launches cost what the earlier start gains.
 static size_t slice_len(size_t k, size_t remaining, size_t n, bool direct) {
-    static const size_t first_env = getenv("LWKZG_SLICE0") ? (size_t)atoi(getenv("LWKZG_SLICE0")) : 0;  // experiment: length of the first slice
+    const size_t first_env = knobs().slice0;  // experiment: length of the first slice
     const size_t first = first_env ? first_env : kMaxChunk / 8;
     size_t want = kMaxChunk / 2;
     if ((n < kMaxChunk || direct || first_env) && k < 2 && first < kMaxChunk / 2) want = k == 0 ? first : kMaxChunk / 2 - first;
@@ -2124,8 +2208,7 @@ static size_t slice_len(size_t k, size_t remaining, size_t n, bool direct) {
 
 // LWKZG_COALESCE=0: single-blob calls are not merged with concurrent ones
 static bool coalesce_singles() {
-    static const bool on = !(getenv("LWKZG_COALESCE") && atoi(getenv("LWKZG_COALESCE")) == 0);
-    return on;
+    return knobs().coalesce;
 }
 
 static bool combiner_init(Ctx *c) {
@@ -2430,7 +2513,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
         set_error("lwkzg_compute_blob_kzg_proof_batch: out of device memory for %zu results", n);
         return C_KZG_MALLOC;
     }
-    static const bool timing = getenv("LWKZG_TIMING") != nullptr;  // phase wall-clock to stderr
+    const bool timing = knobs().timing;  // phase wall-clock to stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -2912,7 +2995,7 @@ static hipError_t form_build(Ctx *c, bool lagrange, int bits, size_t row_pref, i
         bt.table_bytes += direct_table_entries(bits) * row;
         return hipSuccess;
     };
-    static const int forced_env = getenv("LWKZG_DIRECT_ROW") ? atoi(getenv("LWKZG_DIRECT_ROW")) : 0;
+    const int forced_env = knobs().direct_row;
     const int forced = forced_env ? forced_env : (int)row_pref;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
@@ -2986,7 +3069,7 @@ static void tables_follow_mode(Ctx *c, int mode, bool may_swap) {
     // The two forms' tables have the SAME geometry (width, windows, row size): the other form's allocations move over as they are and
     // the build kernels run again over them -- no hipFree / hipMalloc of 275 GB, no wait for the driver's scrub (7-8.5 s ->
     // the kernels' half second). LWKZG_SET_MODE_IN_PLACE=0: free and allocate, the A/B arm.
-    static const bool in_place_on = !(getenv("LWKZG_SET_MODE_IN_PLACE") && atoi(getenv("LWKZG_SET_MODE_IN_PLACE")) == 0);
+    const bool in_place_on = knobs().set_mode_in_place;
     FormRef other = form_ref(c, !want_lag);
     if (in_place_on && other.bits == bits && other.table0) {
         auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -3362,14 +3445,13 @@ namespace lwk {
 //   LWKZG_DIRECT_BITS=10..16: that width, or the bucket engine when it does not fit
 //   LWKZG_DIRECT_BITS=auto  : the widest of 16 .. 10 that fits at all (what bench.py's headline asks for explicitly)
 void direct_from_env(const KZGSettings *s) {
-    const char *v = getenv("LWKZG_DIRECT_BITS");
-    if (v && *v) {
-        if (!strcmp(v, "auto")) {
+    if (knobs().has_direct_bits) {
+        if (knobs().direct_bits < 0) {   // "auto"
             for (int bits = kDirectMaxBits; bits >= kDirectMinBits; bits--)
                 if (lwkzg_enable_direct_table(s, bits) == C_KZG_OK) return;
             return;
         }
-        if (atoi(v) != 0) (void)lwkzg_enable_direct_table(s, atoi(v));
+        if (knobs().direct_bits != 0) (void)lwkzg_enable_direct_table(s, knobs().direct_bits);
         return;
     }
     size_t free_b = 0, total_b = 0;

@@ -132,8 +132,11 @@ void launch_z_from_bytes(const uint8_t *z_bytes, Fr *z_mont, int32_t *status, in
 // (compute_challenge, /root/reference/src/utils.rs:120-154).
 // verdict_scratch (n words, with aff_out and kind_out): the validation runs as three launches with the subgroup test on a quad of
 // lanes per point (k_subgroup_coop_asm) instead of one lane per point for the whole chain
+// apart (r06): the launches carry an LDS footprint they never touch, sized so that the dispatcher cannot place their workgroups on the
+// compute units of a challenge-hash kernel running beside them (knobs.h: verify_pad_kb; profiles/r06_experiments.md section 1)
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                                 hipStream_t st, G1Affine29 *aff_out = nullptr, int32_t *kind_out = nullptr, uint32_t *verdict_scratch = nullptr);
+                                 hipStream_t st, G1Affine29 *aff_out = nullptr, int32_t *kind_out = nullptr, uint32_t *verdict_scratch = nullptr,
+                                 bool apart = false);
 // verify side: three variable-base linear combinations in one launch (setup.hip).
 //   set 0 = sum r_i P_i, set 1 = sum rz_i P_i (P = proofs), set 2 = sum r_i C_i (C = commitments);
 // per-block partial sums to partial[set * nblk + block]
@@ -144,12 +147,37 @@ void launch_point_multiples(const G1Affine29 *pts, const int32_t *kind, G1Affine
 void launch_point_multiples2(const G1Affine29 *pts_a, const int32_t *kind_a, G1Affine29 *mult_a, const G1Affine29 *pts_b,
                              const int32_t *kind_b, G1Affine29 *mult_b, size_t n, hipStream_t st);  // two sets, one launch
 // launch_validate_commitments in two launches (sha256.hip): the multiples above can start after the first
-void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st);
+void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st, bool apart = false);
 void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                           hipStream_t st, uint32_t *verdict_scratch = nullptr);
+                           hipStream_t st, uint32_t *verdict_scratch = nullptr, bool apart = false);
+// the same two steps for both point sets of a verification at once (one launch per kernel: r06)
+void launch_decompress_points2(const uint8_t *in48_a, G1Affine29 *pts_a, int32_t *kind_a, const uint8_t *in48_b, G1Affine29 *pts_b,
+                               int32_t *kind_b, size_t n, hipStream_t st, bool apart = false);
+void launch_subgroup_canon2(G1Affine29 *pts_a, int32_t *kind_a, uint8_t *canon48_a, uint32_t *verdict_a, G1Affine29 *pts_b, int32_t *kind_b,
+                            uint8_t *canon48_b, uint32_t *verdict_b, int32_t *status, int bad_code, size_t n, hipStream_t st, bool apart = false);
 void launch_lincomb3(const G1Affine29 *proofs, const int32_t *proof_kind, const G1Affine29 *proof_mult, const G1Affine29 *comms,
                      const int32_t *comm_kind, const G1Affine29 *comm_mult, const uint8_t *sc_r_be, const uint8_t *sc_rz_be,
                      G1Xyzz29 *partial, size_t n, hipStream_t st);
+// ---- the verification's linear combinations as one latency-shaped bucket MSM (vmsm.hip, r06) ----------------------------------
+constexpr int kVmsmDigits = 16;                  // byte digits of a 128-bit half scalar
+constexpr int kVmsmRows = 2 * kVmsmDigits;       // rows per point: [2^(8 j)]P and [2^(8 j)](-phi(P)), j = 0..15
+constexpr int kVmsmSteps = kVmsmDigits - 1;      // rows per half beyond the point itself
+constexpr int kVmsmMaxTerms = 64;                // terms per slice (one workgroup of k_vmsm_accumulate), at most
+constexpr size_t kVmsmPinBytes = 33 * 32 + 3 * 96 + 3 * 4 + 52;  // the pinned host block of a verification: powers up, sums down
+constexpr int kVmsmListCap = 24;                 // rows of one digit value a slice lists before its lane falls back to a scan
+// rows of two point sets in one launch, beside the challenge hash: tab_*[row * n + i]; tmp: 15 x 2n XYZZ, pre: 15 x 2n field elements
+void launch_vmsm_multiples2(const G1Affine29 *pts_a, const int32_t *kind_a, G1Affine29 *tab_a, const G1Affine29 *pts_b,
+                            const int32_t *kind_b, G1Affine29 *tab_b, G1Xyzz29 *tmp, F29<2> *pre, size_t n, hipStream_t st, bool apart = false);
+// pw: 33 Fr in Montgomery form, r^(2^k) for k = 0..31 and r^first; sc_a / sc_b: 8 words per term (lo | hi of a_i = r^(first+i), b_i = a_i z_i)
+void launch_vmsm_scalars(const uint8_t *z_bytes, int le, const Fr *pw, uint32_t *sc_a, uint32_t *sc_b, size_t n, hipStream_t st);
+uint32_t vmsm_terms_per_slice(size_t n);
+size_t vmsm_slices(size_t n);
+size_t vmsm_max_slices(size_t cap);
+// partial: 3 x vmsm_slices(n) x 256 XYZZ; list_cap <= kVmsmListCap (smaller only to force the overflow path in tests)
+void launch_vmsm_accumulate(const uint32_t *sc_a, const uint32_t *sc_b, const G1Affine29 *tab_p, const int32_t *kind_p,
+                            const G1Affine29 *tab_c, const int32_t *kind_c, G1Xyzz29 *partial, size_t n, hipStream_t st);
+// bsum: 3 x 256 XYZZ; out96 / inf: the three sums, affine big-endian x | y and an infinity flag each (what launch_xyzz29_to_affine_be leaves)
+void launch_vmsm_reduce(const G1Xyzz29 *partial, G1Xyzz29 *bsum, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from = nullptr);

@@ -17,6 +17,7 @@
 // of algorithmic traffic), so the kernels are organised around VGPR residency and wave balance,
 // not around HBM bandwidth; DESIGN.md has the arithmetic.
 #include "kernels.h"
+#include "knobs.h"
 
 #include <stdlib.h>
 
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kSortThreads) void k_digit_sort(const uint4 *__rest
 void launch_digit_sort(const uint32_t *scalars_raw, uint32_t *sorted, uint32_t *bucket_start, uint32_t *perm,
                        size_t n_blobs, hipStream_t st) {
     ProfScope p("k_digit_sort", st);
-    static const int staged = !(getenv("LWKZG_SORT_STAGE") && atoi(getenv("LWKZG_SORT_STAGE")) == 0);
+    const bool staged = knobs().sort_stage;
     if (staged)
         hipLaunchKernelGGL(k_digit_sort<true>, dim3((unsigned)n_blobs), dim3(kSortThreads), 0, st, (const uint4 *)scalars_raw, sorted, bucket_start, perm);
     else
@@ -415,8 +416,7 @@ __global__ __launch_bounds__(kAccThreads) void k_bucket_accumulate_asm(const G1A
 }
 
 static bool bucket_asm_enabled() {
-    static const bool on = !(getenv("LWKZG_BUCKET_ASM") && atoi(getenv("LWKZG_BUCKET_ASM")) == 0);
-    return on;
+    return knobs().bucket_asm;
 }
 
 void launch_bucket_accumulate(const G1Affine29 *table, const uint32_t *sorted, const uint32_t *bucket_start,
@@ -487,8 +487,7 @@ __global__ __launch_bounds__(kRedThreads) void k_bucket_reduce(const G1Xyzz29 *_
 }
 
 static int reduce_lanes_override() {
-    static const int v = getenv("LWKZG_REDUCE_LANES") ? atoi(getenv("LWKZG_REDUCE_LANES")) : 0;
-    return v;
+    return knobs().reduce_lanes;
 }
 
 void launch_bucket_reduce(const G1Xyzz29 *buckets, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st) {

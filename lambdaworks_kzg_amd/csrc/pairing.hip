@@ -12,6 +12,7 @@
 // Only the accept/reject bit leaves this file, so no intermediate representation needs to match
 // anything upstream.
 #include "engine.h"
+#include "knobs.h"
 #include "fp2.h"
 #include "hostfp.h"
 
@@ -298,7 +299,7 @@ H12 cyclotomic_sqr(const H12 &a) {
 // a^x for the (negative) curve parameter x = -0xd201000000010000, a in the cyclotomic subgroup
 // (where the inverse is the conjugate). LWKZG_PAIRING_GENERIC_SQR=1 squares with the generic product (cross-check).
 H12 exp_by_x(const H12 &a) {
-    static const int generic = getenv("LWKZG_PAIRING_GENERIC_SQR") ? 1 : 0;
+    const int generic = knobs().pairing_generic_sqr ? 1 : 0;
     H12 acc = a;  // bit 63
     for (int i = 62; i >= 0; i--) {
         acc = generic ? acc * acc : cyclotomic_sqr(acc);
@@ -315,7 +316,7 @@ H12 exp_by_x(const H12 &a) {
 bool final_exponentiation_is_one(const H12 &f) {
     H12 t = f12conj(f) * f12inv(f);  // f^(p^6 - 1)
     t = frob_p2(t) * t;               // ^(p^2 + 1)
-    static const int naive = getenv("LWKZG_PAIRING_NAIVE") ? 1 : 0;
+    const int naive = knobs().pairing_naive ? 1 : 0;
     if (naive) {
         auto m12 = [](const H12 &a, const H12 &b) { return a * b; };
         return f12is_one(pow_big<H12>(t, f12one(), g_c.hard, g_c.hard_n, m12));
@@ -404,7 +405,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
         py[i] = HFp::from_fe(ps[i].y);
     }
     H12 f = f12one();
-    static const int on_the_fly = getenv("LWKZG_PAIRING_NO_PRECOMP") ? 1 : 0;  // =1: the loop below that walks T itself (cross-check)
+    const int on_the_fly = knobs().pairing_no_precomp ? 1 : 0;  // =1: the loop below that walks T itself (cross-check)
     if (!on_the_fly) {
         const auto t0 = std::chrono::steady_clock::now();
         std::shared_ptr<const FixedQ> fq[4];
@@ -427,7 +428,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
             }
             return g;
         };
-        static const bool two_threads = host_threads() >= 2 && !getenv("LWKZG_PAIRING_ONE_THREAD");
+        static const bool two_threads = host_threads() >= 2 && !knobs().pairing_one_thread;
         if (n == 2 && two_threads) {
             // the two pairings of a verification on two threads: each pays its own squarings (36 of the 74 field products
             // of a step), but the loop takes 0.26 ms instead of 0.40 ms
@@ -439,7 +440,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
         } else {
             f = miller(0, n);
         }
-        static const bool timing = getenv("LWKZG_TIMING") != nullptr;
+        const bool timing = knobs().timing;
         if (!timing) return final_exponentiation_is_one(f12conj(f));  // z < 0
         const auto t1 = std::chrono::steady_clock::now();
         const bool verdict = final_exponentiation_is_one(f12conj(f));

@@ -7,6 +7,8 @@
 // kzgsettings_to_structured_reference_string (/root/reference/src/srs.rs:258-280): the device
 // table is built once and cached in the settings' context.
 #include "kernels.h"
+#include "knobs.h"
+#include "glv.cuh"
 
 namespace lwk {
 
@@ -120,37 +122,6 @@ constexpr int kLincombLanes = 2 * kLincombPieces;               // lanes per ter
 constexpr int kLincombTerms = kLincombThreads / kLincombLanes;  // 32 terms per workgroup
 constexpr int kPieceBits = 128 / kLincombPieces;
 
-// k = lo + hi * z^2 with z^2 = 0xac45a4010001a4020000000100000000 (the curve parameter squared, 128 bits);
-// k < r = z^4 - z^2 + 1, so both halves fit 128 bits. Bitwise restoring division, once per lane.
-__device__ __forceinline__ void split_by_z2(uint32_t lo[4], uint32_t hi[4], const uint32_t k[8]) {
-    const uint32_t d[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};
-    uint32_t rem[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 4; i++) hi[i] = 0;
-    for (int bit = 255; bit >= 0; bit--) {
-        const uint32_t top = rem[3] >> 31;
-        rem[3] = (rem[3] << 1) | (rem[2] >> 31);
-        rem[2] = (rem[2] << 1) | (rem[1] >> 31);
-        rem[1] = (rem[1] << 1) | (rem[0] >> 31);
-        rem[0] = (rem[0] << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
-        uint32_t t[4];
-        uint64_t br = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint64_t v = (uint64_t)rem[i] - d[i] - br;
-            t[i] = (uint32_t)v;
-            br = (v >> 32) & 1u;
-        }
-        if (top || !br) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) rem[i] = t[i];
-            if (bit < 128) hi[bit >> 5] |= 1u << (bit & 31);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) lo[i] = rem[i];
-}
-
 // mult[(j - 1) n + i] = [2^(32 j)] pts[i], j = 1 .. 3, affine, for the points the validation kernel accepted. Needs the
 // points only, not the scalars: it runs right behind the validation, beside the per-blob pass, and lets k_lincomb3 cut
 // every scalar into 32-bit pieces on lanes of their own (a lone wave needs ~8-10 us per group operation however idle
@@ -183,16 +154,18 @@ __global__ __launch_bounds__(64) void k_point_multiples(const G1Affine29 *__rest
     mult[gid] = xyzz29_to_affine29(*(G1Xyzz29 *)&acc);
 }
 
+unsigned verify_pad_bytes(int which, const void *kernel);  // sha256.hip
+
 void launch_point_multiples(const G1Affine29 *pts, const int32_t *kind, G1Affine29 *mult, size_t n, hipStream_t st) {
     ProfScope p("k_point_multiples", st);
-    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64)), dim3(64), 0, st, pts, kind, mult,
+    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64)), dim3(64), verify_pad_bytes(2, (const void *)k_point_multiples), st, pts, kind, mult,
                        pts, kind, mult, n);
 }
 
 void launch_point_multiples2(const G1Affine29 *pts_a, const int32_t *kind_a, G1Affine29 *mult_a, const G1Affine29 *pts_b,
                              const int32_t *kind_b, G1Affine29 *mult_b, size_t n, hipStream_t st) {
     ProfScope p("k_point_multiples", st);
-    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64), 2), dim3(64), 0, st, pts_a, kind_a,
+    hipLaunchKernelGGL(k_point_multiples, dim3((unsigned)(((kLincombPieces - 1) * n + 63) / 64), 2), dim3(64), verify_pad_bytes(2, (const void *)k_point_multiples), st, pts_a, kind_a,
                        mult_a, pts_b, kind_b, mult_b, n);
 }
 

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include "kernels.h"
+#include "knobs.h"
 
 namespace lwk {
 
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(256) void k_challenge_pairs(const uint8_t *__restri
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from) {
     if (n == 0) return;
-    static const bool pairs = !(getenv("LWKZG_HASH_PAIRS") && atoi(getenv("LWKZG_HASH_PAIRS")) == 0);
-    static const int prio = getenv("LWKZG_HASH_PRIO") ? atoi(getenv("LWKZG_HASH_PRIO")) : 1;
+    const bool pairs = knobs().hash_pairs;
+    const int prio = knobs().hash_prio;
     ProfScope p(only_if_differs_from ? "k_challenge_fixup" : "k_challenge", st);
     if (pairs)
         hipLaunchKernelGGL(k_challenge_pairs<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, canon48, z_mont, le, n,
@@ -379,7 +380,7 @@ void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, 
 // part 1: everything the commitment does not touch (2048 of the 2050 blocks), beside the commitment MSM
 void launch_challenge_midstate(const uint8_t *blobs, uint32_t *midstate, size_t n, hipStream_t st) {
     if (n == 0) return;
-    static const int prio = getenv("LWKZG_HASH_PRIO") ? atoi(getenv("LWKZG_HASH_PRIO")) : 1;
+    const int prio = knobs().hash_prio;
     ProfScope p("k_challenge_midstate", st);
     hipLaunchKernelGGL(k_challenge_pairs<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, blobs, (const uint8_t *)nullptr,
                        (Fr *)nullptr, 0, n, (const uint8_t *)nullptr, prio, midstate);
@@ -539,21 +540,17 @@ __global__ __launch_bounds__(64) void k_validate_commitments(const uint8_t *__re
 }
 
 static bool validate_coop_enabled() {
-    static const bool on = !(getenv("LWKZG_VALIDATE_COOP") && atoi(getenv("LWKZG_VALIDATE_COOP")) == 0);
-    return on;
+    return knobs().validate_coop;
 }
 
-void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st);
-void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n, hipStream_t st,
-                           uint32_t *verdict_scratch);
 
 void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                                 hipStream_t st, G1Affine29 *aff_out, int32_t *kind_out, uint32_t *verdict_scratch) {
+                                 hipStream_t st, G1Affine29 *aff_out, int32_t *kind_out, uint32_t *verdict_scratch, bool apart) {
     // r05: with scratch for the points and the verdicts the validation is three launches -- the square root (one lane per point, windowed),
     // the subgroup test on a quad of lanes per point (k_subgroup_coop_asm), canonical bytes + verdicts -- 2.0 -> ~1.0 ms whatever the batch
     if (aff_out && kind_out && verdict_scratch && n && validate_coop_enabled()) {
-        launch_decompress_points(comm48, aff_out, kind_out, n, st);
-        launch_subgroup_canon(aff_out, kind_out, canon48, status, bad_code, n, st, verdict_scratch);
+        launch_decompress_points(comm48, aff_out, kind_out, n, st, apart);
+        launch_subgroup_canon(aff_out, kind_out, canon48, status, bad_code, n, st, verdict_scratch, apart);
         return;
     }
     ProfScope p("k_validate_commitments", st);
@@ -563,7 +560,7 @@ void launch_validate_commitments(const uint8_t *comm48, uint8_t *canon48, int32_
     // footprint the kernel never touches keeps them apart: 112 KB here + the hash kernel's 48 KB (or a second
     // validation workgroup) exceed the 160 KB of a compute unit, so the dispatcher has to pick another one. The hash
     // of 1024 blobs takes 3.2 ms instead of 4.3 ms beside it (LWKZG_VALIDATE_LDS_PAD=0 switches the padding off).
-    static const unsigned lds_pad = getenv("LWKZG_VALIDATE_LDS_PAD") ? (unsigned)atoi(getenv("LWKZG_VALIDATE_LDS_PAD")) : 112u * 1024u;
+    const unsigned lds_pad = knobs().validate_lds_pad;
     static std::atomic<bool> pad_ok{true};  // a runtime that refuses the footprint gets the plain launch from then on
     if (lds_pad && pad_ok.load(std::memory_order_relaxed)) {
         (void)hipGetLastError();
@@ -631,9 +628,14 @@ __device__ __forceinline__ F29<2> sqrt_chain_lds(const F29<2> &a, const uint32_t
     return r;
 }
 
-__global__ __launch_bounds__(64) void k_decompress_points(const uint8_t *__restrict__ in48, G1Affine29 *__restrict__ pts,
-                                                          int32_t *__restrict__ kind, size_t n) {
+// blockIdx.y selects one of two point sets (a verification's proofs and commitments in one launch; a single set passes itself twice)
+__global__ __launch_bounds__(64) void k_decompress_points(const uint8_t *__restrict__ in48_a, G1Affine29 *__restrict__ pts_a,
+                                                          int32_t *__restrict__ kind_a, const uint8_t *__restrict__ in48_b,
+                                                          G1Affine29 *__restrict__ pts_b, int32_t *__restrict__ kind_b, size_t n) {
     __shared__ uint32_t tab[16][14][64];   // 56 KiB: two workgroups to a compute unit
+    const uint8_t *in48 = blockIdx.y ? in48_b : in48_a;
+    G1Affine29 *pts = blockIdx.y ? pts_b : pts_a;
+    int32_t *kind = blockIdx.y ? kind_b : kind_a;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     F29<2> x = F29<2>::zero(), y = F29<2>::zero();
@@ -650,9 +652,15 @@ __global__ __launch_bounds__(64) void k_decompress_points(const uint8_t *__restr
 
 // verdict (optional): the cooperative subgroup test's word per point (k_subgroup_coop_asm: 0 = not in G1, 1 = in G1, 2 = undetermined --
 // an addition met P = +-Q in its low 56 bits --, which this kernel settles with the complete-branches test)
-__global__ __launch_bounds__(64) void k_subgroup_canon(G1Affine29 *__restrict__ pts, int32_t *__restrict__ kind,
-                                                       uint8_t *__restrict__ canon48, int32_t *__restrict__ status, int bad_code,
-                                                       size_t n, const uint32_t *__restrict__ verdict) {
+__global__ __launch_bounds__(64) void k_subgroup_canon(G1Affine29 *__restrict__ pts_a, int32_t *__restrict__ kind_a,
+                                                       uint8_t *__restrict__ canon48_a, const uint32_t *__restrict__ verdict_a,
+                                                       G1Affine29 *__restrict__ pts_b, int32_t *__restrict__ kind_b,
+                                                       uint8_t *__restrict__ canon48_b, const uint32_t *__restrict__ verdict_b,
+                                                       int32_t *__restrict__ status, int bad_code, size_t n) {
+    G1Affine29 *pts = blockIdx.y ? pts_b : pts_a;
+    int32_t *kind = blockIdx.y ? kind_b : kind_a;
+    uint8_t *canon48 = blockIdx.y ? canon48_b : canon48_a;
+    const uint32_t *verdict = blockIdx.y ? verdict_b : verdict_a;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int k0 = kind[i];
@@ -689,17 +697,38 @@ __global__ __launch_bounds__(64) void k_subgroup_canon(G1Affine29 *__restrict__ 
     kind[i] = rc;
 }
 
-void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st) {
+// LWKZG_VERIFY_PAD_KB (experiment, knobs.h): an LDS footprint the validation kernels never touch, so that the dispatcher cannot put their
+// workgroups on the compute units the hash kernel's workgroups occupy (profiles/r06_experiments.md section 1)
+unsigned verify_pad_bytes(int which, const void *kernel) {
+    static std::atomic<bool> allowed[3];  // a footprint above the default limit needs the attribute once per kernel
+    const unsigned b = (unsigned)knobs().verify_pad_kb[which] * 1024u;
+    if (b > 48u * 1024u && !allowed[which].exchange(true)) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+    return b;
+}
+
+void launch_decompress_points(const uint8_t *in48, G1Affine29 *pts, int32_t *kind, size_t n, hipStream_t st, bool apart) {
     ProfScope p("k_decompress_points", st);
-    hipLaunchKernelGGL(k_decompress_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, in48, pts, kind, n);
+    hipLaunchKernelGGL(k_decompress_points, dim3((unsigned)((n + 63) / 64)), dim3(64), apart ? verify_pad_bytes(0, (const void *)k_decompress_points) : 0u, st,
+                       in48, pts, kind, in48, pts, kind, n);
+}
+
+void launch_decompress_points2(const uint8_t *in48_a, G1Affine29 *pts_a, int32_t *kind_a, const uint8_t *in48_b, G1Affine29 *pts_b,
+                               int32_t *kind_b, size_t n, hipStream_t st, bool apart) {
+    ProfScope p("k_decompress_points", st);
+    hipLaunchKernelGGL(k_decompress_points, dim3((unsigned)((n + 63) / 64), 2), dim3(64), apart ? verify_pad_bytes(0, (const void *)k_decompress_points) : 0u, st,
+                       in48_a, pts_a, kind_a, in48_b, pts_b, kind_b, n);
 }
 
 // The subgroup test on a QUAD of lanes per point (tools/gen_subgroup_asm.py writes subgroup_asm.inc and explains it): doublings in three
 // rounds of one product per lane, the cooperative MSM kernel's addition, the public bits of |z| as a scalar loop. Workgroups of four
 // unrelated waves (one per SIMD of a compute unit), 16 points per wave.
-__global__ __launch_bounds__(256) void k_subgroup_coop_asm(const G1Affine29 *__restrict__ pts, const int32_t *__restrict__ kind,
-                                                           uint32_t *__restrict__ verdict, uint32_t n) {
+__global__ __launch_bounds__(256) void k_subgroup_coop_asm(const G1Affine29 *__restrict__ pts_a, const int32_t *__restrict__ kind_a,
+                                                           uint32_t *__restrict__ verdict_a, const G1Affine29 *__restrict__ pts_b,
+                                                           const int32_t *__restrict__ kind_b, uint32_t *__restrict__ verdict_b, uint32_t n) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const G1Affine29 *pts = blockIdx.y ? pts_b : pts_a;
+    const int32_t *kind = blockIdx.y ? kind_b : kind_a;
+    uint32_t *verdict = blockIdx.y ? verdict_b : verdict_a;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 16;
     __builtin_amdgcn_s_setprio(2);
@@ -713,20 +742,31 @@ __global__ __launch_bounds__(256) void k_subgroup_coop_asm(const G1Affine29 *__r
 #endif
 }
 
-void launch_subgroup_coop(const G1Affine29 *pts, const int32_t *kind, uint32_t *verdict, size_t n, hipStream_t st) {
-    ProfScope p("k_subgroup_coop_asm", st);
-    hipLaunchKernelGGL(k_subgroup_coop_asm, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, pts, kind, verdict, (uint32_t)n);
-}
-
 void launch_subgroup_canon(G1Affine29 *pts, int32_t *kind, uint8_t *canon48, int32_t *status, int bad_code, size_t n,
-                           hipStream_t st, uint32_t *verdict_scratch) {
+                           hipStream_t st, uint32_t *verdict_scratch, bool apart) {
     const uint32_t *verdict = nullptr;
     if (verdict_scratch && validate_coop_enabled()) {
-        launch_subgroup_coop(pts, kind, verdict_scratch, n, st);
+        ProfScope p("k_subgroup_coop_asm", st);
+        hipLaunchKernelGGL(k_subgroup_coop_asm, dim3((unsigned)((n + 63) / 64)), dim3(256), apart ? verify_pad_bytes(1, (const void *)k_subgroup_coop_asm) : 0u, st,
+                           pts, kind, verdict_scratch, pts, kind, verdict_scratch, (uint32_t)n);
         verdict = verdict_scratch;
     }
     ProfScope p("k_subgroup_canon", st);
-    hipLaunchKernelGGL(k_subgroup_canon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pts, kind, canon48, status, bad_code, n, verdict);
+    hipLaunchKernelGGL(k_subgroup_canon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pts, kind, canon48, verdict, pts, kind, canon48, verdict,
+                       status, bad_code, n);
+}
+
+// both point sets of a verification in one launch each (the quad test, then canonical bytes and verdicts)
+void launch_subgroup_canon2(G1Affine29 *pts_a, int32_t *kind_a, uint8_t *canon48_a, uint32_t *verdict_a, G1Affine29 *pts_b, int32_t *kind_b,
+                            uint8_t *canon48_b, uint32_t *verdict_b, int32_t *status, int bad_code, size_t n, hipStream_t st, bool apart) {
+    {
+        ProfScope p("k_subgroup_coop_asm", st);
+        hipLaunchKernelGGL(k_subgroup_coop_asm, dim3((unsigned)((n + 63) / 64), 2), dim3(256), apart ? verify_pad_bytes(1, (const void *)k_subgroup_coop_asm) : 0u, st,
+                           pts_a, kind_a, verdict_a, pts_b, kind_b, verdict_b, (uint32_t)n);
+    }
+    ProfScope p("k_subgroup_canon", st);
+    hipLaunchKernelGGL(k_subgroup_canon, dim3((unsigned)((n + 63) / 64), 2), dim3(64), 0, st, pts_a, kind_a, canon48_a, verdict_a, pts_b, kind_b, canon48_b,
+                       verdict_b, status, bad_code, n);
 }
 
 }  // namespace lwk

@@ -11,6 +11,7 @@
 // accept/reject bit with G2 and [tau]G2 taken straight from the setup.
 #include <chrono>
 #include "engine.h"
+#include "knobs.h"
 #include <memory>
 #include "fp2.h"
 #include "hostfp.h"
@@ -438,7 +439,23 @@ C_KZG_RET shard_partial(Shard &sh, const uint8_t *records_all, size_t n_total, s
             base = base * base;
         }
     }
-    std::vector<uint8_t> sc_r(32 * n), sc_rz(32 * n);
+    // three variable-base linear combinations: on the GPU over the points the validation kernels left there, or on the
+    // host threads when the batch was small enough to be validated there
+    const bool on_host = sh.vb.h_aff.size() == 2 * n && sh.vb.h_kind.size() == 2 * n;
+    // r06: the GPU derives its scalars from r itself (vmsm.hip: r^(2^k) and r^first go up, 1 KiB) and is at work on the sums while this
+    // thread walks the powers for sum r^i y_i; r05's arm needs the 2 x 32 n scalar bytes from here first
+    const bool dev_msm = n != 0 && !on_host && vmsm_ready(sh.vb);
+    if (dev_msm) {
+        Fr pw[33];
+        HFr sq = r_mont;
+        for (int k = 0; k < 32; k++) {
+            pw[k] = sq.to_fe();
+            sq = sq * sq;
+        }
+        pw[32] = rp.to_fe();
+        if (vmsm_begin(sh.ctx, sh.vb, pw, le ? 1 : 0, n) != C_KZG_OK) return C_KZG_ERROR;
+    }
+    std::vector<uint8_t> sc_r(dev_msm ? 0 : 32 * n), sc_rz(dev_msm ? 0 : 32 * n);
     for (size_t i = 0; i < n; i++) {
         uint32_t zr[8], yr[8];
         if (le) {
@@ -449,23 +466,22 @@ C_KZG_RET shard_partial(Shard &sh, const uint8_t *records_all, size_t n_total, s
             raw_from_be<8>(yr, &sh.ys[32 * i]);
         }
         if (raw_geq<8>(zr, FrParams::MOD) || raw_geq<8>(yr, FrParams::MOD)) return C_KZG_ERROR;  // the GPU wrote canonical values
-        hfr_to_be(&sc_r[32 * i], rp * one_raw);
-        hfr_to_be(&sc_rz[32 * i], rp * hfr_raw(zr));
+        if (!dev_msm) {
+            hfr_to_be(&sc_r[32 * i], rp * one_raw);
+            hfr_to_be(&sc_rz[32 * i], rp * hfr_raw(zr));
+        }
         ysum = ysum + rp * hfr_raw(yr);
         rp = rp * r_mont;
     }
     if (beside) beside(ysum);
     if (n == 0) return C_KZG_OK;
-    // three variable-base linear combinations: on the GPU over the points the validation kernels left there, or on the
-    // host threads when the batch was small enough to be validated there
-    const bool on_host = sh.vb.h_aff.size() == 2 * n && sh.vb.h_kind.size() == 2 * n;
     if (on_host) {
         host_lincomb3(out, sh.vb.h_aff.data(), sh.vb.h_kind.data(), sc_r.data(), sc_rz.data(), n);
         return C_KZG_OK;
     }
     uint8_t sums[3][96];
     int infs[3];
-    C_KZG_RET rc = lincomb3_device_host(sh.ctx, sh.vb, sc_r.data(), sc_rz.data(), n, sums, infs);
+    C_KZG_RET rc = dev_msm ? vmsm_finish(sh.ctx, sh.vb, sums, infs) : lincomb3_device_host(sh.ctx, sh.vb, sc_r.data(), sc_rz.data(), n, sums, infs);
     if (rc != C_KZG_OK) return C_KZG_ERROR;
     for (int k = 0; k < 3; k++) {
         if (infs[k]) continue;
@@ -557,7 +573,7 @@ static C_KZG_RET verify_batch_impl(bool *ok, const Blob *blobs, const Bytes48 *c
     if (n == 1 && !device_inputs) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);  // lib.rs:544
     if (!blobs || !commitments_bytes || !proofs_bytes || !s) return bad(mode);
 
-    static const bool timing = getenv("LWKZG_TIMING") != nullptr;  // phase wall-clock to stderr
+    const bool timing = knobs().timing;  // phase wall-clock to stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();

@@ -147,7 +147,7 @@ def test_host_pairing_variants_agree():
     want = "100" * 12 + "10"
     for var in ({}, {"LWKZG_PAIRING_ONE_THREAD": "1"}, {"LWKZG_PAIRING_NO_PRECOMP": "1"}, {"LWKZG_PAIRING_GENERIC_SQR": "1"},
                 {"LWKZG_PAIRING_NAIVE": "1", "LWKZG_PAIRING_NO_PRECOMP": "1"}):
-        env = dict(os.environ, **var)
+        env = dict(os.environ, LWKZG_EXPERIMENTAL="1", **var)     # (cross-check arms are experiment knobs: csrc/knobs.h)
         got = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1]
         assert got == want, (var, got)
 
@@ -281,15 +281,32 @@ def test_transform_lazy_bounds_walkthrough():
     assert 10 * (worst_limb + 1) * (1 << 56) + (1 << 36) < 1 << 64
 
 
-def test_every_environment_knob_is_in_the_integration_table():
-    """the getenv knobs of csrc/ were documented in five places; INTEGRATION.md carries the one table, and a knob that exists
-    in the sources without a row there (or a row without a knob) fails here"""
+def test_every_environment_knob_is_in_the_integration_table(K):
+    """the getenv knobs of csrc/ were documented in five places; VERDICT r05: 37 of them, read in the middle of functions.
+    r06: ONE file reads the environment (csrc/knobs.hip, once), nothing else in the library calls getenv, the knobs come in two classes
+    -- operational (always honoured; at most 20) and experiment (A/B arms, honoured only with LWKZG_EXPERIMENTAL=1) -- and INTEGRATION.md
+    carries one table per class: a knob without a row (or a row without a knob) fails here."""
     src_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "csrc")
-    knobs = set()
     for f in os.listdir(src_dir):
-        if f.endswith((".hip", ".h", ".cuh")):
-            knobs |= set(re.findall(r'getenv\("(LWKZG_[A-Z_0-9]+)"\)', open(os.path.join(src_dir, f)).read()))
+        if f.endswith((".hip", ".h", ".cuh", ".inc")) and f != "knobs.hip":
+            assert "getenv(" not in open(os.path.join(src_dir, f)).read(), f
+    read = set(re.findall(r'"(LWKZG_[A-Z_0-9]+)"', open(os.path.join(src_dir, "knobs.hip")).read().split("knob_names_operational()")[0]))
+    rep = K.knob_report()
+    op, ex = set(rep["operational"].split()), set(rep["experimental_names"].split())
+    assert not (op & ex) and op | ex == read, (sorted(read - (op | ex)), sorted((op | ex) - read))
+    assert len(op) <= 20, len(op)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    rows = set(re.findall(r"^\s*\| `(LWKZG_[A-Z_0-9]+)` \|", doc, flags=re.M))
-    assert len(knobs) >= 20
-    assert knobs == rows, (sorted(knobs - rows), sorted(rows - knobs))
+    op_doc, ex_doc = doc.split("<!-- experiment knobs -->")
+    rows_op = set(re.findall(r"^\s*\| `(LWKZG_[A-Z_0-9]+)` \|", op_doc, flags=re.M))
+    rows_ex = set(re.findall(r"^\s*\| `(LWKZG_[A-Z_0-9]+)` \|", ex_doc, flags=re.M))
+    assert rows_op == op, (sorted(op - rows_op), sorted(rows_op - op))
+    assert rows_ex == ex, (sorted(ex - rows_ex), sorted(rows_ex - ex))
+
+
+def test_glv_split_by_barrett_equals_the_restoring_division(tmp_path):
+    """csrc/glv.cuh as plain C++: k = lo + hi z^2 by Barrett's reduction (k_vmsm_scalars, behind r on the verification's critical path)
+    against the bitwise restoring division (k_lincomb3, the r05 arm) on edge values and 10^6 random integers below 2^255"""
+    exe = str(tmp_path / "glv_split_check")
+    subprocess.check_call(["g++", "-O2", "-Wall", "-Werror", "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "glv_split_check.cpp"), "-o", exe])
+    n, bad = (int(x) for x in subprocess.check_output([exe], text=True).split())
+    assert n > 1000000 and bad == 0

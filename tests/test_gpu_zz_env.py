@@ -53,7 +53,7 @@ def test_plain_hash_kernel_still_agrees(K, gpu_setup):
             "K.compute_blob_kzg_proof_batch_device(o.data_ptr(), d.data_ptr(), c.data_ptr(), n, ts, None, None); "
             "torch.cuda.synchronize(); print(bytes(o.cpu().numpy().tobytes()).hex())"
             % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH, n))
-    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, LWKZG_HASH_PAIRS="0")).decode().split()
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, LWKZG_EXPERIMENTAL="1", LWKZG_HASH_PAIRS="0")).decode().split()
     assert out[-1] == want
 
 
@@ -98,7 +98,7 @@ def test_ckzg_mode_from_the_environment_loads_the_lagrange_form(K, oracle, oracl
             % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH))
     for extra, bits in (({"LWKZG_DIRECT_BITS": "12"}, "12"), ({"LWKZG_DIRECT_BITS": "0"}, "0"),
                         ({"LWKZG_DIRECT_BITS": "0", "LWKZG_BUCKET_ASM": "0", "LWKZG_SORT_STAGE": "0"}, "0")):
-        env = dict(os.environ, LWKZG_MODE="ckzg", **extra)
+        env = dict(os.environ, LWKZG_MODE="ckzg", LWKZG_EXPERIMENTAL="1", **extra)
         out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
         mode, got_bits, forms_at_load, forms_after, c_hex, p_hex = out[-6:]
         assert mode == "1" and got_bits == bits, out[-6:]

@@ -1,5 +1,6 @@
 # Collects the round's measurement artifacts on the GPU box (one gpurun call); tools/publish_profiles.sh copies the
 # summaries into profiles/. Counters are collected in their own rocprofv3 runs (--pmc only), never with trace flags.
+export LWKZG_EXPERIMENTAL=1   # the A/B arms below are experiment knobs (csrc/knobs.h, r06)
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,6 +1,7 @@
 # The library's HOST code under AddressSanitizer + UndefinedBehaviorSanitizer on the GPU box (device code built as always:
 # make -C lambdaworks_kzg_amd/csrc hostasan): the concurrent host front -- coalesced single-blob callers, proof fronts, two caller
 # streams, batch verification, load / free cycles -- with every allocation and every signed overflow of the host side checked.
+export LWKZG_EXPERIMENTAL=1   # the A/B arms below are experiment knobs (csrc/knobs.h, r06)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/host_asan

@@ -1,3 +1,4 @@
+export LWKZG_EXPERIMENTAL=1   # the A/B arms below are experiment knobs (csrc/knobs.h, r06)
 cd $GRAFT_REPO_ROOT
 L=$PWD/lambdaworks_kzg_amd/lib
 gcc -std=c11 -O1 -I include tests/lib_test_mirror.c -o /tmp/mirror -L $L -llambdaworks_kzg -Wl,-rpath,$L -Wl,-rpath,/opt/rocm/lib || exit 1
