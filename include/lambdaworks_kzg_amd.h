@@ -355,6 +355,12 @@ C_KZG_RET lwkzg_pairing_product_is_one(bool *ok, const uint8_t *g1_compressed, c
  * the compute_challenge message (src/utils.rs:120-144), as the host-pointer proof entry points compute it. */
 C_KZG_RET lwkzg_challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *commitments48, size_t n);
 
+/* Host-only: the batch challenge of verify_blob_kzg_proof_batch (src/utils.rs:166-206) over a transcript of n_total 160-byte records
+ * (lwkzg_verify_shard_begin*'s output, all shards in order): r = SHA-256("RCKZGBATCH___V1_" | le64(4096) | le64(n_total) | records) read as a
+ * field element in `mode`'s byte order and reduced; r_out = its canonical value, 32 bytes big-endian. What every shard derives inside
+ * lwkzg_verify_shard_partial; exposed so that a sharded verifier can log / cross-check it (tests hold it against hashlib). */
+C_KZG_RET lwkzg_batch_challenge_host(uint8_t r_out[32], const uint8_t *records_all, size_t n_total, int mode);
+
 /* Engine introspection / profiling (bench.py). Kernel timings use hipEvents on the launch stream. */
 int lwkzg_device_count(void);
 int lwkzg_set_device(int ordinal);                 /* device used by subsequent load_* calls */

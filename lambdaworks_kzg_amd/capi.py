@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_device_count", "lwkzg_set_device", "lwkzg_version", "lwkzg_last_error",
     "lwkzg_profile_enable", "lwkzg_profile_reset", "lwkzg_profile_report",
     "lwkzg_msm_window_bits", "lwkzg_msm_num_windows", "lwkzg_pairing_product_is_one",
-    "lwkzg_challenge_digests_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
+    "lwkzg_challenge_digests_host", "lwkzg_batch_challenge_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_table_forms", "lwkzg_enable_direct_table_forms", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
     "lwkzg_timing_report", "lwkzg_runtime_init", "lwkzg_knob_report",
@@ -135,6 +135,7 @@ def lib():
     l.lwkzg_profile_report.restype = sz
     l.lwkzg_pairing_product_is_one.argtypes = [C.POINTER(C.c_bool), C.c_char_p, C.c_char_p, sz]
     l.lwkzg_challenge_digests_host.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    l.lwkzg_batch_challenge_host.argtypes = [C.c_char_p, C.c_char_p, sz, ci]
     l.lwkzg_g1_msm_tiled_device.argtypes = [vp, vp, sz, ps, vp]
     l.lwkzg_g1_sum_compressed.argtypes = [C.c_char_p, C.c_char_p, sz]
     pi = C.POINTER(C.c_int)
@@ -652,6 +653,14 @@ def pairing_product_is_one(g1_compressed, g2_compressed):
     ok = C.c_bool(False)
     _check("lwkzg_pairing_product_is_one", lib().lwkzg_pairing_product_is_one(C.byref(ok), g1_compressed, g2_compressed, n))
     return bool(ok.value)
+
+
+def batch_challenge_host(records_all, n_total, mode):
+    """r of verify_blob_kzg_proof_batch over a transcript of 160-byte records, canonical 32 bytes big-endian (lwkzg_batch_challenge_host)"""
+    assert len(records_all) == VERIFY_RECORD_BYTES * n_total
+    out = C.create_string_buffer(32)
+    _check("lwkzg_batch_challenge_host", lib().lwkzg_batch_challenge_host(out, records_all, n_total, mode))
+    return out.raw
 
 
 def challenge_digests_host(blobs, commitments):

@@ -111,6 +111,9 @@ struct VerifyBuffers {
     F29<2> *vm_pre = nullptr;
     uint32_t *sc_a = nullptr, *sc_b = nullptr;
     Fr *vm_pw = nullptr;
+    uint8_t *d_rec = nullptr;       // 160 bytes per blob + a first-bad-index word: the transcript assembled on the device (k_verify_records)
+    uint8_t *h_rec = nullptr;       // hipHostMalloc: the same, where one copy lands
+    size_t rec_cap = 0;             // blobs d_rec / h_rec hold
     uint8_t *h_pin = nullptr;       // hipHostMalloc: 33 Fr | 3 x 96 bytes | 3 x int32
     hipEvent_t vm_done = nullptr;   // recorded behind the results' copy (vmsm_begin), waited for by vmsm_finish
     // small batches validated on the host threads keep their points here instead (n commitments, then n proofs; kind 0 =
@@ -290,8 +293,11 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
                               int mode, uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb,
                               const uint8_t *trusted_canon_c = nullptr);
 // the same for device-resident inputs (d_ pointers; z32 .. canon_p are host memory)
+// records_out (r06; 160 n host bytes, C | z | y | pi per blob): when given, the transcript is assembled on the device and comes back in ONE
+// copy through pinned memory; z32 .. canon_p are then not written
 C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d_comm, const uint8_t *d_proofs, size_t n, int mode,
-                                uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, hipStream_t caller);
+                                uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, hipStream_t caller,
+                                uint8_t *records_out = nullptr);
 C_KZG_RET lincomb3_device_host(Ctx *c, VerifyBuffers &vb, const uint8_t *sc_r, const uint8_t *sc_rz, size_t n,
                                uint8_t sums[3][96], int infs[3]);
 // r06: the same three sums from r alone (vmsm.hip). pw33: r^(2^k), k = 0..31, then r^first, Montgomery form. vmsm_begin only

@@ -1204,6 +1204,12 @@ void verify_buffers_free(VerifyBuffers &v) {
     dev_free(v.d_part);
     dev_free(v.d_inf);
     dev_free(v.vm_base);
+    dev_free(v.d_rec);
+    if (v.h_rec) {
+        (void)hipHostFree(v.h_rec);
+        v.h_rec = nullptr;
+    }
+    v.rec_cap = 0;
     v.tab_p = v.tab_c = nullptr;
     v.vm_tmp = v.vm_partial = v.vm_bsum = nullptr;
     v.vm_pre = nullptr;
@@ -1248,8 +1254,11 @@ static C_KZG_RET verify_buffers_alloc(VerifyBuffers &v, size_t cap) {
                      b_pw = up(33 * sizeof(Fr));
         ok = hipMalloc((void **)&v.vm_base, 2 * b_tab + b_tmp + b_pre + 2 * b_sc + b_part + b_bsum + b_pw) == hipSuccess &&
              hipHostMalloc((void **)&v.h_pin, kVmsmPinBytes, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void **)&v.d_rec, 160 * cap + 16) == hipSuccess &&
+             hipHostMalloc((void **)&v.h_rec, 160 * cap + 16, hipHostMallocDefault) == hipSuccess &&
              hipEventCreateWithFlags(&v.vm_done, hipEventDisableTiming) == hipSuccess;
         if (ok) {
+            v.rec_cap = cap;
             uint8_t *p = v.vm_base;
             v.tab_p = (G1Affine29 *)p; p += b_tab;
             v.tab_c = (G1Affine29 *)p; p += b_tab;
@@ -1280,6 +1289,7 @@ static void verify_buffers_lend(VerifyBuffers &vb, const VerifyBuffers &v) {
     vb.vm_base = nullptr;   // (not this object's to free)
     vb.tab_p = v.tab_p; vb.tab_c = v.tab_c; vb.vm_tmp = v.vm_tmp; vb.vm_pre = v.vm_pre; vb.sc_a = v.sc_a; vb.sc_b = v.sc_b;
     vb.vm_partial = v.vm_partial; vb.vm_bsum = v.vm_bsum; vb.vm_pw = v.vm_pw; vb.h_pin = v.h_pin; vb.vm_done = v.vm_done;
+    vb.d_rec = v.d_rec; vb.h_rec = v.h_rec; vb.rec_cap = v.rec_cap;
 }
 
 // the rows of both point sets for the linear combinations, on `st` (needs the decompressed points, not the subgroup verdicts):
@@ -1579,7 +1589,8 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
 // caller's (a valid point in a non-canonical encoding) that blob's challenge is taken again over the canonical ones -- a launch that
 // exits at once otherwise. Then chunk by chunk: parse, y = p(z). `caller`: the stream the inputs were produced on (may be null).
 C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d_comm, const uint8_t *d_proofs, size_t n, int mode,
-                                uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, hipStream_t caller) {
+                                uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, hipStream_t caller,
+                                uint8_t *records_out) {
     if (!vb.owned) vb.hold = std::unique_lock<std::mutex>(c->verify_mu);
     std::lock_guard<std::mutex> lk(c->mu);
     LWK_HIP(hipSetDevice(c->device));
@@ -1664,6 +1675,25 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
             quotient_stage(c, mode, w.scalars, z + off, nullptr /* y only */, vb.d_r + 32 * off, le, m, st);
             launch_fr_mont_to_bytes(z + off, vb.d_rz + 32 * off, le, m, st);
         }
+    }
+    if (records_out && vb.d_rec && vb.h_rec && vb.rec_cap >= n) {
+        // r06: the transcript C | z | y | pi per blob assembled by a kernel and ONE copy into pinned memory, the lowest rejected index in its
+        // last word -- where r05 made four copies into pageable vectors, a fifth for the status words, and the host interleaved
+        uint32_t *d_flag = (uint32_t *)(vb.d_rec + 160 * n);
+        LWK_HIP(hipMemsetAsync(d_flag, 0xff, 4, st));
+        launch_verify_records(vb.canon_dev, vb.d_rz, vb.d_r, vb.canon_dev + 48 * n, vb.status_all, vb.d_rec, d_flag, n, st);
+        LWK_HIP(hipMemcpyAsync(vb.h_rec, vb.d_rec, 160 * n + 4, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipStreamSynchronize(st));
+        uint32_t first_bad;
+        memcpy(&first_bad, vb.h_rec + 160 * n, 4);
+        if (first_bad != 0xffffffffu) {
+            int32_t code = 0;
+            LWK_HIP(hipMemcpy(&code, vb.status_all + first_bad, 4, hipMemcpyDeviceToHost));
+            set_error("input %zu rejected (status %d)", (size_t)first_bad, code);
+            return (C_KZG_RET)code;
+        }
+        memcpy(records_out, vb.h_rec, 160 * n);
+        return C_KZG_OK;
     }
     LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
     LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));

@@ -178,6 +178,9 @@ void launch_vmsm_accumulate(const uint32_t *sc_a, const uint32_t *sc_b, const G1
                             const G1Affine29 *tab_c, const int32_t *kind_c, G1Xyzz29 *partial, size_t n, hipStream_t st);
 // bsum: 3 x 256 XYZZ; out96 / inf: the three sums, affine big-endian x | y and an infinity flag each (what launch_xyzz29_to_affine_be leaves)
 void launch_vmsm_reduce(const G1Xyzz29 *partial, G1Xyzz29 *bsum, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
+// records[160 i] = C_i | z_i | y_i | pi_i from the device-resident pieces; *first_bad = lowest index with a status word set (pre-set to 0xffffffff)
+void launch_verify_records(const uint8_t *canon_c, const uint8_t *z32, const uint8_t *y32, const uint8_t *canon_p, const int32_t *status,
+                           uint8_t *records, uint32_t *first_bad, size_t n, hipStream_t st);
 void launch_xyzz29_to_affine_be(const G1Xyzz29 *in, uint8_t *out96, int32_t *inf, size_t n, hipStream_t st);
 void launch_challenge(const uint8_t *blobs, const uint8_t *canon48, Fr *z_mont, int le, size_t n, hipStream_t st,
                       const uint8_t *only_if_differs_from = nullptr);

@@ -161,6 +161,46 @@ void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len) {
     }
 }
 
+// SHA-256 of prefix | msg without building the concatenation (the batch challenge: a 32-byte header in front of 160 bytes per blob that
+// already lie in one buffer, verify.hip); prefix_len < 64
+void sha256_fast_prefixed(uint8_t out[32], const uint8_t *prefix, size_t prefix_len, const uint8_t *msg, size_t len) {
+    if (!have_shani() || prefix_len >= 64) {
+        std::vector<uint8_t> m(prefix_len + len);
+        memcpy(m.data(), prefix, prefix_len);
+        if (len) memcpy(m.data() + prefix_len, msg, len);
+        sha256_fast(out, m.data(), m.size());
+        return;
+    }
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint8_t tail[192];
+    memset(tail, 0, sizeof tail);
+    memcpy(tail, prefix, prefix_len);
+    size_t used = 0, fill = prefix_len;   // bytes of msg consumed; bytes in tail
+    if (prefix_len + len >= 64) {
+        used = 64 - prefix_len;
+        memcpy(tail + prefix_len, msg, used);
+        compress_shani(h, tail, 1);
+        const size_t whole = (len - used) / 64;
+        compress_shani(h, msg + used, whole);
+        used += 64 * whole;
+        memset(tail, 0, sizeof tail);
+        fill = 0;
+    }
+    memcpy(tail + fill, msg + used, len - used);
+    fill += len - used;
+    tail[fill] = 0x80;
+    const size_t tl = fill + 9 <= 64 ? 64 : 128;
+    const uint64_t bits = (uint64_t)(prefix_len + len) * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    compress_shani(h, tail, tl / 64);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(h[k] >> 24);
+        out[4 * k + 1] = (uint8_t)(h[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(h[k] >> 8);
+        out[4 * k + 3] = (uint8_t)h[k];
+    }
+}
+
 // hardware threads this process may really use (shared with the host-side validation of verify.hip)
 static unsigned probe_host_threads() {
     unsigned n = std::thread::hardware_concurrency();

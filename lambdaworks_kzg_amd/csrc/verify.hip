@@ -28,6 +28,7 @@ bool pairing_product_is_one(const G1Affine *ps, const Fp2 *qx, const Fp2 *qy, in
 bool pairing_check_compressed(const uint8_t *g1s, const uint8_t *g2s, int n, bool *ok);
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 void sha256_fast(uint8_t out[32], const uint8_t *msg, size_t len);  // sha256_host.hip: SHA extensions when present
+void sha256_fast_prefixed(uint8_t out[32], const uint8_t *prefix, size_t prefix_len, const uint8_t *msg, size_t len);
 unsigned host_threads();  // sha256_host.hip: hardware threads capped by the cgroup quota
 void host_parallel_for(size_t n, const std::function<void(size_t)> &fn);  // sha256_host.hip: persistent workers
 
@@ -327,7 +328,9 @@ struct Shard {
     size_t n = 0;
     int mode = 0;
     VerifyBuffers vb;
-    std::vector<uint8_t> zs, ys, canon_c, canon_p;
+    std::vector<uint8_t> records;   // C | z | y | pi per blob (160 n): the shard's part of the transcript, and where z_i / y_i are read from
+    const uint8_t *z(size_t i) const { return &records[kRecord * i + 48]; }
+    const uint8_t *y(size_t i) const { return &records[kRecord * i + 80]; }
     ~Shard() {
         if (vb.owned) {  // device memory of the shard's own: freed on its device whether or not the context still exists
             hipSetDevice(device);
@@ -348,30 +351,32 @@ C_KZG_RET shard_begin(Shard &sh, const uint8_t *blobs, const uint8_t *comms, con
     sh.n = n;
     sh.mode = mode;
     sh.vb.owned = own_buffers;
-    sh.zs.resize(32 * n);
-    sh.ys.resize(32 * n);
-    sh.canon_c.resize(48 * n);
-    sh.canon_p.resize(48 * n);
+    sh.records.resize(kRecord * n);
     if (n == 0) return C_KZG_OK;
     // per blob on the GPU: validate C_i and pi_i (decompress + subgroup check + canonical recompression; the
     // decompressed points stay on the device), z_i = challenge(blob_i, C_i), y_i = p_i(z_i)
-    C_KZG_RET rc = device_inputs ? verify_prepare_device(sh.ctx, blobs, comms, proofs, n, mode, sh.zs.data(), sh.ys.data(), sh.canon_c.data(),
-                                                         sh.canon_p.data(), sh.vb, caller)
-                                 : verify_prepare_host(sh.ctx, blobs, comms, proofs, n, mode, sh.zs.data(), sh.ys.data(), sh.canon_c.data(),
-                                                       sh.canon_p.data(), sh.vb);
+    C_KZG_RET rc;
+    if (device_inputs) {   // the transcript is assembled on the device and arrives in one copy (engine.hip)
+        rc = verify_prepare_device(sh.ctx, blobs, comms, proofs, n, mode, nullptr, nullptr, nullptr, nullptr, sh.vb, caller, sh.records.data());
+    } else {
+        std::vector<uint8_t> zs(32 * n), ys(32 * n), canon_c(48 * n), canon_p(48 * n);
+        rc = verify_prepare_host(sh.ctx, blobs, comms, proofs, n, mode, zs.data(), ys.data(), canon_c.data(), canon_p.data(), sh.vb);
+        if (rc == C_KZG_OK)
+            for (size_t i = 0; i < n; i++) {   // z and y enter in the mode's byte order, as to_bytes_be / c-kzg's bytes_from_bls_field do
+                uint8_t *m = &sh.records[kRecord * i];
+                memcpy(m, &canon_c[48 * i], 48);
+                memcpy(m + 48, &zs[32 * i], 32);
+                memcpy(m + 80, &ys[32 * i], 32);
+                memcpy(m + 112, &canon_p[48 * i], 48);
+            }
+    }
     if (rc != C_KZG_OK) return mode == LWKZG_MODE_REFERENCE ? C_KZG_ERROR : rc;
     return C_KZG_OK;
 }
 
-// this shard's records; z and y enter in the mode's byte order, as to_bytes_be / c-kzg's bytes_from_bls_field do
+// this shard's records
 void shard_records(const Shard &sh, uint8_t *out) {
-    for (size_t i = 0; i < sh.n; i++) {
-        uint8_t *m = out + kRecord * i;
-        memcpy(m, &sh.canon_c[48 * i], 48);
-        memcpy(m + 48, &sh.zs[32 * i], 32);
-        memcpy(m + 80, &sh.ys[32 * i], 32);
-        memcpy(m + 112, &sh.canon_p[48 * i], 48);
-    }
+    if (sh.n) memcpy(out, sh.records.data(), kRecord * sh.n);
 }
 
 HFr hfr_raw(const uint32_t t[8]) {
@@ -393,15 +398,14 @@ void hfr_to_be(uint8_t *out, const HFr &x) {
 
 // r (utils.rs:166-206) from the n_total records of the whole batch, in Montgomery form
 HFr batch_challenge_mont(const uint8_t *records, size_t n_total, bool le) {
-    std::vector<uint8_t> msg(32 + n_total * kRecord);
-    memcpy(msg.data(), "RCKZGBATCH___V1_", 16);
-    memset(msg.data() + 16, 0, 16);
-    msg[16] = 0x00;
-    msg[17] = 0x10;  // 4096 LE
-    for (int k = 0; k < 8; k++) msg[24 + k] = (uint8_t)((uint64_t)n_total >> (8 * k));
-    memcpy(msg.data() + 32, records, n_total * kRecord);
+    uint8_t head[32];
+    memcpy(head, "RCKZGBATCH___V1_", 16);
+    memset(head + 16, 0, 16);
+    head[16] = 0x00;
+    head[17] = 0x10;  // 4096 LE
+    for (int k = 0; k < 8; k++) head[24 + k] = (uint8_t)((uint64_t)n_total >> (8 * k));
     uint8_t dg[32];
-    sha256_fast(dg, msg.data(), msg.size());
+    sha256_fast_prefixed(dg, head, 32, records, n_total * kRecord);   // (no 160 n-byte copy of the transcript behind its header)
     uint32_t t[8], rraw[8];
     if (le) raw_from_le<8>(t, dg); else raw_from_be<8>(t, dg);
     Fr f = fe_from_raw<FrParams>(t);  // hash_field_unsafe: reduced mod r
@@ -422,7 +426,7 @@ C_KZG_RET shard_partial(Shard &sh, const uint8_t *records_all, size_t n_total, s
         set_error("verify shard [%zu, %zu) does not fit a batch of %zu", first, first + n, n_total);
         return C_KZG_BADARGS;
     }
-    if (n && memcmp(records_all + kRecord * first + 48, sh.zs.data(), 32) != 0) {
+    if (n && memcmp(records_all + kRecord * first + 48, sh.z(0), 32) != 0) {
         set_error("verify shard: the transcript at index %zu is not this shard's first record", first);
         return C_KZG_BADARGS;
     }
@@ -459,11 +463,11 @@ C_KZG_RET shard_partial(Shard &sh, const uint8_t *records_all, size_t n_total, s
     for (size_t i = 0; i < n; i++) {
         uint32_t zr[8], yr[8];
         if (le) {
-            raw_from_le<8>(zr, &sh.zs[32 * i]);
-            raw_from_le<8>(yr, &sh.ys[32 * i]);
+            raw_from_le<8>(zr, sh.z(i));
+            raw_from_le<8>(yr, sh.y(i));
         } else {
-            raw_from_be<8>(zr, &sh.zs[32 * i]);
-            raw_from_be<8>(yr, &sh.ys[32 * i]);
+            raw_from_be<8>(zr, sh.z(i));
+            raw_from_be<8>(yr, sh.y(i));
         }
         if (raw_geq<8>(zr, FrParams::MOD) || raw_geq<8>(yr, FrParams::MOD)) return C_KZG_ERROR;  // the GPU wrote canonical values
         if (!dev_msm) {
@@ -584,8 +588,7 @@ static C_KZG_RET verify_batch_impl(bool *ok, const Blob *blobs, const Bytes48 *c
                                mode, false, device_inputs, caller);
     if (rc != C_KZG_OK) return rc;
     const auto t1 = now();
-    std::vector<uint8_t> records(kRecord * n);
-    shard_records(sh, records.data());
+    const std::vector<uint8_t> &records = sh.records;   // one shard: its records are the transcript
     HostPoint g;
     if (!setup_generator(g, s)) return C_KZG_ERROR;
     // [sum r^i y_i]G on a thread of its own, beside the linear combinations
@@ -746,6 +749,14 @@ C_KZG_RET lwkzg_g1_sum_compressed(uint8_t out48[48], const uint8_t *points48, si
 C_KZG_RET lwkzg_challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *commitments48, size_t n) {
     if (!digests32 || !blobs || !commitments48) return C_KZG_BADARGS;
     challenge_digests_host(digests32, blobs, commitments48, n);
+    return C_KZG_OK;
+}
+
+// the batch challenge r over a transcript of records, canonical big-endian (host only)
+C_KZG_RET lwkzg_batch_challenge_host(uint8_t r_out[32], const uint8_t *records_all, size_t n_total, int mode) {
+    if (!r_out || (!records_all && n_total) || (mode != LWKZG_MODE_REFERENCE && mode != LWKZG_MODE_CKZG)) return C_KZG_BADARGS;
+    const uint32_t one_limbs[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    hfr_to_be(r_out, batch_challenge_mont(records_all, n_total, mode == LWKZG_MODE_CKZG) * hfr_raw(one_limbs));
     return C_KZG_OK;
 }
 

@@ -218,28 +218,29 @@ void launch_vmsm_accumulate(const uint32_t *sc_a, const uint32_t *sc_b, const G1
 
 // ---- behind r: the slices' sums per bucket (a wave per bucket) ----------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_vmsm_bucket_sums(const G1Xyzz29 *__restrict__ partial, G1Xyzz29 *__restrict__ bsum, uint32_t slices) {
-    __shared__ G1Xyzz29 sh[64];
+    __shared__ G1Xyzz29i sh[64];   // (field products inlined: these kernels are dependent chains, a call boundary per product is pure latency)
     const int b = blockIdx.x + 1, set = blockIdx.y, t = threadIdx.x;
-    G1Xyzz29 acc = G1Xyzz29::infinity();
-    for (uint32_t s = t; s < slices; s += 64) acc = xyzz_add(acc, partial[((size_t)set * slices + s) * 256 + b]);
+    const G1Xyzz29i *part = (const G1Xyzz29i *)partial;
+    G1Xyzz29i acc = G1Xyzz29i::infinity();
+    for (uint32_t s = t; s < slices; s += 64) acc = xyzz_add(acc, part[((size_t)set * slices + s) * 256 + b]);
     sh[t] = acc;
     __syncthreads();
     for (int d = 32; d >= 1; d >>= 1) {
         if (t < d) sh[t] = xyzz_add(sh[t], sh[t + d]);
         __syncthreads();
     }
-    if (t == 0) bsum[set * 256 + b] = sh[0];
+    if (t == 0) bsum[set * 256 + b] = *(const G1Xyzz29 *)&sh[0];
 }
 
 // ---- behind r: sum_b b B_b = sum_{k >= 1} (sum_{b >= k} B_b): suffix scan, tree, and the affine big-endian result ---------------------
 __global__ __launch_bounds__(256) void k_vmsm_weighted(const G1Xyzz29 *__restrict__ bsum, uint8_t *__restrict__ out96, int32_t *__restrict__ inf) {
-    __shared__ G1Xyzz29 sh[256];
+    __shared__ G1Xyzz29i sh[256];
     const int set = blockIdx.x, b = threadIdx.x;
-    G1Xyzz29 v = b >= 1 ? bsum[set * 256 + b] : G1Xyzz29::infinity();
+    G1Xyzz29i v = b >= 1 ? ((const G1Xyzz29i *)bsum)[set * 256 + b] : G1Xyzz29i::infinity();
     sh[b] = v;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
-        G1Xyzz29 o = G1Xyzz29::infinity();
+        G1Xyzz29i o = G1Xyzz29i::infinity();
         if (b + d < 256) o = sh[b + d];
         __syncthreads();
         v = xyzz_add(v, o);
@@ -247,14 +248,14 @@ __global__ __launch_bounds__(256) void k_vmsm_weighted(const G1Xyzz29 *__restric
         __syncthreads();
     }
     // sh[b] = sum_{k >= b} B_k; lane 0 holds the same as lane 1 (B_0 is empty) and stays out of the tree
-    if (b == 0) sh[0] = G1Xyzz29::infinity();
+    if (b == 0) sh[0] = G1Xyzz29i::infinity();
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) {
         if (b < d) sh[b] = xyzz_add(sh[b], sh[b + d]);
         __syncthreads();
     }
     if (b != 0) return;
-    const G1Xyzz29 total = sh[0];
+    const G1Xyzz29 total = *(const G1Xyzz29 *)&sh[0];
     uint8_t *o = out96 + 96 * set;
     if (total.is_inf()) {
         inf[set] = 1;
@@ -277,6 +278,32 @@ void launch_vmsm_reduce(const G1Xyzz29 *partial, G1Xyzz29 *bsum, uint8_t *out96,
     }
     ProfScope p("k_vmsm_weighted", st);
     hipLaunchKernelGGL(k_vmsm_weighted, dim3(3), dim3(256), 0, st, bsum, out96, inf);
+}
+
+// ---- the transcript, assembled where its pieces are (device-resident verification) -----------------------------------------------------
+// records[160 i] = C_i (canonical, 48) | z_i (32) | y_i (32) | pi_i (canonical, 48): the message of the batch challenge r
+// (/root/reference/src/utils.rs:166-206) in ONE buffer, so that one copy into pinned memory replaces four into pageable vectors plus the
+// host's interleaving; first_bad = the lowest index whose status word is set (0xffffffff: none). One lane per 16-byte piece.
+__global__ __launch_bounds__(256) void k_verify_records(const uint8_t *__restrict__ canon_c, const uint8_t *__restrict__ z32,
+                                                        const uint8_t *__restrict__ y32, const uint8_t *__restrict__ canon_p,
+                                                        const int32_t *__restrict__ status, uint4 *__restrict__ records,
+                                                        uint32_t *__restrict__ first_bad, uint32_t n) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = g / 10, piece = g % 10;
+    if (i >= n) return;
+    const uint4 *src = piece < 3   ? (const uint4 *)(canon_c + 48 * (size_t)i) + piece
+                       : piece < 5 ? (const uint4 *)(z32 + 32 * (size_t)i) + (piece - 3)
+                       : piece < 7 ? (const uint4 *)(y32 + 32 * (size_t)i) + (piece - 5)
+                                   : (const uint4 *)(canon_p + 48 * (size_t)i) + (piece - 7);
+    records[10 * (size_t)i + piece] = *src;
+    if (piece == 0 && status[i] != 0) atomicMin(first_bad, i);
+}
+
+void launch_verify_records(const uint8_t *canon_c, const uint8_t *z32, const uint8_t *y32, const uint8_t *canon_p, const int32_t *status,
+                           uint8_t *records, uint32_t *first_bad, size_t n, hipStream_t st) {
+    ProfScope p("k_verify_records", st);
+    hipLaunchKernelGGL(k_verify_records, dim3((unsigned)((10 * n + 255) / 256)), dim3(256), 0, st, canon_c, z32, y32, canon_p, status,
+                       (uint4 *)records, first_bad, (uint32_t)n);
 }
 
 }  // namespace lwk

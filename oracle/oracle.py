@@ -22,7 +22,7 @@ def build(force=False, native=False, out_dir=None):
     out_dir = out_dir or _HERE
     name = "liboracle_kzg_native.so" if native else "liboracle_kzg.so"
     out = os.path.join(out_dir, name)
-    srcs = [os.path.join(_HERE, f) for f in ("ref_kzg.c", "ref_g1.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("ref_kzg.c", "ref_g1.c", "ref_pairing.c")]
     deps = srcs + [os.path.join(_HERE, "ref_field.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
@@ -84,6 +84,15 @@ def _bind(l):
     l.orc_fr_mul_be.restype = None
     l.orc_g1_add_affine.argtypes = [cp, C.POINTER(ci), cp, ci, cp, ci]
     l.orc_g1_mul_affine.argtypes = [cp, C.POINTER(ci), cp, cp]
+    # ref_pairing.c: the plain optimal ate pairing (second opinion on the product's host pairing) and G2 helpers for its inputs
+    l.orc_pairing_product_is_one.argtypes = [C.POINTER(ci), cp, cp, ci]
+    l.orc_g2_generator_mul.argtypes = [cp, cp]
+    l.orc_g2_generator_mul.restype = None
+    l.orc_g2_compress.argtypes = [cp, cp]
+    l.orc_g2_compress.restype = None
+    l.orc_g2_on_curve.argtypes = [cp]
+    l.orc_final_exponent.argtypes = [cp]
+    l.orc_final_exponent.restype = None
     return l
 
 
@@ -188,6 +197,41 @@ def g1_generator_mul(k_int):
     out = C.create_string_buffer(48)
     lib().orc_g1_generator_mul(out, int(k_int % (1 << 256)).to_bytes(32, "big"))
     return out.raw
+
+
+def g2_generator_mul(k_int):
+    """[k]G2 as affine x.c0 | x.c1 | y.c0 | y.c1 (4 x 48 bytes big-endian; all zero = infinity); ref_pairing.c"""
+    out = C.create_string_buffer(192)
+    lib().orc_g2_generator_mul(out, int(k_int % (1 << 256)).to_bytes(32, "big"))
+    return out.raw
+
+
+def g2_compress(xy192):
+    """ZCash compression of an affine G2 point, sign bit included"""
+    out = C.create_string_buffer(96)
+    lib().orc_g2_compress(out, xy192)
+    return out.raw
+
+
+def g2_on_curve(xy192):
+    return bool(lib().orc_g2_on_curve(xy192))
+
+
+def pairing_product_is_one(g1_xy96_list, g2_xy192_list):
+    """prod e(P_i, Q_i) == 1 by the oracle's own pairing (affine Miller loop over Fp2[w]/(w^6 - xi), exponent (p^12-1)/r as it stands).
+    Inputs: affine big-endian coordinates, all-zero = infinity. Raises on points off their curves."""
+    assert len(g1_xy96_list) == len(g2_xy192_list)
+    ok = C.c_int(0)
+    rc = lib().orc_pairing_product_is_one(C.byref(ok), b"".join(g1_xy96_list), b"".join(g2_xy192_list), len(g1_xy96_list))
+    if rc != 0:
+        raise ValueError("a point is not on its curve or not canonical")
+    return bool(ok.value)
+
+
+def final_exponent():
+    out = C.create_string_buffer(544)
+    lib().orc_final_exponent(out)
+    return int.from_bytes(out.raw, "big")
 
 
 def g1_decompress(b48):

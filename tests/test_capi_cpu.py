@@ -165,6 +165,21 @@ def test_host_fiat_shamir_digests_match_hashlib(K):
         assert g == hashlib.sha256(msg).digest()
 
 
+def test_batch_challenge_matches_hashlib(K):
+    """r of verify_blob_kzg_proof_batch (/root/reference/src/utils.rs:166-206): the header is hashed in front of the transcript without
+    building the concatenation (sha256_fast_prefixed); transcript lengths on every side of a block boundary, both byte orders"""
+    import hashlib
+    import random
+    from lambdaworks_kzg_amd import capi
+    from conftest import R
+    rnd = random.Random(66)
+    for n in (0, 1, 2, 3, 4, 5, 7, 64, 301):
+        rec = bytes(rnd.getrandbits(8) for _ in range(160 * n))
+        dg = hashlib.sha256(b"RCKZGBATCH___V1_" + (4096).to_bytes(8, "little") + n.to_bytes(8, "little") + rec).digest()
+        assert capi.batch_challenge_host(rec, n, K.MODE_REFERENCE) == (int.from_bytes(dg, "big") % R).to_bytes(32, "big"), n
+        assert capi.batch_challenge_host(rec, n, K.MODE_CKZG) == (int.from_bytes(dg, "little") % R).to_bytes(32, "big"), n
+
+
 def test_product_arithmetic_host_crosscheck(tmp_path):
     """The kernels' own field / group sources (LWK_HD), compiled for the host: division-step inversion vs Fermat,
     28-bit-limb lazy field vs the 32-bit CIOS field, hot-loop XYZZ scalar multiplication vs the CIOS one
