@@ -578,12 +578,17 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
     // tail short although another call's waves take compute-unit slots away (60k instead of 53k proofs/s at 256 blobs)
     const int kFillEnv = knobs().direct_fill;
     const int kFill = kFillEnv ? kFillEnv : fill ? fill : 512;
-    if ((int)n_blobs <= coop_max_blobs() && !fill) {
-        // the cooperative kernel; `lane_scratch` takes the hand-off sums, the words behind the redo flags the hand-off counters
-        CoopParams prm{};
-        const int rpq = coop_rows_per_quad(plan.nw, n_blobs);
-        uint32_t units, counters;
-        coop_geometry(plan, rpq, prm.n0, units, counters);
+    // the cooperative kernel's hand-off lives in workspace that is idle on this path: a blob's sums in its slice of `lane_scratch` (4096
+    // XYZZ per blob), its counters in the words behind the redo flags (kNumBuckets + 1 per blob). Geometries that do not fit -- only
+    // reachable through the experiment knob LWKZG_COOP_RPQ (1 row per quad on a 16- or 20-window table: 4369 / 5461 units) -- take the
+    // throughput kernels instead of writing past the slice
+    CoopParams prm{};
+    const int rpq = coop_rows_per_quad(plan.nw, n_blobs ? n_blobs : 1);
+    uint32_t units = 0, counters = 0;
+    coop_geometry(plan, rpq, prm.n0, units, counters);
+    const bool coop_fits = units <= (uint32_t)kBlobElems && 1 + counters <= (uint32_t)kNumBuckets + 1;
+    if ((int)n_blobs <= coop_max_blobs() && !fill && coop_fits) {
+        // `lane_scratch` takes the hand-off sums, the words behind the redo flags the hand-off counters
         // K = (H - 1) * sum of 2^(C j) over the signed windows (all but the top one)
         for (int j = 0; j + 1 < plan.nw; j++) {
             const int bit = plan.c * j;

@@ -370,13 +370,16 @@ static C_KZG_RET chunk_host_functions(Ctx *c, const uint8_t *blobs, size_t n, hi
                                       hipMemcpyDeviceToHost, sc);
         if (e == hipSuccess) e = hipEventRecord(h.chunk_done[k], sc);
         if (e == hipSuccess) e = hipStreamWaitEvent(sf, h.chunk_done[k], 0);
+        bool queued = false;   // once the host function is in the queue args[k] is ITS to delete (a failing event record
+                               // behind a successful launch freed it here as well -- a use-after-free in the callback, then a double free)
         if (e == hipSuccess) {
             ProfScope p(prof_name, sf);
             e = hipLaunchHostFunc(sf, fn, args[k]);
+            queued = e == hipSuccess;
         }
-        if (e == hipSuccess && record_hashed) e = hipEventRecord(h.hashed[k], sf);   // (the host function itself is in the queue: args[k] is its now)
+        if (e == hipSuccess && record_hashed) e = hipEventRecord(h.hashed[k], sf);
         if (e != hipSuccess) {
-            for (size_t j = k; j < args.size(); j++) delete args[j];
+            for (size_t j = queued ? k + 1 : k; j < args.size(); j++) delete args[j];
             set_error("host-assisted challenge: %s", hipGetErrorString(e));
             (void)hipGetLastError();
             if (hipEventRecord(c->ev_join[kMaxSplit - 2], sc) == hipSuccess) hipStreamWaitEvent(join, c->ev_join[kMaxSplit - 2], 0);
@@ -767,7 +770,9 @@ static HFp hfp_from_limbs28(const uint32_t *l) {
             v >>= 64;
         }
     }
-    for (int shift = 3; shift >= 0; shift--) {  // minus 8p, 4p, 2p, p where that leaves it non-negative
+    // minus 2^16 p, ..., 2p, p where that leaves it non-negative: whatever lazy bound a producer leaves (14 limbs below 2^32 are an integer
+    // below 2^396 < 2^17 p), the result is the residue in [0, p) -- ADVICE r05: the four subtractions of r05 silently assumed < 16p
+    for (int shift = 16; shift >= 0; shift--) {
         uint64_t kp[7], d[7];
         for (int j = 0; j < 7; j++) {
             const uint64_t lo = j < 6 ? HFpPar::P[j] : 0, below = j > 0 ? HFpPar::P[j - 1] : 0;
@@ -1654,6 +1659,14 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
         launch_validate_commitments(d_comm, vb.canon_dev, vb.status_all, bad, n, sc, vb.pts_c, vb.kind_c, vb.verdict_c);
         launch_point_multiples(vb.pts_c, vb.kind_c, vb.mult_c, n, sc);
         LWK_HIP(hipEventRecord(c->ev_join[1], sc));
+    }
+    if (!apart && fused) {
+        // More than half the chip's compute units would hold a hash workgroup: the footprints cannot keep anything apart any more, and a
+        // hash workgroup is as slow as the slowest of its four barrier-coupled waves -- 16384 blobs: the hash 7.8 ms with the validation's
+        // waves among its own, 3.2 ms alone (profiles/r06_experiments.md section 3). The validation and the rows (~1.7 ms on the whole
+        // chip) therefore go first and the hash follows them.
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
+        LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
     }
     if (!knobs().verify_order) launch_challenge(d_blobs, d_comm, z, le, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));

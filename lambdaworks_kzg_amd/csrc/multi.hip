@@ -79,6 +79,28 @@ C_KZG_RET on_every_device(size_t parts, F f) {
     return C_KZG_OK;
 }
 
+// nothing may unwind across the C ABI: the entry points size host vectors by the number of devices and of blobs
+template <class F>
+C_KZG_RET guarded_multi(const char *what, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        set_error("%s: out of host memory", what);
+        return C_KZG_MALLOC;
+    } catch (...) {
+        set_error("%s: unexpected exception", what);
+        return C_KZG_ERROR;
+    }
+}
+
+// the shards of a verification are released on every way out of it
+struct ShardsGuard {
+    std::vector<LwkzgVerifyShard *> &v;
+    ~ShardsGuard() {
+        for (LwkzgVerifyShard *sh : v) lwkzg_verify_shard_free(sh);
+    }
+};
+
 bool devices_ok(const int *devices, size_t n) {
     if (!devices || n == 0 || n > 64) {
         set_error("lwkzg_multi: need 1 .. 64 device ordinals");
@@ -160,20 +182,22 @@ template <class Call>
 C_KZG_RET sharded_batch(const LwkzgMulti *m, size_t n, size_t *first_bad, Call call) {
     if (!m) return C_KZG_BADARGS;
     if (first_bad) *first_bad = (size_t)-1;
-    const size_t parts = m->s.size();
-    std::vector<size_t> bad(parts, (size_t)-1);
-    C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
-        size_t lo, hi;
-        shard_range(n, k, parts, lo, hi);
-        if (hi == lo) return C_KZG_OK;
-        size_t fb = (size_t)-1;
-        const int r = call(&m->s[k], lo, hi - lo, &fb);
-        if (r != C_KZG_OK && fb != (size_t)-1) bad[k] = lo + fb;
-        return r;
+    return guarded_multi("lwkzg_multi batch", [&]() -> C_KZG_RET {
+        const size_t parts = m->s.size();
+        std::vector<size_t> bad(parts, (size_t)-1);
+        C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
+            size_t lo, hi;
+            shard_range(n, k, parts, lo, hi);
+            if (hi == lo) return C_KZG_OK;
+            size_t fb = (size_t)-1;
+            const int r = call(&m->s[k], lo, hi - lo, &fb);
+            if (r != C_KZG_OK && fb != (size_t)-1) bad[k] = lo + fb;
+            return r;
+        });
+        if (first_bad)
+            for (size_t k = 0; k < parts && *first_bad == (size_t)-1; k++) *first_bad = bad[k];
+        return rc;
     });
-    if (first_bad)
-        for (size_t k = 0; k < parts && *first_bad == (size_t)-1; k++) *first_bad = bad[k];
-    return rc;
 }
 
 }  // namespace
@@ -255,38 +279,40 @@ template <class Call>
 C_KZG_RET sharded_device_batch(const LwkzgMulti *m, const size_t *n_per_device, size_t *first_bad, Call call) {
     if (!m || !n_per_device) return C_KZG_BADARGS;
     if (first_bad) *first_bad = (size_t)-1;
-    const size_t parts = m->s.size();
-    std::vector<size_t> bad(parts, (size_t)-1);
-    C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
-        const size_t cnt = n_per_device[k];
-        if (!cnt) return C_KZG_OK;
-        LWK_HIP(hipSetDevice(m->dev[k]));
-        int32_t *d_status = nullptr;
-        LWK_HIP(hipMalloc((void **)&d_status, cnt * sizeof(int32_t)));
-        std::vector<int32_t> h(cnt);
-        int r = call(k, cnt, d_status);
-        if (r == C_KZG_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), d_status, cnt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)) {
-            set_error("device %d: %s", m->dev[k], hipGetErrorString(hipGetLastError()));
-            r = C_KZG_ERROR;
-        }
-        hipFree(d_status);
-        if (r != C_KZG_OK) return r;
-        for (size_t i = 0; i < cnt; i++)
-            if (h[i] != 0) {
-                bad[k] = i;
-                set_error("blob %zu of device %d's shard rejected (status %d)", i, m->dev[k], h[i]);
-                return h[i];   // (the status words are C_KZG_RET values: ERROR in reference mode, BADARGS in c-kzg mode)
+    return guarded_multi("lwkzg_multi device batch", [&]() -> C_KZG_RET {
+        const size_t parts = m->s.size();
+        std::vector<size_t> bad(parts, (size_t)-1);
+        C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
+            const size_t cnt = n_per_device[k];
+            if (!cnt) return C_KZG_OK;
+            std::vector<int32_t> h(cnt);   // (before the device allocation: a bad_alloc here must not leak it)
+            LWK_HIP(hipSetDevice(m->dev[k]));
+            int32_t *d_status = nullptr;
+            LWK_HIP(hipMalloc((void **)&d_status, cnt * sizeof(int32_t)));
+            int r = call(k, cnt, d_status);
+            if (r == C_KZG_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), d_status, cnt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)) {
+                set_error("device %d: %s", m->dev[k], hipGetErrorString(hipGetLastError()));
+                r = C_KZG_ERROR;
             }
-        return C_KZG_OK;
-    });
-    if (first_bad) {
-        size_t base = 0;
-        for (size_t k = 0; k < parts && *first_bad == (size_t)-1; k++) {
-            if (bad[k] != (size_t)-1) *first_bad = base + bad[k];
-            base += n_per_device[k];
+            hipFree(d_status);
+            if (r != C_KZG_OK) return r;
+            for (size_t i = 0; i < cnt; i++)
+                if (h[i] != 0) {
+                    bad[k] = i;
+                    set_error("blob %zu of device %d's shard rejected (status %d)", i, m->dev[k], h[i]);
+                    return h[i];   // (the status words are C_KZG_RET values: ERROR in reference mode, BADARGS in c-kzg mode)
+                }
+            return C_KZG_OK;
+        });
+        if (first_bad) {
+            size_t base = 0;
+            for (size_t k = 0; k < parts && *first_bad == (size_t)-1; k++) {
+                if (bad[k] != (size_t)-1) *first_bad = base + bad[k];
+                base += n_per_device[k];
+            }
         }
-    }
-    return rc;
+        return rc;
+    });
 }
 }  // namespace
 extern "C" {
@@ -314,30 +340,26 @@ C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch_device(bool *ok, const void *c
     if (!ok) return C_KZG_BADARGS;
     *ok = false;
     if (!m || !blobs_dev || !commitments48_dev || !proofs48_dev || !n_per_device) return C_KZG_BADARGS;
-    const size_t parts = m->s.size();
-    std::vector<LwkzgVerifyShard *> shard(parts, nullptr);
-    std::vector<size_t> first(parts + 1, 0);
-    for (size_t k = 0; k < parts; k++) first[k + 1] = first[k] + n_per_device[k];
-    const size_t n = first[parts];
-    if (n == 0) return verify_blob_kzg_proof_batch(ok, nullptr, nullptr, nullptr, 0, &m->s[0]);   // (the empty batch's mode-dependent verdict)
-    std::vector<uint8_t> records, partials;
-    try {
-        records.resize(n * LWKZG_VERIFY_RECORD_BYTES + 1);
-        partials.resize(parts * LWKZG_VERIFY_PARTIAL_BYTES);
-    } catch (const std::bad_alloc &) {
-        return C_KZG_MALLOC;
-    }
-    C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
-        return lwkzg_verify_shard_begin_device(&shard[k], records.data() + first[k] * LWKZG_VERIFY_RECORD_BYTES, blobs_dev[k], commitments48_dev[k],
-                                               proofs48_dev[k], n_per_device[k], &m->s[k], nullptr);
-    });
-    if (rc == C_KZG_OK)
-        rc = on_every_device(parts, [&](size_t k) -> int {
-            return lwkzg_verify_shard_partial(partials.data() + k * LWKZG_VERIFY_PARTIAL_BYTES, shard[k], records.data(), n, first[k]);
+    return guarded_multi("lwkzg_multi_verify_blob_kzg_proof_batch_device", [&]() -> C_KZG_RET {
+        const size_t parts = m->s.size();
+        std::vector<LwkzgVerifyShard *> shard(parts, nullptr);
+        ShardsGuard free_shards{shard};
+        std::vector<size_t> first(parts + 1, 0);
+        for (size_t k = 0; k < parts; k++) first[k + 1] = first[k] + n_per_device[k];
+        const size_t n = first[parts];
+        if (n == 0) return verify_blob_kzg_proof_batch(ok, nullptr, nullptr, nullptr, 0, &m->s[0]);   // (the empty batch's mode-dependent verdict)
+        std::vector<uint8_t> records(n * LWKZG_VERIFY_RECORD_BYTES + 1), partials(parts * LWKZG_VERIFY_PARTIAL_BYTES);
+        C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
+            return lwkzg_verify_shard_begin_device(&shard[k], records.data() + first[k] * LWKZG_VERIFY_RECORD_BYTES, blobs_dev[k], commitments48_dev[k],
+                                                   proofs48_dev[k], n_per_device[k], &m->s[k], nullptr);
         });
-    for (LwkzgVerifyShard *sh : shard) lwkzg_verify_shard_free(sh);
-    if (rc != C_KZG_OK) return rc;
-    return lwkzg_verify_shards_finish(ok, partials.data(), parts, n, &m->s[0]);
+        if (rc == C_KZG_OK)
+            rc = on_every_device(parts, [&](size_t k) -> int {
+                return lwkzg_verify_shard_partial(partials.data() + k * LWKZG_VERIFY_PARTIAL_BYTES, shard[k], records.data(), n, first[k]);
+            });
+        if (rc != C_KZG_OK) return rc;
+        return lwkzg_verify_shards_finish(ok, partials.data(), parts, n, &m->s[0]);
+    });
 }
 
 // verify_blob_kzg_proof_batch (src/lib.rs:525-692) over the devices: per-blob work sharded, ONE r, ONE linear combination, ONE pairing check
@@ -346,37 +368,33 @@ C_KZG_RET lwkzg_multi_verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, c
     if (!ok) return C_KZG_BADARGS;
     *ok = false;
     if (!m || ((!blobs || !commitments || !proofs) && n)) return C_KZG_BADARGS;
-    const size_t parts = m->s.size();
-    std::vector<LwkzgVerifyShard *> shard(parts, nullptr);
-    std::vector<uint8_t> records, partials;
-    C_KZG_RET rc = C_KZG_OK;
-    try {
-        records.resize(n * LWKZG_VERIFY_RECORD_BYTES + 1);
-        partials.resize(parts * LWKZG_VERIFY_PARTIAL_BYTES);
-    } catch (const std::bad_alloc &) {
-        return C_KZG_MALLOC;
-    }
-    rc = on_every_device(parts, [&](size_t k) -> int {
-        size_t lo, hi;
-        shard_range(n, k, parts, lo, hi);
-        return lwkzg_verify_shard_begin(&shard[k], records.data() + lo * LWKZG_VERIFY_RECORD_BYTES, blobs + lo, commitments + lo, proofs + lo, hi - lo,
-                                        &m->s[k]);
-    });
-    if (rc == C_KZG_OK)   // (the "all-gather" of the records: they already sit in one host array)
-        rc = on_every_device(parts, [&](size_t k) -> int {
+    return guarded_multi("lwkzg_multi_verify_blob_kzg_proof_batch", [&]() -> C_KZG_RET {
+        const size_t parts = m->s.size();
+        std::vector<LwkzgVerifyShard *> shard(parts, nullptr);
+        ShardsGuard free_shards{shard};
+        std::vector<uint8_t> records(n * LWKZG_VERIFY_RECORD_BYTES + 1), partials(parts * LWKZG_VERIFY_PARTIAL_BYTES);
+        C_KZG_RET rc = on_every_device(parts, [&](size_t k) -> int {
             size_t lo, hi;
             shard_range(n, k, parts, lo, hi);
-            return lwkzg_verify_shard_partial(partials.data() + k * LWKZG_VERIFY_PARTIAL_BYTES, shard[k], records.data(), n, lo);
+            return lwkzg_verify_shard_begin(&shard[k], records.data() + lo * LWKZG_VERIFY_RECORD_BYTES, blobs + lo, commitments + lo, proofs + lo, hi - lo,
+                                            &m->s[k]);
         });
-    for (LwkzgVerifyShard *sh : shard) lwkzg_verify_shard_free(sh);
-    if (rc != C_KZG_OK) return rc;
-    return lwkzg_verify_shards_finish(ok, partials.data(), parts, n, &m->s[0]);
+        if (rc == C_KZG_OK)   // (the "all-gather" of the records: they already sit in one host array)
+            rc = on_every_device(parts, [&](size_t k) -> int {
+                size_t lo, hi;
+                shard_range(n, k, parts, lo, hi);
+                return lwkzg_verify_shard_partial(partials.data() + k * LWKZG_VERIFY_PARTIAL_BYTES, shard[k], records.data(), n, lo);
+            });
+        if (rc != C_KZG_OK) return rc;
+        return lwkzg_verify_shards_finish(ok, partials.data(), parts, n, &m->s[0]);
+    });
 }
 
 // BASELINE configs[4]: out = sum_k scalars[k] * g1[k mod 4096] over n_terms (a positive multiple of 4096) host-resident big-endian
 // scalars: whole tiles per device, one 48-byte partial sum back from each, added on the host.
 C_KZG_RET lwkzg_multi_g1_msm_tiled(uint8_t out48[48], const uint8_t *scalars_be, size_t n_terms, const LwkzgMulti *m) {
     if (!m || !out48 || !scalars_be || n_terms == 0 || n_terms % 4096) return C_KZG_BADARGS;
+    return guarded_multi("lwkzg_multi_g1_msm_tiled", [&]() -> C_KZG_RET {
     const size_t parts = m->s.size(), tiles = n_terms / 4096;
     std::vector<uint8_t> partial(parts * 48, 0);
     std::vector<int> have(parts, 0);
@@ -408,6 +426,7 @@ C_KZG_RET lwkzg_multi_g1_msm_tiled(uint8_t out48[48], const uint8_t *scalars_be,
     for (size_t k = 0; k < parts; k++)
         if (have[k]) pts.insert(pts.end(), partial.begin() + k * 48, partial.begin() + k * 48 + 48);
     return lwkzg_g1_sum_compressed(out48, pts.data(), pts.size() / 48);
+    });
 }
 
 }  // extern "C"

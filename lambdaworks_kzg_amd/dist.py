@@ -19,8 +19,12 @@ def shard_range(n_items, world_size, rank):
     Returns (start, count) for `rank`; the shards cover [0, n_items) exactly once."""
     if world_size <= 0 or not (0 <= rank < world_size):
         raise ValueError("bad rank/world_size")
-    # ONE rule for the C library's node-level entry points (csrc/multi.hip) and for this module: the library's own function
-    return capi.shard_range(n_items, world_size, rank)
+    # ONE rule for the C library's node-level entry points (csrc/multi.hip: lwkzg_shard_range) and for this module: part k owns
+    # [ceil(k n / G), ceil((k + 1) n / G)). Closed form here -- a launcher or a CPU-only rank that only wants its slice must not need the
+    # native library (ADVICE r05); tests/test_capi_cpu.py::test_one_shard_rule_from_c_and_python holds the two against each other.
+    lo = -(-rank * n_items // world_size)
+    hi = -(-(rank + 1) * n_items // world_size)
+    return lo, hi - lo
 
 
 def owner_of(item, n_items, world_size):

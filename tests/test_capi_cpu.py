@@ -228,9 +228,9 @@ def test_c_consumers_compile_and_link_against_the_header_and_library(tmp_path):
 def test_one_shard_rule_from_c_and_python(tmp_path):
     """csrc/multi.hip cut its shards at floor(n k / G) while dist.py and the header said ceil -- both contiguous, two rules
     for one contract. There is ONE function now (lwkzg_shard_range: part k owns [ceil(k n / G), ceil((k + 1) n / G)), i.e. item i belongs
-    to part floor(i G / n)); multi.hip uses it, dist.shard_range calls it. A C program prints it for fewer items than parts, one more
+    to part floor(i G / n)); multi.hip uses it, dist.shard_range states the same closed form (no native library needed to compute a slice: ADVICE r05) and capi.shard_range is the binding. A C program prints it for fewer items than parts, one more
     than parts, none at all, and the bench's shapes; the closed form and the Python binding must agree line by line."""
-    from lambdaworks_kzg_amd import dist as D
+    from lambdaworks_kzg_amd import capi, dist as D
     lib_dir = os.path.join(ROOT, "lambdaworks_kzg_amd", "lib")
     exe = str(tmp_path / "shard_rule")
     subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
@@ -243,7 +243,7 @@ def test_one_shard_rule_from_c_and_python(tmp_path):
     for n, g, k, first, count in rows:
         lo, hi = -(-k * n // g), -(-(k + 1) * n // g)
         assert (first, count) == (lo, hi - lo), (n, g, k)
-        assert D.shard_range(n, g, k) == (first, count)
+        assert D.shard_range(n, g, k) == (first, count) == capi.shard_range(n, g, k)
         for i in range(first, first + count):
             assert D.owner_of(i, n, g) == k == i * g // n
     src = open(os.path.join(ROOT, "lambdaworks_kzg_amd", "csrc", "multi.hip")).read()

@@ -232,3 +232,25 @@ def test_bench_gpus_2_without_a_launcher(tmp_path):
     assert line["roofline"]["kernel"].startswith("k_direct_accumulate") and line["roofline"]["avg_launch_ms"] > 0
     detail = json.load(open(env["LWKZG_BENCH_DETAIL"]))
     assert detail["value"] == pytest.approx(line["value"], rel=1e-5) and "scaling_note" in detail
+
+
+def test_bench_gpus_8_rehearsal_on_one_device(tmp_path):
+    """VERDICT r05 item 2, "rehearse first contact": the command the driver runs on an 8-GPU node, with its EIGHT ranks on this one
+    device over gloo (RCCL refuses several ranks per device), the bucket engine (eight 41 GB tables do not fit one device) and a small
+    batch. What it pins: eight ranks rendezvous, the setup image is broadcast once and imported seven times, every rank times its own
+    shard, rank 0's line aggregates eight per-rank values and says dist.ranks == 8. NOT a scaling number: eight ranks share one GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LWKZG_BENCH_DETAIL=str(tmp_path / "detail8.json"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LWKZG_MODE", "LWKZG_DIRECT_BITS"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--direct-bits", "0", "--no-extra-legs", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-4000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8000, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    d = line["dist"]
+    assert d["initialised"] is True and d["ranks"] == 8 and d["backend"] == "gloo"
+    assert len(d["per_rank_value"]) == 8 and all(v > 0 for v in d["per_rank_value"]) and len(d["devices"]) == 8
+    assert line["config"]["direct_bits"] == 0

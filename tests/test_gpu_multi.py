@@ -194,3 +194,39 @@ def test_multi_device_resident_shards(K, single, multi, counts_of):
     assert e.value.rc == K.C_KZG_ERROR and multi.first_bad.value == bad_at
     with pytest.raises(K.KzgError):
         multi.verify_blob_kzg_proof_batch_device(ptr(d_blobs), ptr(d_comm), ptr(d_proof), counts)
+
+
+def test_eight_contexts_on_one_device(K, single):
+    """lwkzg_multi_load with EIGHT entries -- the node's shape -- here all on device 0 (fresh process, 10-bit tables:
+    eight default tables do not fit one device). Uneven shards (70 blobs over eight contexts), the one-r batch verification over eight
+    shards, eight partial sums of the tiled MSM: bytes and verdicts of the single-device calls."""
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import blobs as B, lambdaworks_kzg_amd as K\n"
+        "from lambdaworks_kzg_amd import capi\n"
+        "m = capi.MultiSetup.from_file(%r, [0] * 8)\n"
+        "assert m.device_count() == 8 and m.devices() == [0] * 8\n"
+        "data = B.synthetic_batch(84000, 70)\n"
+        "c = m.blob_to_kzg_commitment_batch(data); p = m.compute_blob_kzg_proof_batch(data, b''.join(c))\n"
+        "ok = m.verify_blob_kzg_proof_batch(data, b''.join(c), b''.join(p), 70)\n"
+        "bad = m.verify_blob_kzg_proof_batch(data, b''.join(c), b''.join(p[1:] + p[:1]), 70)\n"
+        "t = m.g1_msm_tiled(B.synthetic_batch(84100, 9))\n"
+        "print(b''.join(c).hex(), b''.join(p).hex(), ok, bad, t.hex()); m.free()\n"
+    ) % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH)
+    env = dict(os.environ, LWKZG_DIRECT_BITS="10")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode().split()
+    c_hex, p_hex, ok, bad, t_hex = out[-5:]
+    data = B.synthetic_batch(84000, 70)
+    want_c = K.blob_to_kzg_commitment_batch(data, single)
+    want_p = K.compute_blob_kzg_proof_batch(data, b"".join(want_c), single)
+    assert c_hex == b"".join(want_c).hex() and p_hex == b"".join(want_p).hex()
+    assert ok == "True" and bad == "False"
+    import torch
+    from lambdaworks_kzg_amd import capi
+    sc = B.synthetic_batch(84100, 9)
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    d_out = torch.empty(48, dtype=torch.uint8, device="cuda")
+    capi.g1_msm_tiled_device(d_out.data_ptr(), d_sc.data_ptr(), 9 * 4096, single)
+    torch.cuda.synchronize()
+    assert t_hex == bytes(d_out.cpu().numpy().tobytes()).hex()
