@@ -380,6 +380,11 @@ size_t lwkzg_timing_report(const KZGSettings *s, char *buf, size_t cap);
  * list the variable names; experiment knobs (A/B arms of measurements) are honoured only with LWKZG_EXPERIMENTAL=1 and are otherwise
  * ignored (reported under LWKZG_VERBOSE). Returns bytes needed (incl. NUL). INTEGRATION.md section 5 documents the operational ones. */
 size_t lwkzg_knob_report(char *buf, size_t cap);
+/* Test hook: the schedule (csrc/plan.h: ProofSchedule, 0 = small-host .. 4 = GPU chains) the most recent
+ * lwkzg_compute_blob_kzg_proof_batch_device call of this process took, -1 before the first. tests/test_gpu_plan.py forces each schedule
+ * once (LWKZG_EXPERIMENTAL=1 LWKZG_PROOF_SCHEDULE=k) and reads it back. */
+int lwkzg_last_proof_schedule(void);
+
 /* First use of the HIP runtime by this process (device context + this library's code object), so that a caller can pay
  * and time it apart from its first real call. 0, or -1 without a GPU. */
 int lwkzg_runtime_init(void);

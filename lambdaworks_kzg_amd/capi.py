@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "lwkzg_challenge_digests_host", "lwkzg_batch_challenge_host", "lwkzg_g1_msm_tiled_device", "lwkzg_g1_sum_compressed",
     "lwkzg_commit_and_prove_batch_device", "lwkzg_enable_direct_table", "lwkzg_direct_table_bits", "lwkzg_direct_table_forms", "lwkzg_enable_direct_table_forms", "lwkzg_direct_num_windows", "lwkzg_direct_row_bytes",
     "lwkzg_compute_challenges_device",
-    "lwkzg_timing_report", "lwkzg_runtime_init", "lwkzg_knob_report",
+    "lwkzg_timing_report", "lwkzg_runtime_init", "lwkzg_knob_report", "lwkzg_last_proof_schedule",
     "lwkzg_multi_load", "lwkzg_multi_load_file", "lwkzg_multi_free", "lwkzg_multi_device_count", "lwkzg_multi_device", "lwkzg_multi_settings",
     "lwkzg_multi_set_mode", "lwkzg_multi_enable_direct_table", "lwkzg_multi_blob_to_kzg_commitment_batch",
     "lwkzg_multi_compute_blob_kzg_proof_batch", "lwkzg_multi_compute_kzg_proof_batch", "lwkzg_multi_verify_blob_kzg_proof_batch",
@@ -200,6 +200,11 @@ def set_mode(mode):
 
 def get_mode():
     return lib().lwkzg_get_mode()
+
+
+def last_proof_schedule():
+    """the schedule (csrc/plan.h: ProofSchedule) the last device-resident blob-proof call of this process took; -1 before the first"""
+    return int(lib().lwkzg_last_proof_schedule())
 
 
 def knob_report():

@@ -17,6 +17,7 @@ namespace lwk {
 
 constexpr uint64_t kCtxMagic = 0x4c574b5a47414d44ull;  // "LWKZGAMD"
 constexpr size_t kMaxChunk = 1024;                      // blobs per launch set
+static_assert(kMaxChunk == kPlanMaxChunk, "plan.h plans in the engine's chunks");
 constexpr int kMaxSplit = 8;                            // sub-batches (streams) a launch set may be cut into
 
 void set_error(const char *fmt, ...);
@@ -218,6 +219,21 @@ struct LagrangeForm {
 };
 
 // The object KZGSettings.fs points to. Its first member is a genuine FFTSettings.
+// Device-side double buffer of the long host-pointer batches (r06; /root/reference/fuzz/base_fuzz.h:17-34 is that kind of caller: plain
+// host arrays). r05 cut such a batch into slices of 512 blobs on two streams and two workspace halves, so that the upload of one slice ran
+// beside the compute of the other -- and paid for it with 512-blob launches (two workgroups per blob, a fold per slice: 77k ops/s where a
+// 1024-blob launch does 92k). What the measurements say (profiles/r06_h2d_bench.txt): a hipMemcpy from pageable memory runs at 56 GB/s once
+// the pages have been touched (13 GB/s the first time), as fast as from pinned memory -- the upload was never the bottleneck, the slice
+// size was. So: slice k is uploaded into slot k mod 2 of this buffer on a copy stream of its own, and the SAME device-resident pipeline
+// that a device pointer would get (commit_batch_device: whole chunks of up to 1024 blobs, one compute stream) reads it from there; the
+// upload of slice k + 1 runs beside the compute of slice k, and a slot is reused once the parse of its previous occupant has run.
+// 2 x 1024 blobs = 256 MiB of device memory per context, allocated by the first long batch and kept.
+struct DevStage {
+    uint8_t *slot[2] = {nullptr, nullptr};
+    hipEvent_t copied[2] = {nullptr, nullptr}, parsed[2] = {nullptr, nullptr};
+    bool ready = false, failed = false;
+};
+
 struct Ctx {
     FFTSettings fs;
     uint64_t magic;
@@ -261,6 +277,9 @@ struct Ctx {
     Fr28 *tw28_fwd, *tw28_inv;  // the same twiddles in the transform's own arithmetic (fr28.cuh)
     Workspace ws;
     SmallProofHost sph;
+    DevStage stage;     // under mu
+    uint8_t *host_res = nullptr;   // results / verdicts / digests of a long host-pointer batch on the device (grow-only, under mu):
+    size_t host_res_cap = 0;       // r05 allocated and freed them per call, 6 ms of a 52 ms call of 4096 blobs (profiles/r06_experiments.md section 6)
     VerifyBuffers vs;   // verify-side scratch, sized for vs_cap blobs
     size_t vs_cap;
     std::mutex verify_mu;

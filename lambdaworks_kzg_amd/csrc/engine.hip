@@ -249,6 +249,7 @@ static void sph_free(SmallProofHost &h) {
 // host threads (0 = never). Default 64 since r05 (the GPU's validation went from 2.0 to 1.1 ms: at 128 blobs the mid-size path below takes 2.9 ms where this one
 // takes 3.6, at 64 both 2.25, at 16 this one 1.2 against 1.8; gpurun_out r05/gpu14); r04's table, when the default was 128 (default engine, same box, ms per call with / without: 1 blob 0.80 / 3.62, 16: 0.87 / 3.61, 64: 1.96 / 4.29,
 // 128: 3.41 / 5.05, 256: 6.43 / 6.68 -- beyond that the copy out and the host threads cost what the GPU chains did; gpurun_out r04c).
+static std::atomic<int> g_last_proof_schedule{-1};   // test hook (lwkzg_last_proof_schedule): the schedule the last device-resident proof call took
 static size_t small_proof_host_limit() {
     const size_t x = knobs().small_proof_host;
     return x > kMaxChunk ? kMaxChunk : x;
@@ -293,6 +294,19 @@ static size_t mid_proof_chunks() {   // experiment knob: host functions (= chunk
 static size_t mid_proof_host_limit() {
     const size_t x = knobs().mid_proof_host;
     return x > kMaxChunk ? kMaxChunk : x;
+}
+
+// the knobs a plan depends on, clamped as the engine uses them (plan.h: PlanKnobs)
+static PlanKnobs plan_knobs() {
+    PlanKnobs k;
+    k.small_proof_host = small_proof_host_limit();
+    k.mid_proof_host = mid_proof_host_limit();
+    k.mid_proof_chunks = mid_proof_chunks();
+    k.mid_proof_pipe = knobs().mid_proof_pipe;
+    k.mid_proof_pipe_min = knobs().mid_proof_pipe_min;
+    k.mid_proof_parts = knobs().mid_proof_parts;
+    k.heavy_serial = knobs().heavy_serial;
+    return k;
 }
 
 // Are the host threads warm? The mid-size host-assisted challenge (hashing on the host threads, pipelined with the copy out) beats
@@ -458,6 +472,12 @@ static void ctx_destroy(Ctx *c) {
         if (c->comb.pinned_status[k]) hipHostFree(c->comb.pinned_status[k]);
     }
     if (c->comb.pinned_blobs) hipHostFree(c->comb.pinned_blobs);
+    dev_free(c->host_res);
+    for (int k = 0; k < 2; k++) {
+        dev_free(c->stage.slot[k]);
+        if (c->stage.copied[k]) hipEventDestroy(c->stage.copied[k]);
+        if (c->stage.parsed[k]) hipEventDestroy(c->stage.parsed[k]);
+    }
     sph_free(c->sph);
     free(c->fs.expanded_roots_of_unity);
     free(c->fs.reverse_roots_of_unity);
@@ -948,9 +968,37 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
     // blobs of the call are hashed optimistically from the caller's bytes on `st` while the validation stream
     // validates all commitments, then only the lanes whose canonical bytes differ are redone. A call of several chunks
     // therefore pays the two chains once, not once per chunk.
+    // WHICH schedule runs in front of the MSM is a pure function of the batch, the host threads' warmth, the other context's state, the
+    // table forms and the knobs (plan.h: plan_proof_call; the table is pinned by tests/test_plan_cpu.py). The engine's part: the inputs,
+    // the pinned staging the host-assisted schedules need (asked for only when the plan wants it; if it cannot be had the plan is taken
+    // again without it), and the launches.
+    const bool evf = proof_in_evaluation_form(c, mode);   // (then the quotient's MSM runs on the Lagrange form's table)
+    const bool msm_direct = evf ? c->lag.direct_table != nullptr : c->direct_table && !proof_on_lagrange(c, mode);
+    const bool warm = host_assist_warm(), busy = peer_busy(c);
+    const PlanKnobs pk = plan_knobs();
+    ProofPlan plan = plan_proof_call(n, warm, busy, msm_direct, true, pk);
+    const int forced = knobs().proof_schedule;   // experiment: tests/test_gpu_plan.py runs every schedule once on the same inputs
+    if (forced >= 0 && forced <= kProofGpuChains && n <= kMaxChunk) {
+        PlanKnobs fk = pk;
+        fk.small_proof_host = forced == kProofSmallHost ? kMaxChunk : 0;
+        fk.mid_proof_host = forced == kProofSmallHost || forced == kProofGpuChains ? 0 : kMaxChunk;
+        fk.mid_proof_pipe = forced == kProofMidPiped;
+        fk.mid_proof_pipe_min = 0;
+        plan = plan_proof_call(n, forced != kProofMidCold, false, forced == kProofMidPiped ? msm_direct : false, true, fk);
+    }
     SmallProofArgs *host_args = nullptr;
-    if (n <= small_proof_host_limit() && sph_reserve(c, n)) host_args = new (std::nothrow) SmallProofArgs{&c->sph, n, le ? kStatusBadArgs : kStatusError};
-    if (host_args) {
+    if (plan.needs_staging()) {
+        bool ok = sph_reserve(c, n);
+        if (ok && plan.schedule == kProofSmallHost) {
+            host_args = new (std::nothrow) SmallProofArgs{&c->sph, n, le ? kStatusBadArgs : kStatusError};
+            ok = host_args != nullptr;
+        }
+        if (!ok) plan = plan_proof_call(n, warm, busy, msm_direct, false, pk);
+    }
+    g_last_proof_schedule.store((int)plan.schedule, std::memory_order_relaxed);
+    const bool piped = plan.schedule == kProofMidPiped;
+    switch (plan.schedule) {
+    case kProofSmallHost: {
         // A small call: both chains above cost their full 2-3 ms for a handful of blobs, and the host does the same work in a tenth
         // of that (3.63 ms device-resident against 0.82 ms through the host-pointer ABI at one blob). The blobs and
         // commitments go out to pinned memory, a host function hashes and validates them on the host threads IN STREAM ORDER (the
@@ -973,7 +1021,9 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         LWK_HIP(hipMemcpyAsync(canon, h.canon, n * 48, hipMemcpyHostToDevice, st));
         launch_z_from_bytes(w.zbytes, z, nullptr, le, n, st);  // digest -> Fr, reduced (utils.rs:148-154)
         launch_challenge(blobs, canon, z, le, n, st, comm48);
-    } else if (n <= mid_proof_host_limit() && !peer_busy(c) && !host_assist_warm()) {
+        break;
+    }
+    case kProofMidCold: {
         // mid-size call, host threads cold: the GPU's hash kernel this once, and a nudge for the threads on the side stream
         LWK_HIP(hipEventRecord(c->ev_fork, st));
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
@@ -986,7 +1036,10 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         launch_challenge(blobs, comm48, z, le, n, st);
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge(blobs, canon, z, le, n, st, comm48);
-    } else if (n <= mid_proof_host_limit() && !peer_busy(c) && sph_reserve(c, n)) {
+        break;
+    }
+    case kProofMidHost:
+    case kProofMidPiped: {
         // mid-size call on a settings object whose other context is idle (a producer that alternates two caller streams hides the GPU's hash
         // behind the other call's MSM at no cost, and two calls' host hashing would queue for the same host threads: 70.9k against 49.7k
         // proofs/s at 256 blobs on two streams -- there the hash kernel stays): the validation on the GPU's side stream as in the large path; the hashing on the host threads, chunk by chunk
@@ -999,12 +1052,9 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         // bytes, and once the validation's canonical bytes exist a blob whose bytes were NOT canonical (a valid point in an exotic
         // encoding: infinity with stray bits) gets its challenge, quotient and MSM again in a second pass that exits at its first
         // instruction for every other blob. 256 blobs: hash 2.1 ms -> MSM 2.3 ms in series becomes 1.05 -> 1.2 || 1.05 -> 1.2.
-        const bool pipe_on = knobs().mid_proof_pipe;
-        const size_t chunks = (n + ((n + mid_proof_chunks() - 1) / mid_proof_chunks()) - 1) / ((n + mid_proof_chunks() - 1) / mid_proof_chunks());
-        const size_t pipe_min = knobs().mid_proof_pipe_min;   // (128 blobs: 3.3 ms pipelined, 2.9 not)
-        const bool evf = proof_in_evaluation_form(c, mode);   // (then the quotient's MSM runs on the Lagrange form's table)
-        const bool piped = pipe_on && (evf ? c->lag.direct_table != nullptr : c->direct_table && !proof_on_lagrange(c, mode)) && n >= pipe_min &&
-                           chunks >= 2 && chunks % 2 == 0 && n <= kMaxChunk;
+        // (plan.h decides `piped`: the knob, a direct table under the quotient's MSM, at least mid_proof_pipe_min blobs -- 128 blobs: 3.3 ms
+        // pipelined, 2.9 not --, an even number of chunks, one launch set)
+        const size_t chunks = plan.chunks;
         LWK_HIP(hipEventRecord(c->ev_fork, st));
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
         LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
@@ -1021,13 +1071,11 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
             }
         }
         if (piped) {
-            const size_t per = (n + mid_proof_chunks() - 1) / mid_proof_chunks();
+            const size_t per = plan.per_chunk;
             // sub-batches of whole chunks, alternating between the call's stream and a second one: a sub-batch's quotient and MSM start
             // when ITS chunks are hashed, and its latency-shaped folds run beside the next sub-batch's accumulation
-            const size_t parts_env = knobs().mid_proof_parts;
-            // (four measured best at 256 while the validation took 2 ms; with 1.1 ms of it two win there, 61.9k against 59.7k proofs/s; at 384 four: 66.0k against 63.7k)
-            size_t parts = parts_env ? parts_env : (n >= 320 ? 4 : 2);
-            while (parts > 1 && chunks % parts) parts--;
+            // (plan.h: four measured best at 256 while the validation took 2 ms; with 1.1 ms of it two win there, 61.9k against 59.7k proofs/s; at 384 four: 66.0k against 63.7k)
+            const size_t parts = plan.parts;
             const size_t cps = chunks / parts;   // chunks per sub-batch
             uint32_t *differs = w.perm;   // (bucket-engine scratch, idle on a direct table: one word per blob)
             hipStream_t s2 = c->aux[2];
@@ -1060,7 +1108,9 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         launch_z_from_bytes(w.zbytes, z, nullptr, le, n, st);  // digest -> Fr, reduced (utils.rs:148-154)
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge(blobs, canon, z, le, n, st, comm48);   // only the lanes whose canonical commitment bytes differ from the caller's
-    } else {
+        break;
+    }
+    case kProofGpuChains: {
         LWK_HIP(hipEventRecord(c->ev_fork, st));
         LWK_HIP(hipStreamWaitEvent(c->vstream, c->ev_fork, 0));
         launch_validate_commitments(comm48, canon, stt, le ? kStatusBadArgs : kStatusError, n, c->vstream, longcall ? w.val_pts_long : w.val_pts,
@@ -1069,14 +1119,15 @@ C_KZG_RET blob_proof_batch_device(Ctx *c, uint8_t *out48, const uint8_t *blobs, 
         launch_challenge(blobs, comm48, z, le, n, st);
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         launch_challenge(blobs, canon, z, le, n, st, comm48);
+        break;
+    }
     }
     // the ALU-bound phase: in turns with the settings' other context (engine.h: heavy_done), so that THIS call's hash
     // above ran beside the other call's MSM and the other call's next hash runs beside this one
     Ctx *pr = c->primary;
     // (up to half a chunk: there the MSM is about as long as the hash and the two pipelines would phase-lock; a longer
     // MSM covers the other call's hash by itself, and taking turns only adds bubbles -- 81k against 90k proofs/s at 1024)
-    const int hs_env = knobs().heavy_serial;
-    const bool heavy_serial = hs_env >= 0 ? hs_env != 0 : n <= kMaxChunk / 2;
+    const bool heavy_serial = plan.heavy_serial;
     if (heavy_serial) {
         std::lock_guard<std::mutex> hk(pr->heavy_mu);
         LWK_HIP(hipStreamWaitEvent(st, pr->heavy_done, 0));
@@ -1319,6 +1370,72 @@ static C_KZG_RET vs_reserve(Ctx *c, size_t n) {
     return C_KZG_OK;
 }
 
+// device memory for the results of a long host-pointer batch: the context's own grow-only block (no hipMalloc / hipFree inside a call: both
+// are synchronous and cost milliseconds). Caller holds c->mu; nullptr when the memory cannot be had.
+static uint8_t *host_res_block(Ctx *c, size_t bytes) {
+    if (c->host_res_cap >= bytes) return c->host_res;
+    (void)hipDeviceSynchronize();
+    dev_free(c->host_res);
+    c->host_res = nullptr;
+    c->host_res_cap = 0;
+    size_t cap = (size_t)1 << 20;
+    while (cap < bytes) cap <<= 1;
+    if (hipMalloc((void **)&c->host_res, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        c->host_res = nullptr;
+        return nullptr;
+    }
+    c->host_res_cap = cap;
+    return c->host_res;
+}
+
+// ---- the device-side double buffer of the long host-pointer batches (engine.h: DevStage). Caller holds c->mu. ---------------------------
+static bool dev_stage_ready(Ctx *c) {
+    DevStage &r = c->stage;
+    if (r.ready || r.failed || !knobs().host_stage) return r.ready && knobs().host_stage;
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++)
+        ok = hipMalloc((void **)&r.slot[k], kMaxChunk * (size_t)kBlobBytes) == hipSuccess &&
+             hipEventCreateWithFlags(&r.copied[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&r.parsed[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {   // no memory for it (a 275 GB table): r05's slices, quietly
+        (void)hipGetLastError();
+        for (int k = 0; k < 2; k++) {
+            dev_free(r.slot[k]);
+            if (r.copied[k]) hipEventDestroy(r.copied[k]);
+            if (r.parsed[k]) hipEventDestroy(r.parsed[k]);
+            r.slot[k] = nullptr;
+            r.copied[k] = r.parsed[k] = nullptr;
+        }
+        r.failed = true;
+        return false;
+    }
+    r.ready = true;
+    return true;
+}
+// slice lengths of a staged batch: a short first slice (the GPU is at work after a sixteenth of a 4096-blob upload), then whole chunks
+static size_t stage_slice_len(size_t k, size_t remaining) {
+    const size_t want = k == 0 ? kMaxChunk / 4 : kMaxChunk;
+    return remaining < want ? remaining : want;
+}
+// upload `cnt` blobs into slot k mod 2 on the copy stream (behind the parse of the slot's previous occupant) and make `compute` wait for it
+static C_KZG_RET stage_upload(Ctx *c, size_t k, const uint8_t *src, size_t cnt, hipStream_t compute, uint8_t **d_blobs) {
+    DevStage &r = c->stage;
+    const int s = (int)(k & 1);
+    hipStream_t sc = c->aux[3];   // (aux[0..2] are the sub-batch streams of the launch sets)
+    if (k >= 2) LWK_HIP(hipStreamWaitEvent(sc, r.parsed[s], 0));
+    LWK_HIP(hipMemcpyAsync(r.slot[s], src, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sc));
+    LWK_HIP(hipEventRecord(r.copied[s], sc));
+    LWK_HIP(hipStreamWaitEvent(compute, r.copied[s], 0));
+    *d_blobs = r.slot[s];
+    return C_KZG_OK;
+}
+// every kernel that reads slot k mod 2 has been enqueued on `compute`
+static C_KZG_RET stage_parsed(Ctx *c, size_t k, hipStream_t compute) {
+    LWK_HIP(hipEventRecord(c->stage.parsed[k & 1], compute));
+    return C_KZG_OK;
+}
+
 // Batches longer than one chunk (1024 blobs). All 2n points are validated ONCE up front (two launches side by side; the kernel is a 2 ms
 // latency chain whatever n is), and the blobs then go through in slices that alternate between the two halves of the
 // workspace and two streams: while the GPU parses / evaluates one slice, this thread is already inside the (blocking,
@@ -1380,8 +1497,8 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         s.hc = comm48 + 48 * off;
         s.dig.resize(32 * m);
         Slot *sp = &s;  // digests assume the caller's commitment bytes are canonical; finish() confirms or refutes that
-        s.hasher.start([sp]() { challenge_digests_host(sp->dig.data(), sp->hb, sp->hc, sp->m); });
         uint8_t *d_blobs = w.blobs + s.base * (size_t)kBlobBytes;
+        s.hasher.start([sp]() { challenge_digests_host(sp->dig.data(), sp->hb, sp->hc, sp->m); });
         LWK_HIP(hipMemcpyAsync(d_blobs, s.hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, s.sk));
         LWK_HIP(hipMemsetAsync(w.status + s.base, 0, m * 4, s.sk));
         coefficients_stage(c, d_blobs, m, mode, w.status + s.base, s.sk, s.base);
@@ -1642,7 +1759,12 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
     // cannot share a compute unit with a hash workgroup (or with each other), as long as the hash leaves half the chip free.
     const bool apart = n <= kVerifyApartMax;
     const bool fused = knobs().verify_fused || knobs().verify_msm;
-    if (knobs().verify_order) launch_challenge(d_blobs, d_comm, z, le, n, st);   // experiment: the hash submitted first
+    // Up to 8192 blobs (the hash on at most half the compute units) the hash is submitted FIRST and takes its compute units; the padded
+    // validation workgroups then fill the others, a compute unit each, and queue among themselves where those run out -- submitted first,
+    // they would take the whole chip and the hash would wait for them (8192 blobs: the hash 7.6 ms behind 256 exclusive decompression
+    // workgroups; profiles/r06_experiments.md section 3). LWKZG_VERIFY_ORDER=1 (experiment) is the other order.
+    const bool hash_first = fused ? (apart != (knobs().verify_order != 0)) : knobs().verify_order != 0;
+    if (hash_first) launch_challenge(d_blobs, d_comm, z, le, n, st);
     if (fused) {   // r06: ONE launch per kernel over both point sets; the rows start as soon as the points are decompressed
         launch_decompress_points2(d_proofs, vb.pts_p, vb.kind_p, d_comm, vb.pts_c, vb.kind_c, n, sv, apart);
         LWK_HIP(hipEventRecord(c->ev_join[2], sv));
@@ -1668,7 +1790,7 @@ C_KZG_RET verify_prepare_device(Ctx *c, const uint8_t *d_blobs, const uint8_t *d
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
         LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
     }
-    if (!knobs().verify_order) launch_challenge(d_blobs, d_comm, z, le, n, st);
+    if (!hash_first) launch_challenge(d_blobs, d_comm, z, le, n, st);
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[0], 0));
     LWK_HIP(hipStreamWaitEvent(st, c->ev_join[1], 0));
     drain.armed = false;  // both side streams are joined into the main stream from here on
@@ -1921,6 +2043,8 @@ size_t lwkzg_profile_report(char *buf, size_t cap) {
 __global__ void k_runtime_init(int *p) {
     if (p) *p = 1;
 }
+
+extern "C" int lwkzg_last_proof_schedule(void) { return g_last_proof_schedule.load(std::memory_order_relaxed); }
 
 extern "C" int lwkzg_runtime_init(void) {
     if (!gpu_available()) return -1;
@@ -2410,19 +2534,46 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
     std::vector<int32_t> h_status(n);
     // results and verdicts of all slices stay on the device until the end: a D2H copy into pageable memory would make
     // this thread wait for the slice it belongs to
-    uint8_t *d_out_all = nullptr;
-    int32_t *d_status_all = nullptr;
-    if (hipMalloc((void **)&d_out_all, n * 48) != hipSuccess || hipMalloc((void **)&d_status_all, n * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        if (d_out_all) hipFree(d_out_all);
+    uint8_t *d_out_all = host_res_block(c, ((n * 48 + 255) & ~(size_t)255) + n * 4);
+    if (!d_out_all) {
         set_error("lwkzg_blob_to_kzg_commitment_batch: out of device memory for %zu results", n);
         return C_KZG_MALLOC;
     }
-    struct Freer {
-        void *a, *b;
-        ~Freer() { hipFree(a); hipFree(b); }
-    } freer{d_out_all, d_status_all};
+    int32_t *d_status_all = (int32_t *)(d_out_all + ((n * 48 + 255) & ~(size_t)255));
     LWK_HIP(hipEventRecord(c->ev_fork, c->stream));
+    if (n > kMaxChunk && dev_stage_ready(c)) {   // (up to one chunk r05's 128 + 384 + 512 slices measure better: 81.9k against 79.9k ops/s at 1024 blobs)
+        // r06 (engine.h: DevStage): the slices are uploaded into a device-side double buffer on a copy stream and go through the
+        // device-resident pipeline itself -- whole chunks, one compute stream -- while the next one is on its way
+        hipStream_t st = c->stream;
+        LWK_HIP(hipStreamWaitEvent(c->aux[3], c->ev_fork, 0));
+        size_t k = 0;
+        for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
+            cnt = stage_slice_len(k, n - off);
+            uint8_t *d_blobs = nullptr;
+            const auto tu0 = std::chrono::steady_clock::now();
+            rc = stage_upload(c, k, (const uint8_t *)(blobs + off), cnt, st, &d_blobs);
+            if (knobs().timing)
+                fprintf(stderr, "[lambdaworks_kzg_amd] staged commitments: slice %zu (%zu blobs) upload call %.2f ms\n", k, cnt,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
+            if (rc == C_KZG_OK) rc = commit_batch_device(c, d_out_all + 48 * off, d_blobs, cnt, mode, st, d_status_all + off);
+            if (rc == C_KZG_OK) rc = stage_parsed(c, k, st);   // (behind the whole slice: the bucket engine's sub-batches parse on streams of their own)
+            if (rc != C_KZG_OK) {
+                hipStreamSynchronize(c->aux[3]);
+                hipStreamSynchronize(st);
+                return rc;
+            }
+        }
+        LWK_HIP(hipMemcpyAsync((uint8_t *)out, d_out_all, n * 48, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipMemcpyAsync(h_status.data(), d_status_all, n * 4, hipMemcpyDeviceToHost, st));
+        LWK_HIP(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; i++)
+            if (h_status[i] != 0) {
+                if (first_bad) *first_bad = i;
+                set_error("blob %zu rejected (status %d)", i, h_status[i]);
+                return map_rc((C_KZG_RET)h_status[i], mode);
+            }
+        return C_KZG_OK;
+    }
     LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
     LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
     size_t k = 0;
@@ -2460,19 +2611,14 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
 
 namespace {
 
-struct DevBlock {  // one device allocation carved into 256-byte aligned pieces
+struct DevBlock {  // a piece of the context's result block (host_res_block) carved into 256-byte aligned pieces
     uint8_t *base = nullptr;
     size_t used = 0, cap = 0;
-    ~DevBlock() { if (base) hipFree(base); }
     static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
-    bool alloc(size_t bytes) {
+    bool alloc(Ctx *c, size_t bytes) {
         cap = bytes;
-        if (hipMalloc((void **)&base, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            base = nullptr;
-            return false;
-        }
-        return true;
+        base = host_res_block(c, bytes);
+        return base != nullptr;
     }
     uint8_t *take(size_t bytes) {
         uint8_t *p = base + used;
@@ -2499,7 +2645,7 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
     if (rc != C_KZG_OK) return rc;
     Workspace &w = c->ws;
     DevBlock blk;
-    if (!blk.alloc(DevBlock::pad(n * 48) + 2 * DevBlock::pad(n * 32) + DevBlock::pad(n * 4))) {
+    if (!blk.alloc(c, DevBlock::pad(n * 48) + 2 * DevBlock::pad(n * 32) + DevBlock::pad(n * 4))) {
         set_error("lwkzg_compute_kzg_proof_batch: out of device memory for %zu results", n);
         return C_KZG_MALLOC;
     }
@@ -2510,10 +2656,24 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
     LWK_HIP(hipMemcpyAsync(d_z, zs, n * 32, hipMemcpyHostToDevice, st));
     LWK_HIP(hipMemsetAsync(d_status, 0, n * 4, st));
     LWK_HIP(hipEventRecord(c->ev_fork, st));
-    LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-    LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    const bool staged = n > kMaxChunk && dev_stage_ready(c);   // r06: whole chunks from a device-side double buffer, one compute stream (engine.h: DevStage)
+    if (staged) LWK_HIP(hipStreamWaitEvent(c->aux[3], c->ev_fork, 0));
+    for (size_t off = 0, cnt = 0, k = 0; staged && off < n; off += cnt, k++) {
+        cnt = stage_slice_len(k, n - off);
+        uint8_t *d_blobs = nullptr;
+        if ((rc = stage_upload(c, k, blobs + off * (size_t)kBlobBytes, cnt, st, &d_blobs)) != C_KZG_OK) return rc;
+        coefficients_stage(c, d_blobs, cnt, mode, d_status + off, st, 0);
+        if ((rc = stage_parsed(c, k, st)) != C_KZG_OK) return rc;
+        launch_z_from_bytes(d_z + 32 * off, w.z, d_status + off, le, cnt, st);
+        quotient_stage(c, mode, w.scalars, w.z, w.scalars2, d_y + 32 * off, le, cnt, st);
+        msm_stages(c, w.scalars2, d_out + 48 * off, cnt, st, 0, false, quotient_to_msm_form(c, mode, cnt, st, 0));
+    }
+    if (!staged) {
+        LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+        LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    }
     size_t k = 0;
-    for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
+    for (size_t off = 0, cnt = 0; !staged && off < n; off += cnt, k++) {
         cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
         const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
         hipStream_t sk = c->aux[k & 1];
@@ -2552,7 +2712,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
     if (rc != C_KZG_OK) return rc;
     Workspace &w = c->ws;
     DevBlock blk;
-    if (!blk.alloc(3 * DevBlock::pad(n * 48) + DevBlock::pad(n * 32) + DevBlock::pad(n * 4))) {
+    if (!blk.alloc(c, 3 * DevBlock::pad(n * 48) + DevBlock::pad(n * 32) + DevBlock::pad(n * 4))) {
         set_error("lwkzg_compute_blob_kzg_proof_batch: out of device memory for %zu results", n);
         return C_KZG_MALLOC;
     }
@@ -2577,17 +2737,25 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
     launch_validate_commitments(d_comm, d_canon, d_status, le ? kStatusBadArgs : kStatusError, n, sv);  // lib.rs:372-375
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     bool validated = false;
+    const bool staged = n > kMaxChunk && dev_stage_ready(c);   // r06 (engine.h: DevStage): whole chunks from a device-side double buffer on ONE compute stream
+    if (staged) LWK_HIP(hipStreamWaitEvent(c->aux[3], c->ev_fork, 0));
     size_t k = 0;
     for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
-        cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
-        const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
-        hipStream_t sk = c->aux[k & 1];
+        cnt = staged ? stage_slice_len(k, n - off) : slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
+        const size_t lo = staged ? 0 : (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
+        hipStream_t sk = staged ? st : c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
         const uint8_t *hb = blobs + off * (size_t)kBlobBytes, *hc = comm48 + 48 * off;
         uint8_t *dig = h_dig.data() + 32 * off;
+        // the host threads hash the slice (the digests assume canonical commitment bytes) beside its upload, which blocks this thread while
+        // the runtime stages it
         SideTask hasher([=]() { challenge_digests_host(dig, hb, hc, cnt); });
         const auto ta = now();
-        LWK_HIP(hipMemcpyAsync(d_blobs, hb, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
+        if (staged) {
+            if ((rc = stage_upload(c, k, hb, cnt, sk, &d_blobs)) != C_KZG_OK) return rc;
+        } else {
+            LWK_HIP(hipMemcpyAsync(d_blobs, hb, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
+        }
         const auto tb = now();
         coefficients_stage(c, d_blobs, cnt, mode, d_status + off, sk, lo);
         hasher.join();
@@ -2607,6 +2775,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
         } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
             launch_challenge(d_blobs, d_canon + 48 * off, w.z + lo, le, cnt, sk);
         }
+        if (staged && (rc = stage_parsed(c, k, sk)) != C_KZG_OK) return rc;   // (the slot's last reader is in the queue)
         quotient_stage(c, mode, w.scalars + so, w.z + lo, w.scalars2 + so, nullptr, le, cnt, sk);
         msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo, false, quotient_to_msm_form(c, mode, cnt, sk, lo));
     }
@@ -2935,6 +3104,9 @@ static C_KZG_RET reserve_ctx(Ctx *c, size_t max_batch) {
             if (hipLaunchHostFunc(hs, host_noop_fn, nullptr) != hipSuccess) (void)hipGetLastError();
         for (hipStream_t hs : {c->aux[0], c->aux[1], c->vstream}) (void)hipStreamSynchronize(hs);
     }
+    // a caller that announces batches of more than a chunk gets the device-side double buffer of the long host-pointer batches now (256 MiB)
+    // instead of inside its first long call; the twin context never runs host-pointer batches
+    if (max_batch > kMaxChunk && !c->is_twin) (void)dev_stage_ready(c);
     return C_KZG_OK;
 }
 

@@ -28,7 +28,6 @@ struct Knobs {
     bool timing = false;             // LWKZG_TIMING: phase wall clock of verification / proof slices to stderr
     bool verbose = false;            // LWKZG_VERBOSE: every set_error() message to stderr
     bool experimental = false;       // LWKZG_EXPERIMENTAL: honour the experiment knobs below
-    size_t stage_slice = 512;        // LWKZG_STAGE_SLICE: blobs per pinned staging slice of long host-pointer batches (r06)
 
     // ---- experiment (A/B arms; LWKZG_EXPERIMENTAL=1) ----------------------------------------------------------------------------
     bool direct_asm = true;          // LWKZG_DIRECT_ASM=0: compiler-scheduled k_direct_accumulate
@@ -49,6 +48,7 @@ struct Knobs {
     size_t mid_proof_pipe_min = 192; // LWKZG_MID_PROOF_PIPE_MIN
     size_t mid_proof_parts = 0;      // LWKZG_MID_PROOF_PARTS
     size_t mid_proof_chunks = 4;     // LWKZG_MID_PROOF_CHUNKS
+    int proof_schedule = -1;         // LWKZG_PROOF_SCHEDULE=0..4: force that schedule (plan.h: ProofSchedule) for device-resident proof calls of up to 1024 blobs (tests)
     int heavy_serial = -1;           // LWKZG_HEAVY_SERIAL
     int split = 0;                   // LWKZG_SPLIT: windows of a scalar over this many workgroups (tiny batches)
     size_t slice0 = 0;               // LWKZG_SLICE0: first slice of a long host-pointer batch
@@ -58,10 +58,10 @@ struct Knobs {
     int verify_msm = 1;              // LWKZG_VERIFY_MSM=0: r05's per-point multiples + Straus pieces (k_point_multiples, k_lincomb3)
     int verify_fused = 1;            // LWKZG_VERIFY_FUSED=0: commitments and proofs validated by separate launches on two side streams
     int verify_pad_kb[3] = {60, 116, 116};  // LWKZG_VERIFY_PAD_KB="d,s,m": unused LDS (KiB) per workgroup of the decompression / subgroup / rows kernels of a verification
-    int verify_order = 0;            // LWKZG_VERIFY_ORDER=1: the hash is submitted before the validation launches
+    int verify_order = 0;            // LWKZG_VERIFY_ORDER=1: the other submission order of hash and validation (shipped: the hash first up to 8192 blobs, last above)
     int verify_cu_mask = 0;          // LWKZG_VERIFY_CU_MASK=k: side streams confined to k compute units per XCD (hipExtStreamCreateWithCUMask)
     int vmsm_list_cap = 0;           // LWKZG_VMSM_LIST_CAP: rows per digit a slice lists before the scan fallback (tests force the fallback with 1)
-    bool stage_pinned = true;        // LWKZG_STAGE_PINNED=0: long host-pointer batches copy from the caller's pageable memory
+    bool host_stage = true;          // LWKZG_HOST_STAGE=0: long host-pointer batches in r05's 512-blob slices on two streams instead of whole chunks from the device-side double buffer
 };
 
 const Knobs &knobs();

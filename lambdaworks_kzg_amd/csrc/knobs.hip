@@ -64,9 +64,6 @@ Knobs read_env() {
     r.num(k.host_finish, "LWKZG_HOST_FINISH", OP);
     r.present(k.timing, "LWKZG_TIMING", OP);
     r.present(k.verbose, "LWKZG_VERBOSE", OP);
-    r.num(k.stage_slice, "LWKZG_STAGE_SLICE", OP);
-    if (k.stage_slice < 64) k.stage_slice = 64;
-    if (k.stage_slice > 512) k.stage_slice = 512;
 
     r.flag(k.direct_asm, "LWKZG_DIRECT_ASM", EXP);
     r.flag(k.fold_asm, "LWKZG_FOLD_ASM", EXP);
@@ -89,6 +86,7 @@ Knobs read_env() {
     r.num(k.mid_proof_parts, "LWKZG_MID_PROOF_PARTS", EXP);
     r.num(k.mid_proof_chunks, "LWKZG_MID_PROOF_CHUNKS", EXP);
     r.num(k.heavy_serial, "LWKZG_HEAVY_SERIAL", EXP);
+    r.num(k.proof_schedule, "LWKZG_PROOF_SCHEDULE", EXP);
     r.num(k.split, "LWKZG_SPLIT", EXP);
     r.num(k.slice0, "LWKZG_SLICE0", EXP);
     r.flag(k.set_mode_in_place, "LWKZG_SET_MODE_IN_PLACE", EXP);
@@ -109,7 +107,7 @@ Knobs read_env() {
     r.num(k.verify_order, "LWKZG_VERIFY_ORDER", EXP);
     r.num(k.verify_cu_mask, "LWKZG_VERIFY_CU_MASK", EXP);
     r.num(k.vmsm_list_cap, "LWKZG_VMSM_LIST_CAP", EXP);
-    r.flag(k.stage_pinned, "LWKZG_STAGE_PINNED", EXP);
+    r.flag(k.host_stage, "LWKZG_HOST_STAGE", EXP);
     return k;
 }
 
@@ -122,16 +120,16 @@ const Knobs &knobs() {
 
 const char *knob_names_operational() {
     return "LWKZG_MODE LWKZG_DIRECT_BITS LWKZG_DIRECT_ROW LWKZG_COALESCE LWKZG_TWIN LWKZG_SMALL_PROOF_HOST LWKZG_MID_PROOF_HOST "
-           "LWKZG_HOST_WARM_MS LWKZG_HOST_FINISH LWKZG_TIMING LWKZG_VERBOSE LWKZG_EXPERIMENTAL LWKZG_STAGE_SLICE";
+           "LWKZG_HOST_WARM_MS LWKZG_HOST_FINISH LWKZG_TIMING LWKZG_VERBOSE LWKZG_EXPERIMENTAL";
 }
 
 const char *knob_names_experimental() {
     return "LWKZG_DIRECT_ASM LWKZG_FOLD_ASM LWKZG_BUCKET_ASM LWKZG_DIRECT_FILL LWKZG_COOP LWKZG_COOP_MAX LWKZG_COOP_RPQ LWKZG_SORT_STAGE "
            "LWKZG_REDUCE_LANES LWKZG_HASH_PAIRS LWKZG_HASH_PRIO LWKZG_VALIDATE_COOP LWKZG_VALIDATE_LDS_PAD LWKZG_CKZG_EVAL_PROOFS "
-           "LWKZG_MID_PROOF_PIPE LWKZG_MID_PROOF_PIPE_MIN LWKZG_MID_PROOF_PARTS LWKZG_MID_PROOF_CHUNKS LWKZG_HEAVY_SERIAL LWKZG_SPLIT "
+           "LWKZG_MID_PROOF_PIPE LWKZG_MID_PROOF_PIPE_MIN LWKZG_MID_PROOF_PARTS LWKZG_MID_PROOF_CHUNKS LWKZG_HEAVY_SERIAL LWKZG_PROOF_SCHEDULE LWKZG_SPLIT "
            "LWKZG_SLICE0 LWKZG_SET_MODE_IN_PLACE LWKZG_PAIRING_GENERIC_SQR LWKZG_PAIRING_NAIVE LWKZG_PAIRING_NO_PRECOMP "
            "LWKZG_PAIRING_ONE_THREAD LWKZG_VERIFY_MSM LWKZG_VERIFY_FUSED LWKZG_VERIFY_PAD_KB LWKZG_VERIFY_ORDER LWKZG_VERIFY_CU_MASK LWKZG_VMSM_LIST_CAP "
-           "LWKZG_STAGE_PINNED";
+           "LWKZG_HOST_STAGE";
 }
 
 }  // namespace lwk
@@ -142,16 +140,16 @@ extern "C" __attribute__((visibility("default"))) size_t lwkzg_knob_report(char 
     const int n = snprintf(
         tmp, sizeof tmp,
         "{\"experimental\": %s, \"mode\": %d, \"direct_bits\": %s%d, \"direct_row\": %d, \"coalesce\": %d, \"twin\": %d, "
-        "\"small_proof_host\": %zu, \"mid_proof_host\": %zu, \"host_warm_ms\": %d, \"host_finish\": %zu, \"stage_slice\": %zu, "
+        "\"small_proof_host\": %zu, \"mid_proof_host\": %zu, \"host_warm_ms\": %d, \"host_finish\": %zu, "
         "\"timing\": %d, \"verbose\": %d, \"direct_asm\": %d, \"fold_asm\": %d, \"bucket_asm\": %d, \"coop\": %d, \"coop_max\": %d, "
         "\"hash_pairs\": %d, \"hash_prio\": %d, \"validate_coop\": %d, \"ckzg_eval_proofs\": %d, \"mid_proof_pipe\": %d, "
         "\"verify_msm\": %d, \"verify_fused\": %d, \"verify_pad_kb\": [%d, %d, %d], \"verify_order\": %d, \"vmsm_list_cap\": %d, "
-        "\"stage_pinned\": %d, \"operational\": \"%s\", \"experimental_names\": \"%s\"}",
+        "\"host_stage\": %d, \"operational\": \"%s\", \"experimental_names\": \"%s\"}",
         k.experimental ? "true" : "false", k.mode, k.has_direct_bits ? "" : "null, \"direct_bits_unset_default\": ", k.direct_bits, k.direct_row,
-        (int)k.coalesce, (int)k.twin, k.small_proof_host, k.mid_proof_host, k.host_warm_ms, k.host_finish, k.stage_slice, (int)k.timing,
+        (int)k.coalesce, (int)k.twin, k.small_proof_host, k.mid_proof_host, k.host_warm_ms, k.host_finish, (int)k.timing,
         (int)k.verbose, (int)k.direct_asm, (int)k.fold_asm, (int)k.bucket_asm, k.coop, k.coop_max, (int)k.hash_pairs, k.hash_prio,
         (int)k.validate_coop, (int)k.ckzg_eval_proofs, (int)k.mid_proof_pipe, k.verify_msm, k.verify_fused, k.verify_pad_kb[0],
-        k.verify_pad_kb[1], k.verify_pad_kb[2], k.verify_order, k.vmsm_list_cap, (int)k.stage_pinned, lwk::knob_names_operational(),
+        k.verify_pad_kb[1], k.verify_pad_kb[2], k.verify_order, k.vmsm_list_cap, (int)k.host_stage, lwk::knob_names_operational(),
         lwk::knob_names_experimental());
     const size_t need = (size_t)(n < 0 ? 0 : n) + 1;
     if (buf && cap) {

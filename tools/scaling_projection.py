@@ -55,9 +55,10 @@ print(json.dumps(out)); dist.destroy_process_group()
     from lambdaworks_kzg_amd import capi
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-c", code, str(capi.setup_image_bytes())], env=env, capture_output=True, text=True, timeout=600)
-    if p.returncode != 0:
-        return {"error": p.stderr[-600:]}
-    return json.loads(p.stdout.strip().splitlines()[-1])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": (p.stderr or p.stdout)[-600:]}
+    return json.loads(lines[-1])
 
 
 def main():
