@@ -399,7 +399,8 @@ class MultiSetup:
         out = C.create_string_buffer(48 * max(n, 1))
         self.first_bad = C.c_size_t(0)
         _check("lwkzg_multi_blob_to_kzg_commitment_batch", lib().lwkzg_multi_blob_to_kzg_commitment_batch(out, blobs, n, self.h, C.byref(self.first_bad)))
-        return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+        raw = out.raw      # (ONE copy of the buffer: `.raw` inside the comprehension copied all 48 n bytes per element -- 6 ms of Python per 4096 results)
+        return [raw[48 * i:48 * i + 48] for i in range(n)]
 
     def compute_blob_kzg_proof_batch(self, blobs, commitments):
         n = len(blobs) // BYTES_PER_BLOB
@@ -408,7 +409,8 @@ class MultiSetup:
         self.first_bad = C.c_size_t(0)
         _check("lwkzg_multi_compute_blob_kzg_proof_batch",
                lib().lwkzg_multi_compute_blob_kzg_proof_batch(out, blobs, commitments, n, self.h, C.byref(self.first_bad)))
-        return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+        raw = out.raw      # (ONE copy of the buffer: `.raw` inside the comprehension copied all 48 n bytes per element -- 6 ms of Python per 4096 results)
+        return [raw[48 * i:48 * i + 48] for i in range(n)]
 
     def compute_kzg_proof_batch(self, blobs, zs):
         n = len(blobs) // BYTES_PER_BLOB
@@ -417,7 +419,8 @@ class MultiSetup:
         self.first_bad = C.c_size_t(0)
         _check("lwkzg_multi_compute_kzg_proof_batch",
                lib().lwkzg_multi_compute_kzg_proof_batch(out, ys, blobs, zs, n, self.h, C.byref(self.first_bad)))
-        return [(out.raw[48 * i:48 * i + 48], ys.raw[32 * i:32 * i + 32]) for i in range(n)]
+        raw, yraw = out.raw, ys.raw
+        return [(raw[48 * i:48 * i + 48], yraw[32 * i:32 * i + 32]) for i in range(n)]
 
     # ---- shards already in HBM: lists of per-device device pointers and counts (device k's shard on device k)
     @staticmethod
@@ -584,7 +587,8 @@ def blob_to_kzg_commitment_batch(blobs, ts):
     bad = C.c_size_t(0)
     _check("lwkzg_blob_to_kzg_commitment_batch",
            lib().lwkzg_blob_to_kzg_commitment_batch(out, blobs, n, ts.ref(), C.byref(bad)))
-    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+    raw = out.raw      # (ONE copy of the buffer: `.raw` inside the comprehension copied all 48 n bytes per element -- 6 ms of Python per 4096 results)
+    return [raw[48 * i:48 * i + 48] for i in range(n)]
 
 
 def compute_blob_kzg_proof_batch(blobs, commitments, ts):
@@ -594,7 +598,8 @@ def compute_blob_kzg_proof_batch(blobs, commitments, ts):
     bad = C.c_size_t(0)
     _check("lwkzg_compute_blob_kzg_proof_batch",
            lib().lwkzg_compute_blob_kzg_proof_batch(out, blobs, commitments, n, ts.ref(), C.byref(bad)))
-    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+    raw = out.raw      # (ONE copy of the buffer: `.raw` inside the comprehension copied all 48 n bytes per element -- 6 ms of Python per 4096 results)
+    return [raw[48 * i:48 * i + 48] for i in range(n)]
 
 
 def compute_kzg_proof_batch(blobs, zs, ts):
@@ -604,7 +609,8 @@ def compute_kzg_proof_batch(blobs, zs, ts):
     bad = C.c_size_t(0)
     _check("lwkzg_compute_kzg_proof_batch",
            lib().lwkzg_compute_kzg_proof_batch(out, ys, blobs, zs, n, ts.ref(), C.byref(bad)))
-    return [(out.raw[48 * i:48 * i + 48], ys.raw[32 * i:32 * i + 32]) for i in range(n)]
+    raw, yraw = out.raw, ys.raw
+    return [(raw[48 * i:48 * i + 48], yraw[32 * i:32 * i + 32]) for i in range(n)]
 
 
 # ---- device-resident extensions (pointers are ints: torch tensor .data_ptr()) -----------------------
@@ -673,7 +679,8 @@ def challenge_digests_host(blobs, commitments):
     assert len(blobs) == n * BYTES_PER_BLOB
     out = C.create_string_buffer(32 * max(n, 1))
     _check("lwkzg_challenge_digests_host", lib().lwkzg_challenge_digests_host(out, blobs, commitments, n))
-    return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+    raw = out.raw
+    return [raw[32 * i:32 * i + 32] for i in range(n)]
 
 
 def setup_image_bytes():

@@ -1500,8 +1500,8 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         uint8_t *d_blobs = w.blobs + s.base * (size_t)kBlobBytes;
         s.hasher.start([sp]() { challenge_digests_host(sp->dig.data(), sp->hb, sp->hc, sp->m); });
         LWK_HIP(hipMemcpyAsync(d_blobs, s.hb, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, s.sk));
-        LWK_HIP(hipMemsetAsync(w.status + s.base, 0, m * 4, s.sk));
-        coefficients_stage(c, d_blobs, m, mode, w.status + s.base, s.sk, s.base);
+        // (the parser's verdicts go beside the validation's, as in the device-resident form: both only ever write failure codes)
+        coefficients_stage(c, d_blobs, m, mode, vb.status_all + off, s.sk, s.base);
         return C_KZG_OK;
     };
 
@@ -1526,10 +1526,12 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         quotient_stage(c, mode, w.scalars + base * (size_t)kBlobElems * 8, d_z, nullptr /* y only */, d_yb, le, m,
                              sk);
         launch_fr_mont_to_bytes(d_z, d_zb, le, m, sk);
-        LWK_HIP(hipMemcpyAsync(vb.d_rz + 32 * off, d_zb, m * 32, hipMemcpyDeviceToDevice, sk));  // for k_vmsm_scalars
-        LWK_HIP(hipMemcpyAsync(z32 + 32 * off, d_zb, m * 32, hipMemcpyDeviceToHost, sk));
-        LWK_HIP(hipMemcpyAsync(y32 + 32 * off, d_yb, m * 32, hipMemcpyDeviceToHost, sk));
-        return first_status(c, w.status + base, m, sk);
+        // r06: z and y of ALL slices collect on the device (the linear combinations' scalar buffers, idle until then; k_vmsm_scalars reads z
+        // from there) and come back in one copy each at the end -- r05 copied them to pageable memory slice by slice and fetched the
+        // slice's verdicts, two blocking round trips per slice on the submitting thread
+        LWK_HIP(hipMemcpyAsync(vb.d_rz + 32 * off, d_zb, m * 32, hipMemcpyDeviceToDevice, sk));
+        LWK_HIP(hipMemcpyAsync(vb.d_r + 32 * off, d_yb, m * 32, hipMemcpyDeviceToDevice, sk));
+        return C_KZG_OK;
     };
 
     // the slice streams start after the caller's earlier work on the main stream
@@ -1554,7 +1556,9 @@ static C_KZG_RET verify_prepare_long(Ctx *c, const uint8_t *blobs, const uint8_t
         if (rcf != C_KZG_OK) return rcf;
     }
     if (rc_all != C_KZG_OK) return rc_all;
-    return first_status(c, vb.status_all, n, st);  // the validation's verdicts
+    LWK_HIP(hipMemcpyAsync(z32, vb.d_rz, n * 32, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(y32, vb.d_r, n * 32, hipMemcpyDeviceToHost, st));
+    return first_status(c, vb.status_all, n, st);  // the validation's verdicts and the parser's: the lowest rejected index of the batch
 }
 
 // Everything per blob of a batch verification, in one pass over the blobs: validate C_i and pi_i (keeping the
@@ -2656,24 +2660,12 @@ C_KZG_RET point_proofs_sliced(Ctx *c, uint8_t *proofs_out, uint8_t *ys_out, cons
     LWK_HIP(hipMemcpyAsync(d_z, zs, n * 32, hipMemcpyHostToDevice, st));
     LWK_HIP(hipMemsetAsync(d_status, 0, n * 4, st));
     LWK_HIP(hipEventRecord(c->ev_fork, st));
-    const bool staged = n > kMaxChunk && dev_stage_ready(c);   // r06: whole chunks from a device-side double buffer, one compute stream (engine.h: DevStage)
-    if (staged) LWK_HIP(hipStreamWaitEvent(c->aux[3], c->ev_fork, 0));
-    for (size_t off = 0, cnt = 0, k = 0; staged && off < n; off += cnt, k++) {
-        cnt = stage_slice_len(k, n - off);
-        uint8_t *d_blobs = nullptr;
-        if ((rc = stage_upload(c, k, blobs + off * (size_t)kBlobBytes, cnt, st, &d_blobs)) != C_KZG_OK) return rc;
-        coefficients_stage(c, d_blobs, cnt, mode, d_status + off, st, 0);
-        if ((rc = stage_parsed(c, k, st)) != C_KZG_OK) return rc;
-        launch_z_from_bytes(d_z + 32 * off, w.z, d_status + off, le, cnt, st);
-        quotient_stage(c, mode, w.scalars, w.z, w.scalars2, d_y + 32 * off, le, cnt, st);
-        msm_stages(c, w.scalars2, d_out + 48 * off, cnt, st, 0, false, quotient_to_msm_form(c, mode, cnt, st, 0));
-    }
-    if (!staged) {
-        LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-        LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
-    }
+    // (r06: the staged whole-chunk schedule of the commitments -- engine.h: DevStage -- measured 3 % SLOWER here, 88.6k against 91.2k proofs/s at
+    // 4096 blobs: on two streams the evaluation, fold and finalize of one slice run beside the other slice's MSM; profiles/r06_experiments.md section 6)
+    LWK_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
     size_t k = 0;
-    for (size_t off = 0, cnt = 0; !staged && off < n; off += cnt, k++) {
+    for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
         cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
         const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
         hipStream_t sk = c->aux[k & 1];
@@ -2737,13 +2729,12 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
     launch_validate_commitments(d_comm, d_canon, d_status, le ? kStatusBadArgs : kStatusError, n, sv);  // lib.rs:372-375
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     bool validated = false;
-    const bool staged = n > kMaxChunk && dev_stage_ready(c);   // r06 (engine.h: DevStage): whole chunks from a device-side double buffer on ONE compute stream
-    if (staged) LWK_HIP(hipStreamWaitEvent(c->aux[3], c->ev_fork, 0));
+    // (r06: slices on two streams stay -- the staged whole-chunk schedule of the commitments measured 84.9k against 88.1k proofs/s here)
     size_t k = 0;
     for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
-        cnt = staged ? stage_slice_len(k, n - off) : slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
-        const size_t lo = staged ? 0 : (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
-        hipStream_t sk = staged ? st : c->aux[k & 1];
+        cnt = slice_len(k, n - off, n, c->direct_table != nullptr || c->lag.direct_table != nullptr);
+        const size_t lo = (k % 2) * kSlice, so = lo * (size_t)kBlobElems * 8;
+        hipStream_t sk = c->aux[k & 1];
         uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
         const uint8_t *hb = blobs + off * (size_t)kBlobBytes, *hc = comm48 + 48 * off;
         uint8_t *dig = h_dig.data() + 32 * off;
@@ -2751,11 +2742,7 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
         // the runtime stages it
         SideTask hasher([=]() { challenge_digests_host(dig, hb, hc, cnt); });
         const auto ta = now();
-        if (staged) {
-            if ((rc = stage_upload(c, k, hb, cnt, sk, &d_blobs)) != C_KZG_OK) return rc;
-        } else {
-            LWK_HIP(hipMemcpyAsync(d_blobs, hb, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
-        }
+        LWK_HIP(hipMemcpyAsync(d_blobs, hb, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sk));
         const auto tb = now();
         coefficients_stage(c, d_blobs, cnt, mode, d_status + off, sk, lo);
         hasher.join();
@@ -2775,7 +2762,6 @@ C_KZG_RET blob_proofs_sliced(Ctx *c, uint8_t *out, const uint8_t *blobs, const u
         } else {  // a non-canonical (or invalid) encoding in this slice: hash the canonical bytes on the GPU
             launch_challenge(d_blobs, d_canon + 48 * off, w.z + lo, le, cnt, sk);
         }
-        if (staged && (rc = stage_parsed(c, k, sk)) != C_KZG_OK) return rc;   // (the slot's last reader is in the queue)
         quotient_stage(c, mode, w.scalars + so, w.z + lo, w.scalars2 + so, nullptr, le, cnt, sk);
         msm_stages(c, w.scalars2 + so, d_out + 48 * off, cnt, sk, lo, false, quotient_to_msm_form(c, mode, cnt, sk, lo));
     }

@@ -187,7 +187,9 @@ def main():
             g = c["G"][str(G)]
             v = next(v for k, v in g.items() if k.startswith("value_"))
             ms = g.get("rank_ms")
-            cells.append("%.3gk/s%s" % (v / 1e3, "" if ms is None else " (%.2f ms)" % ms))
+            unit = next(k for k in g if k.startswith("value_"))[len("value_"):].replace("_per_s", "/s")
+            sv = "%.3g M" % (v / 1e6) if v >= 1e6 else "%.3g k" % (v / 1e3)
+            cells.append("%s %s%s" % (sv, unit, "" if ms is None else " (%.2f ms)" % ms))
         print("| %s | %s | %.2f | %s |" % (name, " | ".join(cells), c["G"]["8"]["efficiency"], c["bound"].split(":")[0]))
     ts.free()
 
