@@ -305,6 +305,37 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient(const uint4 *__restr
     for (int k = 1; k < kChunk; k <<= 1) m = fr28_mul(m, m);  // z^kChunk
 
     Fr28 v = L;
+    if (!quot_raw) {
+        // y = p(z) alone (batch verification: r06). No suffix is wanted, so the scan's 8 levels x 2 products on every lane become a TREE on
+        // compacted lanes: lane t < active takes elements 2t and 2t + 1, v' = v_2t + m v_2t+1 with m = z^(16 2^level) -- the same for every
+        // pair of a level --, and squares its m. From the second level on only wave 0 works (128 -> 64 -> ... -> 1 active lanes): 18
+        // wave-products behind the 19 of the chunk where the scan issued 64. Bounds as in the scan: a value grows by one product result per
+        // level (<= 3r + 8 x 2r, limbs <= 10 units) and enters the next level's product as the lazy factor.
+        sh_v[t] = v;
+        __syncthreads();
+        for (int active = kThreads / 2; active >= 1; active >>= 1) {
+            Fr28 a, b;
+            if (t < active) {
+                a = sh_v[2 * t];
+                b = sh_v[2 * t + 1];
+            }
+            __syncthreads();
+            if (t < active) {
+                v = fr28_add(a, fr28_mul(m, b));
+                sh_v[t] = v;
+                if (active > 1) m = fr28_mul(m, m);
+            }
+            __syncthreads();
+        }
+        if (t == 0 && y_out) {
+            const Fr28 yv = fr28_canonical(LWK_FR28_MUL_CONST(v, ONE));
+            uint32_t w[8];
+            fr28_unpack(w, yv);
+            uint8_t *yo = y_out + 32 * blob;
+            if (le) raw_to_le<8>(yo, w); else raw_to_be<8>(yo, w);
+        }
+        return;
+    }
     sh_m[t] = m;
     sh_v[t] = v;
     __syncthreads();
@@ -325,16 +356,6 @@ __global__ __launch_bounds__(kThreads) void k_eval_quotient(const uint4 *__restr
         __syncthreads();
     }
     // v == H_t
-    if (!quot_raw) {   // only y = p(z) is wanted (batch verification): it is thread 0's H
-        if (t == 0 && y_out) {
-            const Fr28 yv = fr28_canonical(LWK_FR28_MUL_CONST(v, ONE));
-            uint32_t w[8];
-            fr28_unpack(w, yv);
-            uint8_t *yo = y_out + 32 * blob;
-            if (le) raw_to_le<8>(yo, w); else raw_to_be<8>(yo, w);
-        }
-        return;
-    }
     Fr28 acc;
     if (t + 1 < kThreads) {
         acc = fr28_canonical(LWK_FR28_MUL_CONST(sh_v[t + 1], ONE));   // (up to 3r + 10 x 2r with lazy limbs: one product by 2^280 mod r brings it under 2r)

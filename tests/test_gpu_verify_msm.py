@@ -43,3 +43,31 @@ def test_experiment_knobs_need_the_switch():
     rep = json.loads(p.stdout.strip().splitlines()[-1])
     assert rep["experimental"] is False and rep["verify_msm"] == 1
     assert "LWKZG_VERIFY_MSM ignored" in p.stderr
+
+
+@pytest.mark.parametrize("n", [2, 64, 70, 512])
+def test_identical_and_opposite_points_meet_in_one_bucket(K, gpu_setup, oracle, n):
+    """the bucket sums take the complete branches: a batch of IDENTICAL blobs puts the same row of the same point into a bucket again and
+    again (P + P: the doubling branch of the mixed addition, in the tree and in the scan too), and proofs / commitments at infinity drop
+    out. Honest batches verify, one altered proof does not -- device-resident and host-pointer (the small ones on the host threads)."""
+    import torch
+    import blobs as B
+    from conftest import R
+    blob = B.synthetic_blob(77001)
+    zero = bytes(B.BYTES_PER_BLOB)
+    for blobs in ([blob] * n, [blob, zero] * (n // 2), [zero] * n):
+        data = b"".join(blobs)
+        cj = b"".join(K.blob_to_kzg_commitment_batch(data, gpu_setup))
+        pj = b"".join(K.compute_blob_kzg_proof_batch(data, cj, gpu_setup))
+        db = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        dc = torch.frombuffer(bytearray(cj), dtype=torch.uint8).cuda()
+        dp = torch.frombuffer(bytearray(pj), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        assert K.verify_blob_kzg_proof_batch_device(db.data_ptr(), dc.data_ptr(), dp.data_ptr(), n, gpu_setup) is True
+        assert K.verify_blob_kzg_proof_batch(data, cj, pj, n, gpu_setup) is True
+        other = oracle.g1_generator_mul(12345 % R)
+        bad = pj[:48 * (n - 1)] + other
+        dpb = torch.frombuffer(bytearray(bad), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        assert K.verify_blob_kzg_proof_batch_device(db.data_ptr(), dc.data_ptr(), dpb.data_ptr(), n, gpu_setup) is False
+        assert K.verify_blob_kzg_proof_batch(data, cj, bad, n, gpu_setup) is False
