@@ -570,7 +570,7 @@ static bool direct_asm_enabled() { return knobs().direct_asm; }
 template <int CT>
 static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw,
                             G1Xyzz29 *lane_scratch, G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st,
-                            int fill) {
+                            int fill, uint32_t *redo_flag_out) {
     // many blobs: one workgroup per blob (16 scalars per lane, fewest fold steps); few blobs: spread each over up to
     // 16 workgroups so the chip fills and the dependent chain per lane stays short. `fill` = the number of workgroups
     // to aim for: 512 (two per compute unit, one round) when the kernel has the chip alone; 2048 when the settings
@@ -606,6 +606,15 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
         prm.part_words = units * kCoopUnitWords;
         prm.ctr_words = counters;
         uint32_t *ctr = redo + n_blobs;
+        if (redo_flag_out) {
+            // a one-blob call (r06, engine.hip: combine_run): the hand-off counters have been cleared by the parse kernel in front of this
+            // launch, the redo flag is a word of pinned host memory the caller cleared and will look at after its one synchronisation -- no
+            // fill launch, and no second-pass launch that would exit at its first instruction (the caller repeats a flagged call the long way)
+            ProfScope p("k_coop_msm_asm", st);
+            hipLaunchKernelGGL(k_coop_msm_asm, dim3(prm.n0 / 4, (unsigned)n_blobs), dim3(256), 0, st, table, (const uint4 *)scalars_raw,
+                               (uint32_t *)lane_scratch, ctr, sums, redo_flag_out, prm);
+            return;
+        }
         hipMemsetAsync(redo, 0, n_blobs * (1 + (size_t)counters) * sizeof(uint32_t), st);
         {
             ProfScope p("k_coop_msm_asm", st);
@@ -672,17 +681,27 @@ static void launch_direct_t(const DirectPlanRt &plan, const uint64_t *table, siz
 }
 
 void launch_direct_msm(int bits, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
-                       G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill) {
+                       G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill, uint32_t *redo_flag_out) {
     const DirectPlanRt plan = make_plan(bits);
     if (!plan.entries) return;
     switch (bits) {
-        case 14: launch_direct_t<14>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;
-        case 15: launch_direct_t<15>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;
-        case 16: launch_direct_t<16>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;
-        default: launch_direct_t<0>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill); break;  // 10 .. 13
+        case 14: launch_direct_t<14>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill, redo_flag_out); break;
+        case 15: launch_direct_t<15>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill, redo_flag_out); break;
+        case 16: launch_direct_t<16>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill, redo_flag_out); break;
+        default: launch_direct_t<0>(plan, table, row_bytes, scalars_raw, lane_scratch, partials, redo, sums, n_blobs, st, fill, redo_flag_out); break;  // 10 .. 13
     }
 }
-
+// words behind the redo flag that ONE blob's cooperative launch expects cleared (its hand-off counters), or 0 when a one-blob call on this
+// table would not take the cooperative kernel (switched off, or a geometry that does not fit: the caller then keeps the plain path)
+uint32_t direct_one_blob_counter_words(int bits) {
+    const DirectPlanRt plan = make_plan(bits);
+    if (!plan.entries || coop_max_blobs() < 1) return 0;
+    CoopParams prm{};
+    uint32_t units = 0, counters = 0;
+    coop_geometry(plan, coop_rows_per_quad(plan.nw, 1), prm.n0, units, counters);
+    if (!(units <= (uint32_t)kBlobElems && 1 + counters <= (uint32_t)kNumBuckets + 1)) return 0;
+    return counters;
+}
 template <int CT>
 static void launch_direct_only_t(const DirectPlanRt &plan, const uint64_t *table, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *sums,
                                  const uint32_t *only_if, size_t n_blobs, hipStream_t st) {

@@ -473,6 +473,7 @@ static void ctx_destroy(Ctx *c) {
     }
     if (c->comb.pinned_blobs) hipHostFree(c->comb.pinned_blobs);
     dev_free(c->host_res);
+    if (c->one_pin) hipHostFree(c->one_pin);
     for (int k = 0; k < 2; k++) {
         dev_free(c->stage.slot[k]);
         if (c->stage.copied[k]) hipEventDestroy(c->stage.copied[k]);
@@ -740,20 +741,20 @@ Ctx *ctx_of(const KZGSettings *s) {
 // workgroups, as when the settings' other context is busy, so that the compute units they sit on do not set the launch's end
 // `lagrange`: the scalars are evaluations on the bit-reversed domain and the MSM runs over the Lagrange form of the setup
 static G1Xyzz29 *msm_sums_stage(Ctx *c, const uint32_t *scalars_raw, size_t n, hipStream_t st, size_t base = 0, bool shared_chip = false,
-                                bool lagrange = false) {
+                                bool lagrange = false, G1Xyzz29 *sums_out = nullptr, uint32_t *redo_flag_out = nullptr) {
     Workspace &w = c->ws;
     uint32_t *sorted = w.sorted + base * (size_t)kMaxEntries;
     uint32_t *bstart = w.bucket_start + base * (size_t)(kNumBuckets + 1);
     uint32_t *perm = w.perm + base * (size_t)(kNumBuckets + 1);
     G1Xyzz29 *buckets = w.buckets + base * (size_t)kNumBuckets;
-    G1Xyzz29 *sums = w.sums + base;
+    G1Xyzz29 *sums = sums_out ? sums_out : w.sums + base;   // (sums_out: anywhere the device can write -- pinned host memory for a one-blob call, r06)
     const G1Affine29 *direct = lagrange ? c->lag.direct_table : c->direct_table;
     if (direct) {  // giant-table path: gather + add, nothing else
         // (scratch of the bucket engine, idle on this path: `buckets` holds the per-lane sums of the hand-scheduled kernel,
         // `sorted` the per-workgroup partial sums, `bstart` the redo flags)
         launch_direct_msm(lagrange ? c->lag.direct_bits : c->direct_bits, lagrange ? c->lag.direct_tab.win_dev : c->direct_tab.win_dev,
                           lagrange ? c->lag.direct_row_bytes : c->direct_row_bytes, scalars_raw, buckets, (G1Xyzz29 *)sorted, bstart, sums, n,
-                          st, (shared_chip || peer_busy(c)) ? 2048 : 0);
+                          st, (shared_chip || peer_busy(c)) ? 2048 : 0, redo_flag_out);
         return sums;
     }
     launch_digit_sort(scalars_raw, sorted, bstart, perm, n, st);
@@ -866,11 +867,11 @@ static bool quotient_to_msm_form(Ctx *c, int mode, size_t n, hipStream_t st, siz
 // form (proof_in_evaluation_form; quotient_stage reads what this function left) -- the blob's own evaluations, copied and
 // range-checked with no transform at all. Returns true in that case: an MSM of these scalars must run on the Lagrange form.
 static bool coefficients_stage(Ctx *c, const uint8_t *blobs, size_t n, int mode, int32_t *status, hipStream_t st,
-                               size_t base = 0, bool evaluations_ok = false) {
+                               size_t base = 0, bool evaluations_ok = false, uint32_t *zero = nullptr, uint32_t zero_words = 0) {
     Workspace &w = c->ws;
     uint32_t *scalars = w.scalars + base * (size_t)kBlobElems * 8;
     if (mode == LWKZG_MODE_REFERENCE) {
-        launch_parse_be_reduce(blobs, scalars, n * kBlobElems, st);
+        launch_parse_be_reduce(blobs, scalars, n * kBlobElems, st, zero, zero_words);   // (zero: reference mode only -- the caller checks)
     } else if (evaluations_ok ? commit_on_lagrange(c, mode) : proof_in_evaluation_form(c, mode)) {
         launch_copy_le_check(blobs, scalars, status, n, st);
         return true;
@@ -2405,13 +2406,15 @@ static bool combiner_init(Ctx *c) {
 }
 
 // one launch set for `batch` (all of one mode) on lane `lane`; fills every request's rc and output
-static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch) {
+static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch, bool plain = false) {
     Combiner &cb = c->comb;
     const size_t n = batch.size();
     const int mode = batch[0]->mode;
     const size_t lo = (size_t)lane * kCombineMaxBatch;  // this lane's slice of the workspace
     hipStream_t sk = c->aux[lane];
     const bool host_finish = n <= host_finish_limit();
+    bool zero_copy = false;
+    uint32_t *redo_flag = nullptr;
     C_KZG_RET rc = C_KZG_OK;
     {
         std::lock_guard<std::mutex> lk(c->mu);  // enqueue only: the wait below happens outside
@@ -2424,20 +2427,40 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
             WsLaneUse use(c, lane);
             Workspace &w = c->ws;
             uint8_t *d_blobs = w.blobs + lo * (size_t)kBlobBytes;
-            for (size_t i = 0; i < n && ok; i++)
+            // ONE blob -- the reference's call shape (src/lib.rs:253-283) -- moves no buffer at all (r06): the parse kernel reads the blob from
+            // its pinned staging slot across the link, the cooperative kernel's last wave stores the sum into pinned memory, and in
+            // reference mode, where a blob cannot be rejected, no verdict is cleared or fetched. A kernel trace of r05's call showed the
+            // 118 us kernel among 57 us of copies, fills and the gaps between them (profiles/r06_experiments.md section 7).
+            zero_copy = n == 1 && host_finish && !plain && knobs().zero_copy && (c->direct_table != nullptr || c->lag.direct_table != nullptr);
+            if (zero_copy) d_blobs = cb.pinned_blobs + (size_t)batch[0]->slot * kBlobBytes;
+            // ... and in reference mode on the cooperative kernel two more launches go: the fill of the hand-off counters (the parse kernel
+            // clears them on its way) and the second pass that exits at once on honest data (the redo flag is a pinned word this thread
+            // looks at after its one synchronisation; a flagged call -- P = +-Q inside a quad: chosen scalars only -- is repeated the long way)
+            uint32_t ctr_words = 0;
+            if (zero_copy && mode == LWKZG_MODE_REFERENCE && c->direct_table) ctr_words = direct_one_blob_counter_words(c->direct_bits);
+            if (ctr_words) {
+                redo_flag = (uint32_t *)&cb.pinned_status[lane][1];
+                *redo_flag = 0;
+            }
+            for (size_t i = 0; i < n && ok && !zero_copy; i++)
                 ok = hipMemcpyAsync(d_blobs + i * (size_t)kBlobBytes, cb.pinned_blobs + (size_t)batch[i]->slot * kBlobBytes, kBlobBytes,
                                     hipMemcpyHostToDevice, sk) == hipSuccess;
-            ok = ok && hipMemsetAsync(w.status + lo, 0, n * 4, sk) == hipSuccess;
+            const bool verdicts = !(zero_copy && mode == LWKZG_MODE_REFERENCE);
+            if (verdicts) ok = ok && hipMemsetAsync(w.status + lo, 0, n * 4, sk) == hipSuccess;
+            else cb.pinned_status[lane][0] = 0;
             if (ok) {
-                const bool lg = coefficients_stage(c, d_blobs, n, mode, w.status + lo, sk, lo, true);
-                if (host_finish) {  // the sums come back as they are; inversion and compression below, on this thread
+                uint32_t *ctr0 = w.bucket_start + lo * (size_t)(kNumBuckets + 1) + 1;   // (msm_sums_stage: redo flags at bstart, the counters behind them)
+                const bool lg = coefficients_stage(c, d_blobs, n, mode, w.status + lo, sk, lo, true, redo_flag ? ctr0 : nullptr, ctr_words);
+                if (zero_copy) {
+                    (void)msm_sums_stage(c, w.scalars + lo * (size_t)kBlobElems * 8, n, sk, lo, false, lg, (G1Xyzz29 *)cb.pinned_out[lane], redo_flag);
+                } else if (host_finish) {  // the sums come back as they are; inversion and compression below, on this thread
                     const G1Xyzz29 *sums = msm_sums_stage(c, w.scalars + lo * (size_t)kBlobElems * 8, n, sk, lo, false, lg);
                     ok = hipMemcpyAsync(cb.pinned_out[lane], sums, n * sizeof(G1Xyzz29), hipMemcpyDeviceToHost, sk) == hipSuccess;
                 } else {
                     msm_stages(c, w.scalars + lo * (size_t)kBlobElems * 8, w.out48 + 48 * lo, n, sk, lo, false, lg);
                     ok = hipMemcpyAsync(cb.pinned_out[lane], w.out48 + 48 * lo, n * 48, hipMemcpyDeviceToHost, sk) == hipSuccess;
                 }
-                ok = ok && hipMemcpyAsync(cb.pinned_status[lane], w.status + lo, n * 4, hipMemcpyDeviceToHost, sk) == hipSuccess;
+                if (verdicts) ok = ok && hipMemcpyAsync(cb.pinned_status[lane], w.status + lo, n * 4, hipMemcpyDeviceToHost, sk) == hipSuccess;
             }
         }
         if (!ok && rc == C_KZG_OK) {
@@ -2449,6 +2472,7 @@ static void combine_run(Ctx *c, int lane, const std::vector<CombineReq *> &batch
         set_error("blob_to_kzg_commitment (coalesced): %s", hipGetErrorString(hipGetLastError()));
         rc = C_KZG_ERROR;
     }
+    if (rc == C_KZG_OK && redo_flag && *redo_flag != 0) return combine_run(c, lane, batch, true);   // the complete-branches pass, the long way
     for (size_t i = 0; i < n; i++) {
         CombineReq *r = batch[i];
         if (rc != C_KZG_OK) {
@@ -2884,6 +2908,48 @@ static C_KZG_RET blob_proof_batch_impl(KZGProof *out, const Blob *blobs, const B
     return blob_proof_batch_host(c, out, blobs, commitments, n, mode, first_bad);
 }
 
+// compute_blob_kzg_proof of ONE blob in reference mode on a direct table -- the reference's own call shape (src/lib.rs:361-404) -- with
+// nothing on its critical path that need not be there (r06; r05: 0.32-0.35 ms, of which the host's validation of the commitment, 0.2 ms
+// of one thread, sat between the enqueue and the wait, LONGER than the GPU's whole chain behind the digest). Here the commitment is
+// validated on a thread of its own from the first instruction on; the parse kernel runs beside this thread's hashing (and clears the
+// cooperative kernel's hand-off counters on its way); the digest is read by k_z_from_bytes from pinned memory, the sum is stored into
+// pinned memory by the MSM's last wave, the redo flag is a pinned word: no copy of a result, no fill, no second-pass launch, no verdict
+// word (a reference-mode parse cannot fail; the validation's verdict is this process's own). Anything irregular -- an invalid or
+// non-canonically encoded commitment, P = +-Q inside a quad, no pinned memory -- returns kOneBlobFallback and the caller takes the
+// general path, which owns the error codes. Caller holds c->mu and the workspace.
+static const C_KZG_RET kOneBlobFallback = (C_KZG_RET)100;   // (not a value of the ABI: internal)
+static C_KZG_RET blob_proof_one_host(Ctx *c, uint8_t *out48, const uint8_t *blob, const uint8_t *comm48, int mode) {
+    if (mode != LWKZG_MODE_REFERENCE || !c->direct_table || !knobs().zero_copy || peer_busy(c)) return kOneBlobFallback;
+    const uint32_t ctr_words = direct_one_blob_counter_words(c->direct_bits);
+    if (!ctr_words) return kOneBlobFallback;
+    if (!c->one_pin && hipHostMalloc((void **)&c->one_pin, 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->one_pin = nullptr;
+        return kOneBlobFallback;
+    }
+    if (ctx_reserve(c, 1) != C_KZG_OK) return kOneBlobFallback;
+    Workspace &w = c->ws;
+    hipStream_t st = c->stream;
+    G1Xyzz29 *p_sum = (G1Xyzz29 *)c->one_pin;
+    uint32_t *p_redo = (uint32_t *)(c->one_pin + 256);
+    uint8_t *p_dig = c->one_pin + 320;
+    *p_redo = 0;
+    uint8_t canon[48];
+    int vrc = 2;
+    SideTask validator([&]() { vrc = host_validate_commitment(comm48, canon); });   // lib.rs:372-375, beside everything below
+    LWK_HIP(hipMemcpyAsync(w.blobs, blob, kBlobBytes, hipMemcpyHostToDevice, st));
+    (void)coefficients_stage(c, w.blobs, 1, mode, w.status, st, 0, false, w.bucket_start + 1, ctr_words);
+    challenge_digests_host(p_dig, blob, comm48, 1);   // on this thread, beside the upload and the parse (assumes canonical commitment bytes)
+    launch_z_from_bytes(p_dig, w.z, nullptr, 0, 1, st);   // digest -> Fr, reduced (utils.rs:148-154); read across the link
+    quotient_stage(c, mode, w.scalars, w.z, w.scalars2, nullptr, 0, 1, st);
+    (void)msm_sums_stage(c, w.scalars2, 1, st, 0, false, quotient_to_msm_form(c, mode, 1, st), p_sum, p_redo);
+    validator.join();
+    LWK_HIP(hipStreamSynchronize(st));
+    if (vrc != 0 || memcmp(canon, comm48, 48) != 0 || *p_redo != 0) return kOneBlobFallback;   // (vrc 1: infinity -- canonical c0 00.. only; keep it simple)
+    host_finish_compress(out48, *p_sum);
+    return C_KZG_OK;
+}
+
 static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n, int mode,
                                        size_t *first_bad) {
     std::lock_guard<std::mutex> lk(c->mu);
@@ -2891,6 +2957,10 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
     WsUse wsu(c, c->stream);
     if (n >= kMaxChunk / 2)
         return blob_proofs_sliced(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, n, mode, first_bad);
+    if (n == 1) {
+        const C_KZG_RET r1 = blob_proof_one_host(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, mode);
+        if (r1 != kOneBlobFallback) return r1;
+    }
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         C_KZG_RET rc = ctx_reserve(c, m);

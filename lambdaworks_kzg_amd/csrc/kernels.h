@@ -22,7 +22,7 @@ struct ProfScope {
 // ---- scalar ingest (msm.hip)
 // Mode R: 32-byte big-endian elements -> canonical 8xu32 little-endian limbs, reduced mod r
 // (blob_to_polynomial, /root/reference/src/utils.rs:27-41).
-void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st);
+void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st, uint32_t *zero = nullptr, uint32_t zero_words = 0);
 // Mode C: 32-byte little-endian elements, must be canonical (else status[blob] = BADARGS) -> Montgomery Fr
 
 // ---- MSM (msm.hip)
@@ -67,7 +67,9 @@ void free_direct_table(DirectTable &table);
 // otherwise); `lane_scratch` 4096 * n_blobs entries (the per-lane sums of the hand-scheduled kernel) and `redo` n_blobs words (its flags).
 // fill: workgroups to aim for (0 = 512, the right number when the kernel has the chip alone; see direct.hip).
 void launch_direct_msm(int bits, const uint64_t *win_dev, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *lane_scratch,
-                       G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0);
+                       G1Xyzz29 *partials, uint32_t *redo, G1Xyzz29 *sums, size_t n_blobs, hipStream_t st, int fill = 0,
+                       uint32_t *redo_flag_out = nullptr);
+uint32_t direct_one_blob_counter_words(int bits);   // r06: see direct.hip
 // sums[b] recomputed for the blobs with only_if[b] != 0 (one workgroup each, complete branches; exits at once for the others)
 void launch_direct_msm_only(int bits, const uint64_t *win_dev, size_t row_bytes, const uint32_t *scalars_raw, G1Xyzz29 *sums,
                             const uint32_t *only_if, size_t n_blobs, hipStream_t st);

@@ -61,6 +61,7 @@ struct Knobs {
     int verify_order = 0;            // LWKZG_VERIFY_ORDER=1: the other submission order of hash and validation (shipped: the hash first up to 8192 blobs, last above)
     int verify_cu_mask = 0;          // LWKZG_VERIFY_CU_MASK=k: side streams confined to k compute units per XCD (hipExtStreamCreateWithCUMask)
     int vmsm_list_cap = 0;           // LWKZG_VMSM_LIST_CAP: rows per digit a slice lists before the scan fallback (tests force the fallback with 1)
+    bool zero_copy = true;           // LWKZG_ZERO_COPY=0: a one-blob commitment copies its blob up and its sum and verdict back (r05) instead of reading / writing pinned memory from the kernels
     bool host_stage = true;          // LWKZG_HOST_STAGE=0: long host-pointer batches in r05's 512-blob slices on two streams instead of whole chunks from the device-side double buffer
 };
 

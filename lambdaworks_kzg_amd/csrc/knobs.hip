@@ -107,6 +107,7 @@ Knobs read_env() {
     r.num(k.verify_order, "LWKZG_VERIFY_ORDER", EXP);
     r.num(k.verify_cu_mask, "LWKZG_VERIFY_CU_MASK", EXP);
     r.num(k.vmsm_list_cap, "LWKZG_VMSM_LIST_CAP", EXP);
+    r.flag(k.zero_copy, "LWKZG_ZERO_COPY", EXP);
     r.flag(k.host_stage, "LWKZG_HOST_STAGE", EXP);
     return k;
 }
@@ -129,7 +130,7 @@ const char *knob_names_experimental() {
            "LWKZG_MID_PROOF_PIPE LWKZG_MID_PROOF_PIPE_MIN LWKZG_MID_PROOF_PARTS LWKZG_MID_PROOF_CHUNKS LWKZG_HEAVY_SERIAL LWKZG_PROOF_SCHEDULE LWKZG_SPLIT "
            "LWKZG_SLICE0 LWKZG_SET_MODE_IN_PLACE LWKZG_PAIRING_GENERIC_SQR LWKZG_PAIRING_NAIVE LWKZG_PAIRING_NO_PRECOMP "
            "LWKZG_PAIRING_ONE_THREAD LWKZG_VERIFY_MSM LWKZG_VERIFY_FUSED LWKZG_VERIFY_PAD_KB LWKZG_VERIFY_ORDER LWKZG_VERIFY_CU_MASK LWKZG_VMSM_LIST_CAP "
-           "LWKZG_HOST_STAGE";
+           "LWKZG_HOST_STAGE LWKZG_ZERO_COPY";
 }
 
 }  // namespace lwk

@@ -29,9 +29,11 @@ namespace lwk {
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 // one lane per field element; 32 B in (2 x 16 B), 32 B out
+// (zero / zero_words, r06: words this launch clears on its way -- a one-blob call's hand-off counters, instead of a fill launch of their own)
 __global__ __launch_bounds__(256) void k_parse_be_reduce(const uint4 *__restrict__ in, uint4 *__restrict__ out,
-                                                         size_t n_elems) {
+                                                         size_t n_elems, uint32_t *__restrict__ zero, uint32_t zero_words) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < zero_words) zero[i] = 0u;
     if (i >= n_elems) return;
     uint4 hi = in[2 * i], lo = in[2 * i + 1];  // big-endian: first 16 bytes are the most significant
     uint32_t s[8];
@@ -55,11 +57,11 @@ __global__ __launch_bounds__(256) void k_parse_be_reduce(const uint4 *__restrict
     out[2 * i + 1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st) {
+void launch_parse_be_reduce(const uint8_t *blobs, uint32_t *scalars_raw, size_t n_elems, hipStream_t st, uint32_t *zero, uint32_t zero_words) {
     ProfScope p("k_parse_be_reduce", st);
     unsigned grid = (unsigned)((n_elems + 255) / 256);
     hipLaunchKernelGGL(k_parse_be_reduce, dim3(grid), dim3(256), 0, st, (const uint4 *)blobs, (uint4 *)scalars_raw,
-                       n_elems);
+                       n_elems, zero, zero_words < n_elems ? zero_words : (uint32_t)n_elems);
 }
 
 // ------------------------------------------------------------------------------------------------
