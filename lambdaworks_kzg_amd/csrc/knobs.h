@@ -53,6 +53,7 @@ struct Knobs {
     int split = 0;                   // LWKZG_SPLIT: windows of a scalar over this many workgroups (tiny batches)
     size_t slice0 = 0;               // LWKZG_SLICE0: first slice of a long host-pointer batch
     bool set_mode_in_place = true;   // LWKZG_SET_MODE_IN_PLACE=0
+    bool host_fp_portable = false;   // LWKZG_HOST_FP_PORTABLE: the C product of hostfp.h on a core that has MULX/ADX (the A/B arm)
     bool pairing_generic_sqr = false, pairing_naive = false, pairing_no_precomp = false, pairing_one_thread = false;  // LWKZG_PAIRING_*
     // r06, batch verification
     int verify_msm = 1;              // LWKZG_VERIFY_MSM=0: r05's per-point multiples + Straus pieces (k_point_multiples, k_lincomb3)

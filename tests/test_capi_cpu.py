@@ -139,13 +139,14 @@ print("".join("1" if v else "0" for v in out))
 
 
 def test_host_pairing_variants_agree():
-    """the fixed-Q line precomputation + sparse line products (default: two pairs on two threads; and on one), the loop that walks T itself, the generic Fp12
+    """the fixed-Q line precomputation + sparse line products (default: two pairs on two threads; and on one; and with the host's Fp product in C
+    instead of fp_x86.S), the loop that walks T itself, the generic Fp12
     squaring and the plain 1268-bit final exponentiation all give the expected verdicts on bilinearity cases over
     thirteen distinct G2 points of the tau = 1337 setup"""
     import sys
     code = _PAIRING_CASES % (ROOT, os.path.join(ROOT, "tests", "golden"), SETUP_PATH)
     want = "100" * 12 + "10"
-    for var in ({}, {"LWKZG_PAIRING_ONE_THREAD": "1"}, {"LWKZG_PAIRING_NO_PRECOMP": "1"}, {"LWKZG_PAIRING_GENERIC_SQR": "1"},
+    for var in ({}, {"LWKZG_HOST_FP_PORTABLE": "1"}, {"LWKZG_PAIRING_ONE_THREAD": "1"}, {"LWKZG_PAIRING_NO_PRECOMP": "1"}, {"LWKZG_PAIRING_GENERIC_SQR": "1"},
                 {"LWKZG_PAIRING_NAIVE": "1", "LWKZG_PAIRING_NO_PRECOMP": "1"}):
         env = dict(os.environ, LWKZG_EXPERIMENTAL="1", **var)     # (cross-check arms are experiment knobs: csrc/knobs.h)
         got = subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1]
