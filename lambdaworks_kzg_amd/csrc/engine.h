@@ -32,23 +32,29 @@ const char *get_error();
         }                                                                                     \
     } while (0)
 
-// A piece of host work that runs beside the caller when a thread can be had, and inline when it cannot:
-// std::thread's constructor throws std::system_error under resource exhaustion, and nothing may unwind across the C ABI.
+// A piece of host work that runs beside the caller when a thread can be had, and inline when it cannot. The threads are persistent
+// (sha256_host.hip: side workers, created on demand, parked on a condition variable): handing a job to a parked thread and waiting for
+// it costs ~7 us where creating and joining a std::thread cost ~50 us on the build host -- and a one-blob verification has four such
+// jobs on its critical path. Nothing may unwind across the C ABI: a thread that cannot be created means the job runs inline.
+struct SideWorker;
+SideWorker *side_worker_acquire();                                   // nullptr: none idle and none could be created
+void side_worker_run(SideWorker *w, std::function<void()> fn);       // returns at once
+void side_worker_wait(SideWorker *w);                                // until fn has returned; the worker is idle again afterwards
 struct SideTask {
-    std::thread t;
+    SideWorker *w = nullptr;
     SideTask() = default;
     template <class F>
     explicit SideTask(F &&f) { start(static_cast<F &&>(f)); }
     template <class F>
     void start(F &&f) {
-        try {
-            t = std::thread(f);
-        } catch (...) {
-            f();
-        }
+        join();
+        w = side_worker_acquire();
+        if (w) side_worker_run(w, std::function<void()>(f));
+        else f();
     }
     void join() {
-        if (t.joinable()) t.join();
+        if (w) side_worker_wait(w);
+        w = nullptr;
     }
     ~SideTask() { join(); }
     SideTask(const SideTask &) = delete;

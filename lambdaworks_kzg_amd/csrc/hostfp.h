@@ -155,6 +155,7 @@ inline HostField<Par> operator*(const HostField<Par> &a, const HostField<Par> &b
 // tools/gen_fp_x86.py; 37 ns against 59 ns for the C above on the build host). The C path stays for other cores and
 // is what tests/test_host_fp_asm_cpu.py compares it with. Non-template, so overload resolution prefers it for HFp.
 extern "C" void lwk_fp_mul_adx(uint64_t *r, const uint64_t *a, const uint64_t *b);
+extern "C" void lwk_fp2_mul_adx(uint64_t *r, const uint64_t *a, const uint64_t *b);  // 12 limbs each: (c0, c1) of Fp[u]/(u^2 + 1)
 extern "C" int lwk_cpu_has_bmi2_adx(void);
 inline bool hf_fp_on_adx() {
     static const bool yes = lwk_cpu_has_bmi2_adx() != 0 && !knobs().host_fp_portable;

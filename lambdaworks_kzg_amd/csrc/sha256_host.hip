@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -303,6 +304,90 @@ class HostPool {
 };
 
 }  // namespace
+
+// ---- side workers (engine.h: SideTask) ----------------------------------------------------------------------------------------------
+// One job at a time per worker, handed over under the worker's own mutex; the workers are detached and the table is leaked (a thread
+// parked on a condition variable must never see it destroyed), a forked child starts a table of its own.
+struct SideWorker {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<void()> fn;
+    int state = 0;                    // 0 parked, 1 job handed over, 2 job done
+    std::atomic<bool> taken{false};
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_job.wait(lk, [this]() { return state == 1; });
+            lk.unlock();
+            fn();
+            lk.lock();
+            fn = nullptr;
+            state = 2;
+            cv_done.notify_one();
+        }
+    }
+};
+namespace {
+constexpr unsigned kSideWorkersMax = 64;
+struct SideTable {
+    pid_t pid;
+    std::mutex mu;                    // growing the table
+    std::atomic<unsigned> n{0};
+    SideWorker *w[kSideWorkersMax];
+};
+std::atomic<SideTable *> g_side{nullptr};
+std::mutex g_side_mu;
+}  // namespace
+
+SideWorker *side_worker_acquire() {
+    SideTable *t = g_side.load(std::memory_order_acquire);
+    if (!t || t->pid != getpid()) {
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        t = g_side.load(std::memory_order_acquire);
+        if (!t || t->pid != getpid()) {
+            t = new (std::nothrow) SideTable;
+            if (!t) return nullptr;
+            t->pid = getpid();
+            g_side.store(t, std::memory_order_release);
+        }
+    }
+    const unsigned n = t->n.load(std::memory_order_acquire);
+    for (unsigned i = 0; i < n; i++)
+        if (!t->w[i]->taken.exchange(true, std::memory_order_acquire)) return t->w[i];
+    std::lock_guard<std::mutex> lk(t->mu);
+    const unsigned m = t->n.load(std::memory_order_acquire);
+    if (m >= kSideWorkersMax) return nullptr;
+    SideWorker *w = new (std::nothrow) SideWorker;
+    if (!w) return nullptr;
+    w->taken.store(true, std::memory_order_relaxed);
+    try {
+        std::thread([w]() { w->loop(); }).detach();
+    } catch (...) {
+        delete w;
+        return nullptr;
+    }
+    t->w[m] = w;
+    t->n.store(m + 1, std::memory_order_release);
+    return w;
+}
+
+void side_worker_run(SideWorker *w, std::function<void()> fn) {
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->fn = std::move(fn);
+        w->state = 1;
+    }
+    w->cv_job.notify_one();
+}
+
+void side_worker_wait(SideWorker *w) {
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv_done.wait(lk, [w]() { return w->state == 2; });
+        w->state = 0;
+    }
+    w->taken.store(false, std::memory_order_release);
+}
 
 namespace {
 std::atomic<int64_t> g_host_last_active_ns{0};

@@ -15,6 +15,8 @@
 #include <memory>
 #include "fp2.h"
 #include "hostfp.h"
+#include "glv.cuh"
+#include <mutex>
 
 #include <string.h>
 
@@ -84,11 +86,109 @@ HXyzz xyzz_neg(const HXyzz &p) {
     return r;
 }
 
-HXyzz scalar_mul(const HXyzz &p, const uint32_t k[8]) {
+// [k]P, left-to-right double-and-add: the definition (and the path of a k that is not below r)
+HXyzz scalar_mul_plain(const HXyzz &p, const uint32_t k[8]) {
     HXyzz acc = HXyzz::infinity();
     for (int i = 255; i >= 0; i--) {
         acc = xyzz_dbl(acc);
         if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+const HFp &host_beta() {
+    static const HFp b = []() {
+        uint32_t braw[12];
+        g1_beta_raw(braw);
+        return HFp::from_fe(fe_from_raw<FpParams>(braw));
+    }();
+    return b;
+}
+
+// [k]P for P in G1 and k < r: the split of glv.cuh, k = lo + hi z^2 with [z^2]P = -phi(P) = (beta x, -y), both halves 128 bits, read
+// four bits at a time against the sixteen multiples of P and their images -- 128 doublings and at most 64 additions where the loop
+// above has 256 and ~128 (0.14 -> 0.06 ms under a one-blob verification). The caller's points passed the subgroup test.
+HXyzz scalar_mul(const HXyzz &p, const uint32_t k[8]) {
+    if (p.is_inf()) return p;
+    if (raw_geq<8>(k, FrParams::MOD)) return scalar_mul_plain(p, k);
+    uint32_t lo[4], hi[4];
+    split_by_z2_barrett(lo, hi, k);
+    HXyzz t1[16], t2[16];
+    t1[1] = p;
+    t1[2] = xyzz_dbl(p);
+    for (int i = 3; i < 16; i++) t1[i] = xyzz_add(t1[i - 1], p);
+    const HFp &beta = host_beta();
+    for (int i = 1; i < 16; i++) {
+        t2[i] = t1[i];
+        if (t2[i].is_inf()) continue;   // (cannot happen for a point of order r; kept so that the table is right for any input)
+        t2[i].x = beta * t1[i].x;
+        t2[i].y = neg(t1[i].y);
+    }
+    HXyzz acc = HXyzz::infinity();
+    for (int w = 31; w >= 0; w--) {
+        for (int d = 0; d < 4; d++) acc = xyzz_dbl(acc);   // returns at once while acc is still empty
+        const uint32_t a = (lo[w >> 3] >> (4 * (w & 7))) & 15u, b = (hi[w >> 3] >> (4 * (w & 7))) & 15u;
+        if (a) acc = xyzz_add(acc, t1[a]);
+        if (b) acc = xyzz_add(acc, t2[b]);
+    }
+    return acc;
+}
+
+// [k]G for the generator of the settings (srs.powers_main_group[0]): every verification multiplies the SAME point, so its multiples
+// j 16^w G (w < 64, j = 1..15) are kept in affine form per distinct generator -- 64 mixed additions and no doubling per product
+// (0.14 -> 0.02 ms). Built at the first verification on a generator (960 additions, one inversion: under a millisecond).
+struct FixedBase {
+    HFp gx, gy;
+    std::vector<HFp> x, y;   // [w * 15 + (j - 1)]
+};
+std::shared_ptr<const FixedBase> fixed_base_of(const G1Affine &g) {
+    static std::mutex mu;
+    static std::shared_ptr<const FixedBase> last;
+    const HFp gx = HFp::from_fe(g.x), gy = HFp::from_fe(g.y);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (last && last->gx == gx && last->gy == gy) return last;
+    }
+    auto fb = std::make_shared<FixedBase>();
+    fb->gx = gx;
+    fb->gy = gy;
+    const size_t n = 64 * 15;
+    std::vector<HXyzz> m(n);
+    HXyzz base = HXyzz::from_affine(gx, gy);
+    for (int w = 0; w < 64; w++) {
+        m[15 * w] = base;
+        for (int j = 1; j < 15; j++) m[15 * w + j] = xyzz_add(m[15 * w + j - 1], base);
+        base = xyzz_add(m[15 * w + 14], base);   // 16 x
+    }
+    // to affine with one inversion (Montgomery's trick over zz * zzz); an entry at infinity (a generator of tiny order: not a
+    // setup anyone verifies against) leaves the table unusable and the caller on the generic product
+    std::vector<HFp> d(n), pre(n);
+    for (size_t i = 0; i < n; i++) {
+        if (m[i].is_inf()) return nullptr;
+        d[i] = m[i].zz * m[i].zzz;
+        pre[i] = i ? pre[i - 1] * d[i] : d[i];
+    }
+    HFp iv = inv(pre[n - 1]);
+    fb->x.resize(n);
+    fb->y.resize(n);
+    for (size_t i = n; i-- > 0;) {
+        const HFp di = i ? iv * pre[i - 1] : iv;   // 1 / (zz zzz)
+        if (i) iv = iv * d[i];
+        fb->x[i] = m[i].x * (di * m[i].zzz);
+        fb->y[i] = m[i].y * (di * m[i].zz);
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    last = fb;
+    return fb;
+}
+
+HXyzz generator_mul(const G1Affine &g, const uint32_t k[8]) {
+    std::shared_ptr<const FixedBase> fb = fixed_base_of(g);
+    if (!fb) return scalar_mul_plain(HXyzz::from_affine(HFp::from_fe(g.x), HFp::from_fe(g.y)), k);   // (only on-curve is known of it)
+    HXyzz acc = HXyzz::infinity();
+    for (int w = 0; w < 64; w++) {
+        const uint32_t j = (k[w >> 3] >> (4 * (w & 7))) & 15u;
+        if (j) acc = xyzz_madd(acc, fb->x[15 * w + j - 1], fb->y[15 * w + j - 1]);
     }
     return acc;
 }
@@ -149,11 +249,19 @@ C_KZG_RET verify_core(bool *ok, const HostPoint &c, const uint32_t z[8], const u
         set_error("g1_values[0] is not a curve point");
         return C_KZG_ERROR;
     }
+    const bool timing = knobs().timing;
+    const auto t0 = std::chrono::steady_clock::now();
     HXyzz zpi;
     SideTask side([&]() { zpi = scalar_mul(to_xyzz(pi), z); });  // the two scalar multiplications side by side
-    HXyzz lhs = xyzz_add(to_xyzz(c), xyzz_neg(scalar_mul(to_xyzz(g), y)));  // C - [y]G
+    HXyzz lhs = xyzz_add(to_xyzz(c), xyzz_neg(generator_mul(g.a, y)));  // C - [y]G
+    const auto t1 = std::chrono::steady_clock::now();
     side.join();
     lhs = xyzz_add(lhs, zpi);                                               //   + [z]pi
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lambdaworks_kzg_amd] verification: C - [y]G %.3f ms, [z]pi beside it done after %.3f ms\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t0).count());
+    }
     return pairing_verdict(ok, lhs, to_xyzz(pi), s);
 }
 
@@ -245,9 +353,15 @@ C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Byte
     // order of the reference: commitment, z, y, proof (lib.rs:424-440)
     // (every failure here is the same return code, so the two decompressions may run side by side)
     bool pi_ok = false;
+    const auto t0 = std::chrono::steady_clock::now();
     SideTask side([&]() { pi_ok = host_g1_decompress(pi, proof_bytes->bytes); });
     const bool c_ok = host_g1_decompress(c, commitment_bytes->bytes);
+    const auto t1 = std::chrono::steady_clock::now();
     side.join();
+    if (knobs().timing)
+        fprintf(stderr, "[lambdaworks_kzg_amd] verification: commitment decompressed + subgroup test %.3f ms, the proof beside it done after %.3f ms\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (!c_ok) { set_error("invalid commitment"); return bad(mode); }
     if (!fr_from_bytes(z, z_bytes->bytes, mode)) { set_error("z is not canonical"); return bad(mode); }
     if (!fr_from_bytes(y, y_bytes->bytes, mode)) { set_error("y is not canonical"); return bad(mode); }
@@ -602,7 +716,7 @@ static C_KZG_RET verify_batch_impl(bool *ok, const Blob *blobs, const Bytes48 *c
         side.start([&, ys]() {
             uint32_t ys_raw[8];
             hfr_to_raw(ys_raw, ys);
-            ysum_g = scalar_mul(to_xyzz(g), ys_raw);
+            ysum_g = generator_mul(g.a, ys_raw);
         });
     });
     side.join();
@@ -722,7 +836,7 @@ C_KZG_RET lwkzg_verify_shards_finish(bool *ok, const uint8_t *partials, size_t n
     if (!setup_generator(g, s)) return C_KZG_ERROR;
     uint32_t ys_raw[8];
     hfr_to_raw(ys_raw, ysum);
-    return batch_verdict(ok, sums, scalar_mul(to_xyzz(g), ys_raw), s);
+    return batch_verdict(ok, sums, generator_mul(g.a, ys_raw), s);
 }
 
 // sum of compressed points on the host (gathering the per-GPU partial sums of a sharded long MSM: SURVEY 8e,

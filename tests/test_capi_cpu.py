@@ -326,3 +326,44 @@ def test_glv_split_by_barrett_equals_the_restoring_division(tmp_path):
     subprocess.check_call(["g++", "-O2", "-Wall", "-Werror", "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "glv_split_check.cpp"), "-o", exe])
     n, bad = (int(x) for x in subprocess.check_output([exe], text=True).split())
     assert n > 1000000 and bad == 0
+
+
+def test_host_scalar_products_of_a_verification(K, oracle, oracle_setup):
+    """verify_kzg_proof (/root/reference/src/lib.rs:407-456) is host arithmetic end to end, so it runs here on a KZGSettings put together by hand
+    (the oracle's points in the blst layout, no context): [y]G over the generator's window table and [z]pi over the endomorphism
+    split (verify.hip: generator_mul, scalar_mul) against the oracle's own products, on scalars around every boundary of the two --
+    nibble carries, the 128-bit halves, multiples of z^2, r - 1 -- with C = [y + (tau - z) a]G, pi = [a]G, tau = 1337."""
+    import ctypes as C
+    import random
+    import struct
+    from conftest import R
+    from lambdaworks_kzg_amd import capi
+
+    def blst_fp(be48):
+        return struct.pack("<6Q", *[int.from_bytes(be48[8 * k:8 * k + 8], "big") for k in range(6)])
+
+    g2 = b""
+    for k in (1, 1337):
+        xy = oracle.g2_generator_mul(k)
+        g2 += b"".join(blst_fp(xy[48 * j:48 * j + 48]) for j in range(4)) + blst_fp((1).to_bytes(48, "big")) + blst_fp(bytes(48))
+    g1 = oracle_setup.g1_blst()[:144]
+    g1_buf, g2_buf = C.create_string_buffer(g1, len(g1)), C.create_string_buffer(g2, len(g2))
+    s = capi.KZGSettings()
+    s.fs, s.g1_values, s.g2_values = None, C.addressof(g1_buf), C.addressof(g2_buf)
+    zsq = 0xac45a4010001a4020000000100000000
+    rnd = random.Random(77)
+    edge = [0, 1, 2, 15, 16, 17, 2 ** 64, 2 ** 128 - 1, 2 ** 128, 2 ** 128 + 1, zsq - 1, zsq, zsq + 1, 5 * zsq, (2 ** 127) * 2 + zsq,
+            R - 1, R - 2, R - zsq, (R - 1) // 2, int("f" * 63, 16) % R, int("8" * 64, 16) % R]
+    cases = [(y, z) for y in edge for z in (3, R - 1)] + [(7, z) for z in edge] + [(rnd.randrange(R), rnd.randrange(R)) for _ in range(24)]
+    ok = C.c_bool(False)
+    for i, (y, z) in enumerate(cases):
+        a = rnd.randrange(1, R) if i % 5 else 0            # a = 0: the proof is the point at infinity
+        cm = oracle.g1_generator_mul((y + (1337 - z) * a) % R)
+        pi = oracle.g1_generator_mul(a)
+        zb, yb = z.to_bytes(32, "big"), y.to_bytes(32, "big")
+        assert capi.lib().verify_kzg_proof(C.byref(ok), cm, zb, yb, pi, C.byref(s)) == 0 and ok.value is True, (i, hex(y), hex(z))
+        yb2 = ((y + 1) % R).to_bytes(32, "big")
+        assert capi.lib().verify_kzg_proof(C.byref(ok), cm, zb, yb2, pi, C.byref(s)) == 0 and ok.value is False, (i, hex(y), hex(z))
+        if a:
+            zb2 = ((z + 1) % R).to_bytes(32, "big")
+            assert capi.lib().verify_kzg_proof(C.byref(ok), cm, zb2, yb, pi, C.byref(s)) == 0 and ok.value is False, (i, hex(y), hex(z))
