@@ -40,14 +40,24 @@ struct SideWorker;
 SideWorker *side_worker_acquire();                                   // nullptr: none idle and none could be created
 void side_worker_run(SideWorker *w, std::function<void()> fn);       // returns at once
 void side_worker_wait(SideWorker *w);                                // until fn has returned; the worker is idle again afterwards
+bool side_workers_on();                                              // LWKZG_SIDE_WORKERS=0 (experiment): a std::thread per job, as before r06
 struct SideTask {
     SideWorker *w = nullptr;
+    std::thread t;                                                   // the A/B arm only
     SideTask() = default;
     template <class F>
     explicit SideTask(F &&f) { start(static_cast<F &&>(f)); }
     template <class F>
     void start(F &&f) {
         join();
+        if (!side_workers_on()) {
+            try {
+                t = std::thread(f);
+            } catch (...) {
+                f();
+            }
+            return;
+        }
         w = side_worker_acquire();
         if (w) side_worker_run(w, std::function<void()>(f));
         else f();
@@ -55,6 +65,7 @@ struct SideTask {
     void join() {
         if (w) side_worker_wait(w);
         w = nullptr;
+        if (t.joinable()) t.join();
     }
     ~SideTask() { join(); }
     SideTask(const SideTask &) = delete;

@@ -158,7 +158,11 @@ extern "C" void lwk_fp_mul_adx(uint64_t *r, const uint64_t *a, const uint64_t *b
 extern "C" void lwk_fp2_mul_adx(uint64_t *r, const uint64_t *a, const uint64_t *b);  // 12 limbs each: (c0, c1) of Fp[u]/(u^2 + 1)
 extern "C" int lwk_cpu_has_bmi2_adx(void);
 inline bool hf_fp_on_adx() {
-    static const bool yes = lwk_cpu_has_bmi2_adx() != 0 && !knobs().host_fp_portable;
+    static const bool yes = lwk_cpu_has_bmi2_adx() != 0 && knobs().host_fp_portable != 1;
+    return yes;
+}
+inline bool hf_fp2_on_adx() {
+    static const bool yes = hf_fp_on_adx() && knobs().host_fp_portable != 2;
     return yes;
 }
 inline HFp operator*(const HFp &a, const HFp &b) {

@@ -53,7 +53,8 @@ struct Knobs {
     int split = 0;                   // LWKZG_SPLIT: windows of a scalar over this many workgroups (tiny batches)
     size_t slice0 = 0;               // LWKZG_SLICE0: first slice of a long host-pointer batch
     bool set_mode_in_place = true;   // LWKZG_SET_MODE_IN_PLACE=0
-    bool host_fp_portable = false;   // LWKZG_HOST_FP_PORTABLE: the C product of hostfp.h on a core that has MULX/ADX (the A/B arm)
+    int host_fp_portable = 0;        // LWKZG_HOST_FP_PORTABLE: 1 = the C products of hostfp.h on a core that has MULX/ADX, 2 = only the Fp2 product in C (the A/B arms)
+    int side_workers = 1;            // LWKZG_SIDE_WORKERS: 0 = a std::thread per SideTask, as before r06 (the A/B arm)
     bool pairing_generic_sqr = false, pairing_naive = false, pairing_no_precomp = false, pairing_one_thread = false;  // LWKZG_PAIRING_*
     // r06, batch verification
     int verify_msm = 1;              // LWKZG_VERIFY_MSM=0: r05's per-point multiples + Straus pieces (k_point_multiples, k_lincomb3)

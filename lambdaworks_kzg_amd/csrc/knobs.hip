@@ -90,7 +90,8 @@ Knobs read_env() {
     r.num(k.split, "LWKZG_SPLIT", EXP);
     r.num(k.slice0, "LWKZG_SLICE0", EXP);
     r.flag(k.set_mode_in_place, "LWKZG_SET_MODE_IN_PLACE", EXP);
-    r.present(k.host_fp_portable, "LWKZG_HOST_FP_PORTABLE", EXP);
+    r.num(k.host_fp_portable, "LWKZG_HOST_FP_PORTABLE", EXP);
+    r.num(k.side_workers, "LWKZG_SIDE_WORKERS", EXP);
     r.present(k.pairing_generic_sqr, "LWKZG_PAIRING_GENERIC_SQR", EXP);
     r.present(k.pairing_naive, "LWKZG_PAIRING_NAIVE", EXP);
     r.present(k.pairing_no_precomp, "LWKZG_PAIRING_NO_PRECOMP", EXP);
@@ -131,7 +132,7 @@ const char *knob_names_experimental() {
            "LWKZG_MID_PROOF_PIPE LWKZG_MID_PROOF_PIPE_MIN LWKZG_MID_PROOF_PARTS LWKZG_MID_PROOF_CHUNKS LWKZG_HEAVY_SERIAL LWKZG_PROOF_SCHEDULE LWKZG_SPLIT "
            "LWKZG_SLICE0 LWKZG_SET_MODE_IN_PLACE LWKZG_PAIRING_GENERIC_SQR LWKZG_PAIRING_NAIVE LWKZG_PAIRING_NO_PRECOMP "
            "LWKZG_PAIRING_ONE_THREAD LWKZG_VERIFY_MSM LWKZG_VERIFY_FUSED LWKZG_VERIFY_PAD_KB LWKZG_VERIFY_ORDER LWKZG_VERIFY_CU_MASK LWKZG_VMSM_LIST_CAP "
-           "LWKZG_HOST_STAGE LWKZG_ZERO_COPY LWKZG_HOST_FP_PORTABLE";
+           "LWKZG_HOST_STAGE LWKZG_ZERO_COPY LWKZG_HOST_FP_PORTABLE LWKZG_SIDE_WORKERS";
 }
 
 }  // namespace lwk

@@ -43,7 +43,7 @@ inline H2 operator-(const H2 &a, const H2 &b) { return {a.c0 - b.c0, a.c1 - b.c1
 static_assert(sizeof(H2) == 12 * sizeof(uint64_t), "fp_x86.S reads an Fp2 element as twelve consecutive limbs");
 inline H2 operator*(const H2 &a, const H2 &b) {
 #if defined(__x86_64__)
-    if (hf_fp_on_adx()) {  // three 768-bit products, two reductions (fp_x86.S)
+    if (hf_fp2_on_adx()) {  // three 768-bit products, two reductions (fp_x86.S)
         H2 r;
         lwk_fp2_mul_adx(r.c0.l, a.c0.l, b.c0.l);
         return r;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "plan.h"
+#include "knobs.h"
 
 namespace lwk {
 
@@ -338,6 +339,8 @@ struct SideTable {
 std::atomic<SideTable *> g_side{nullptr};
 std::mutex g_side_mu;
 }  // namespace
+
+bool side_workers_on() { return knobs().side_workers != 0; }
 
 SideWorker *side_worker_acquire() {
     SideTable *t = g_side.load(std::memory_order_acquire);

@@ -54,17 +54,68 @@ struct HostPoint {
     bool inf;
 };
 
+const HFp &host_beta() {
+    static const HFp b = []() {
+        uint32_t braw[12];
+        g1_beta_raw(braw);
+        return HFp::from_fe(fe_from_raw<FpParams>(braw));
+    }();
+    return b;
+}
+
+// a^((p + 1) / 4) on the 64-bit field, four bits of the exponent at a time (p = 3 mod 4: the square root when there is one)
+HFp hfp_pow_quarter(const HFp &a) {
+    static const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                   0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+    HFp tab[16];
+    tab[0] = HFp::one();
+    for (int i = 1; i < 16; i++) tab[i] = tab[i - 1] * a;
+    HFp acc = tab[(e[11] >> 28) & 15u];
+    for (int w = 94; w >= 0; w--) {
+        acc = sqr(sqr(sqr(sqr(acc))));
+        const uint32_t d = (e[w >> 3] >> (4 * (w & 7))) & 15u;
+        if (d) acc = acc * tab[d];
+    }
+    return acc;
+}
+
+// g1_decompress_nocheck (g1.cuh; /root/reference/src/compression.rs:62-103 without the subgroup check) with the square root on the host's
+// own field: the 32-bit-limb form of g1.cuh exists for the GPU and its 381-bit power cost 0.1 ms of a one-blob verification here.
+// Same return codes: 0 = affine point, 1 = infinity, 2 = invalid.
+int host_decompress_nocheck(G1Affine &out, const uint8_t in[48]) {
+    const uint8_t prefix = in[0] >> 5;
+    if (!(prefix & 4)) return 2;
+    if (prefix & 2) return 1;
+    uint8_t b[48];
+    memcpy(b, in, 48);
+    b[0] &= 0x1f;
+    uint32_t raw[12];
+    raw_from_be<12>(raw, b);
+    const Fp x32 = fe_from_raw<FpParams>(raw);   // x >= p is reduced, as in g1.cuh
+    const HFp x = HFp::from_fe(x32);
+    const HFp y2 = sqr(x) * x + HFp::from_fe(fp_from_u32(4));
+    const HFp y = hfp_pow_quarter(y2);
+    if (!(sqr(y) == y2)) return 2;
+    const Fp y32 = y.to_fe(), yn32 = neg(y).to_fe();
+    uint32_t ry[12], ryn[12];
+    fe_to_raw<FpParams>(ry, y32);
+    fe_to_raw<FpParams>(ryn, yn32);
+    const bool y_greater = raw_geq<12>(ry, ryn);
+    const bool want_greater = (prefix & 1) != 0;   // select_sqrt_value_from_third_bit: the greater root iff bit 5 is set
+    out.x = x32;
+    out.y = (want_greater == y_greater) ? y32 : yn32;
+    return 0;
+}
+
 // decompress_g1_point incl. subgroup check (compression.rs:62-103), host side
 bool host_g1_decompress(HostPoint &out, const uint8_t in[48]) {
     out.a.x = Fp::zero();
     out.a.y = Fp::zero();
-    int rc = g1_decompress_nocheck(out.a, in);
+    int rc = host_decompress_nocheck(out.a, in);
     if (rc == 2) return false;
     out.inf = rc == 1;
     if (out.inf) return true;
-    uint32_t braw[12];
-    g1_beta_raw(braw);
-    return g1_in_subgroup_endo<HXyzz>(HFp::from_fe(out.a.x), HFp::from_fe(out.a.y), HFp::from_fe(fe_from_raw<FpParams>(braw)));
+    return g1_in_subgroup_endo<HXyzz>(HFp::from_fe(out.a.x), HFp::from_fe(out.a.y), host_beta());
 }
 
 HXyzz to_xyzz(const HostPoint &p) {
@@ -94,15 +145,6 @@ HXyzz scalar_mul_plain(const HXyzz &p, const uint32_t k[8]) {
         if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_add(acc, p);
     }
     return acc;
-}
-
-const HFp &host_beta() {
-    static const HFp b = []() {
-        uint32_t braw[12];
-        g1_beta_raw(braw);
-        return HFp::from_fe(fe_from_raw<FpParams>(braw));
-    }();
-    return b;
 }
 
 // [k]P for P in G1 and k < r: the split of glv.cuh, k = lo + hi z^2 with [z^2]P = -phi(P) = (beta x, -y), both halves 128 bits, read

@@ -367,3 +367,71 @@ def test_host_scalar_products_of_a_verification(K, oracle, oracle_setup):
         if a:
             zb2 = ((z + 1) % R).to_bytes(32, "big")
             assert capi.lib().verify_kzg_proof(C.byref(ok), cm, zb2, yb, pi, C.byref(s)) == 0 and ok.value is False, (i, hex(y), hex(z))
+
+
+def test_host_decompression_of_a_verification(K, oracle, oracle_setup):
+    """decompress_g1_point (/root/reference/src/compression.rs:62-103) as verify_kzg_proof runs it on the host (verify.hip: host_decompress_nocheck --
+    the square root on 64-bit limbs -- then the endomorphism subgroup test): accept / reject equals the oracle's on valid points under
+    both sign bits, infinity encodings with stray bits, missing flags, x off the curve, x on the curve outside G1, x >= p; and an accepted
+    encoding decodes to the oracle's point (the sign of y: C = +-[k]G verifies against y = +-k with the proof at infinity)."""
+    import ctypes as C
+    import random
+    import struct
+    from conftest import R
+    from lambdaworks_kzg_amd import capi
+    P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+    def blst_fp(be48):
+        return struct.pack("<6Q", *[int.from_bytes(be48[8 * k:8 * k + 8], "big") for k in range(6)])
+
+    g2 = b""
+    for k in (1, 1337):
+        xy = oracle.g2_generator_mul(k)
+        g2 += b"".join(blst_fp(xy[48 * j:48 * j + 48]) for j in range(4)) + blst_fp((1).to_bytes(48, "big")) + blst_fp(bytes(48))
+    g1 = oracle_setup.g1_blst()[:144]
+    g1_buf, g2_buf = C.create_string_buffer(g1, len(g1)), C.create_string_buffer(g2, len(g2))
+    s = capi.KZGSettings()
+    s.fs, s.g1_values, s.g2_values = None, C.addressof(g1_buf), C.addressof(g2_buf)
+    inf = bytes([0xc0]) + bytes(47)
+    rnd = random.Random(99)
+    ok = C.c_bool(False)
+
+    def lib_verdict(c48, y):
+        rc = capi.lib().verify_kzg_proof(C.byref(ok), c48, bytes(32), (y % R).to_bytes(32, "big"), inf, C.byref(s))
+        return None if rc != 0 else bool(ok.value)
+
+    # valid points: both sign bits decode to the oracle's point and its negative
+    for i in range(40):
+        k = rnd.randrange(1, R)
+        c = oracle.g1_generator_mul(k)
+        flipped = bytes([c[0] ^ 0x20]) + c[1:]
+        assert lib_verdict(c, k) is True and lib_verdict(c, R - k) is False
+        assert lib_verdict(flipped, R - k) is True and lib_verdict(flipped, k) is False
+        assert oracle.g1_compress(*oracle.g1_decompress(flipped)) == oracle.g1_generator_mul(R - k)
+    # accept / reject on everything else
+    cands = [inf, bytes([0xc0]) + bytes([0xff] * 47), bytes([0xe0 | 0x1f]) + bytes(range(47)), bytes([0x40]) + bytes(47), bytes(48), bytes([0x20]) + bytes(47),
+             bytes([0x80]) + bytes(47), bytes([0xa0]) + bytes(47)]                       # x = 0: (0, +-2) is on the curve, of order 3
+    good = oracle.g1_generator_mul(12345)
+    cands += [bytes([good[0] & 0x7f]) + good[1:], bytes([good[0] | 0x40]) + good[1:]]    # compression flag cleared; infinity flag set on a point
+    for _ in range(300):
+        x = rnd.randrange(P)
+        cands.append(bytes([0x80 | (0x20 if rnd.random() < 0.5 else 0)]) + bytes(47))   # replaced below
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if rnd.random() < 0.5 else 0)
+        cands[-1] = bytes(b)
+    xg = int.from_bytes(bytes([good[0] & 0x1f]) + good[1:], "big")
+    for x in (xg + P, P, P + 1, (1 << 381) - 1):                                         # x >= p inside 381 bits
+        if x < (1 << 381):
+            b = bytearray(x.to_bytes(48, "big"))
+            b[0] |= 0x80 | (good[0] & 0x20)
+            cands.append(bytes(b))
+    n_acc = 0
+    for c in cands:
+        want = oracle.g1_decompress(c)
+        got = lib_verdict(c, 0)
+        if want is None:
+            assert got is None, c.hex()
+        else:
+            n_acc += 1
+            assert got is want[1], c.hex()      # e(C, G2) == 1 exactly when C is the point at infinity
+    assert n_acc >= 3
