@@ -296,6 +296,8 @@ struct Ctx {
     SmallProofHost sph;
     DevStage stage;     // under mu
     uint8_t *one_pin = nullptr;    // 4 KiB of pinned memory for a ONE-blob proof call (r06): XYZZ sum 224 | redo flag 4 | digest 32; under mu
+    uint8_t *vblobs = nullptr;     // ALL blobs of a long host-pointer verification on the device (grow-only, under mu): verify_prepare_staged
+    size_t vblobs_cap = 0;         // blobs
     uint8_t *host_res = nullptr;   // results / verdicts / digests of a long host-pointer batch on the device (grow-only, under mu):
     size_t host_res_cap = 0;       // r05 allocated and freed them per call, 6 ms of a 52 ms call of 4096 blobs (profiles/r06_experiments.md section 6)
     VerifyBuffers vs;   // verify-side scratch, sized for vs_cap blobs

@@ -473,6 +473,7 @@ static void ctx_destroy(Ctx *c) {
     }
     if (c->comb.pinned_blobs) hipHostFree(c->comb.pinned_blobs);
     dev_free(c->host_res);
+    dev_free(c->vblobs);
     if (c->one_pin) hipHostFree(c->one_pin);
     for (int k = 0; k < 2; k++) {
         dev_free(c->stage.slot[k]);
@@ -1437,6 +1438,115 @@ static C_KZG_RET stage_parsed(Ctx *c, size_t k, hipStream_t compute) {
     return C_KZG_OK;
 }
 
+// ---- long host-pointer verifications, r06 second form: the device-resident pipeline behind an upload --------------------------------------
+// verify_prepare_long below hashes every blob on the host threads, slice by slice beside the upload -- and on a host whose container gets
+// ~32 hardware threads that is the longest stage of its pipeline: 1.78 ms of SHA-256 per 512-blob slice against 1.2 ms of upload, 4096 blobs
+// in 16 ms of which the upload is 9.6 (profiles/r06_experiments.md section 9). Here ALL blobs go into one device buffer (537 MB for 4096 of the 288 GB), in
+// slices on a copy stream, and the hashing is SHARED: the head of the batch is hashed by the GPU's kernel slice by slice as it lands (a
+// 3.2 ms latency chain per launch whatever its size, hidden behind the uploads still to come), the tail by the host threads from the
+// caller's memory, starting at once (their share is what they hash in 0.8 of the upload time at their measured rate). y = p(z) is then
+// read straight from the uploaded blobs (k_eval_quotient_from_blobs / its evaluation-form twin: no coefficient slots to recycle).
+// Reference mode and c-kzg mode on the Lagrange form; other forms, no memory for the buffer, or LWKZG_HOST_STAGE=0 (experiment): the
+// sliced form below. `taken` says which. Caller holds c->mu.
+static uint8_t *vblobs_reserve(Ctx *c, size_t n) {
+    if (c->vblobs_cap >= n) return c->vblobs;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    dev_free(c->vblobs);
+    c->vblobs = nullptr;
+    c->vblobs_cap = 0;
+    size_t cap = 2 * kMaxChunk;
+    while (cap < n) cap <<= 1;
+    if (hipMalloc((void **)&c->vblobs, cap * (size_t)kBlobBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        c->vblobs = nullptr;
+        return nullptr;
+    }
+    c->vblobs_cap = cap;
+    return c->vblobs;
+}
+
+static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8_t *comm48, const uint8_t *proofs48, size_t n, int mode,
+                                       uint8_t *z32, uint8_t *y32, uint8_t *canon_c, uint8_t *canon_p, VerifyBuffers &vb, bool &taken) {
+    taken = false;
+    const int le = mode == LWKZG_MODE_CKZG;
+    const bool evf = proof_in_evaluation_form(c, mode);
+    if (!knobs().host_stage || !(mode == LWKZG_MODE_REFERENCE || evf) || n > ((size_t)1 << 17)) return C_KZG_OK;
+    uint8_t *d_all = vblobs_reserve(c, n);
+    if (!d_all) return C_KZG_OK;
+    C_KZG_RET rc = ws_long_reserve(c, n);
+    if (rc != C_KZG_OK) return rc;
+    taken = true;
+    const int bad = le ? kStatusBadArgs : kStatusError;
+    // Four streams are at work at once here, and the runtime has four hardware queues that it hands out in creation order: the main
+    // stream, the validation stream, aux[0] and aux[1] are the first four a context creates, so none of them queues behind another.
+    // (aux[3] for the uploads shares the validation stream's queue: every upload of the first 3.5 ms waited, 15.9 instead of 13.1 ms.)
+    hipStream_t st = c->stream, sv = c->vstream, sc = c->aux[knobs().stage_streams[0]], sh = c->aux[knobs().stage_streams[1]];
+    Fr *z = c->ws.z_long;
+    // the host's share of the hashing: whole slices at the END of the batch
+    const size_t slice = kMaxChunk / 2;
+    const double upload_rate = 56e9;   // pageable memory -> HBM on this platform (profiles/r06_h2d_bench.txt)
+    double f = 0.8 * host_hash_rate() / upload_rate;
+    if (f > 1.0) f = 1.0;
+    size_t n_gpu = (size_t)((1.0 - f) * (double)n) / slice * slice;   // whole slices for the GPU; the host takes the rest, the ragged end included
+    if (n_gpu > n) n_gpu = n;
+    const size_t n_host = n - n_gpu;
+    std::vector<uint8_t> dig(32 * (n_host ? n_host : 1));
+    SideTask hasher;   // joined by its destructor on every exit (digests assume canonical commitment bytes; the comparison below confirms or refutes that)
+    if (n_host) hasher.start([&, n_gpu, n_host]() { challenge_digests_host(dig.data(), blobs + n_gpu * (size_t)kBlobBytes, comm48 + 48 * n_gpu, n_host); });
+    // up-front validation of every commitment (main stream) and every proof (validation stream), the rows of the linear combinations behind them
+    LWK_HIP(hipMemcpyAsync(vb.comm_in, comm48, n * 48, hipMemcpyHostToDevice, st));
+    LWK_HIP(hipMemsetAsync(vb.status_all, 0, n * 4, st));
+    LWK_HIP(hipEventRecord(c->ev_fork, st));
+    LWK_HIP(hipStreamWaitEvent(sv, c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(sc, c->ev_fork, 0));
+    LWK_HIP(hipStreamWaitEvent(sh, c->ev_fork, 0));
+    LWK_HIP(hipMemcpyAsync(vb.proof_in, proofs48, n * 48, hipMemcpyHostToDevice, sv));
+    launch_validate_commitments(vb.proof_in, vb.canon_dev + 48 * n, vb.status_all, bad, n, sv, vb.pts_p, vb.kind_p, vb.verdict_p);
+    launch_validate_commitments(vb.comm_in, vb.canon_dev, vb.status_all, bad, n, st, vb.pts_c, vb.kind_c, vb.verdict_c);
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 2], st));
+    LWK_HIP(hipStreamWaitEvent(sv, c->ev_join[kMaxSplit - 2], 0));
+    launch_verify_rows(vb, n, sv, false);
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
+    // the uploads (this thread is inside a blocking pageable copy most of the time) and, behind each slice of the head, its hash
+    for (size_t off = 0; off < n; off += slice) {
+        const size_t m = n - off < slice ? n - off : slice;
+        LWK_HIP(hipMemcpyAsync(d_all + off * (size_t)kBlobBytes, blobs + off * (size_t)kBlobBytes, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, sc));
+        if (off < n_gpu) {
+            LWK_HIP(hipEventRecord(c->ev_join[3], sc));
+            LWK_HIP(hipStreamWaitEvent(sh, c->ev_join[3], 0));
+            launch_challenge(d_all + off * (size_t)kBlobBytes, vb.comm_in + 48 * off, z + off, le, m, sh);
+        }
+    }
+    LWK_HIP(hipEventRecord(c->ev_join[3], sc));
+    LWK_HIP(hipStreamWaitEvent(sh, c->ev_join[3], 0));          // every blob is on the device
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[kMaxSplit - 1], 0));   // the validation's canonical bytes and verdicts
+    LWK_HIP(hipMemcpyAsync(canon_c, vb.canon_dev, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(canon_p, vb.canon_dev + 48 * n, n * 48, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 2], st));
+    LWK_HIP(hipStreamSynchronize(st));
+    LWK_HIP(hipStreamWaitEvent(sh, c->ev_join[kMaxSplit - 2], 0));
+    hasher.join();
+    // the head: redo the challenges of blobs whose commitment bytes were not canonical (exits at once otherwise)
+    if (n_gpu) launch_challenge(d_all, vb.canon_dev, z, le, n_gpu, sh, vb.comm_in);
+    // the tail: the host's digests, unless a commitment among them was not in its canonical encoding
+    if (n_host) {
+        if (memcmp(canon_c + 48 * n_gpu, comm48 + 48 * n_gpu, 48 * n_host) == 0) {
+            LWK_HIP(hipMemcpyAsync(vb.d_rz + 32 * n_gpu, dig.data(), 32 * n_host, hipMemcpyHostToDevice, sh));
+            launch_z_from_bytes(vb.d_rz + 32 * n_gpu, z + n_gpu, nullptr, le, n_host, sh);
+        } else {
+            launch_challenge(d_all + n_gpu * (size_t)kBlobBytes, vb.canon_dev + 48 * n_gpu, z + n_gpu, le, n_host, sh);
+        }
+    }
+    if (evf) launch_eval_y_from_blobs_evalform(d_all, z, c->tw28_fwd + kBlobElems / 2, vb.d_r, vb.status_all, n, sh);
+    else launch_eval_y_from_blobs_be(d_all, z, vb.d_r, n, sh);
+    launch_fr_mont_to_bytes(z, vb.d_rz, le, n, sh);
+    LWK_HIP(hipEventRecord(c->ev_join[3], sh));
+    LWK_HIP(hipStreamWaitEvent(st, c->ev_join[3], 0));
+    LWK_HIP(hipMemcpyAsync(z32, vb.d_rz, n * 32, hipMemcpyDeviceToHost, st));
+    LWK_HIP(hipMemcpyAsync(y32, vb.d_r, n * 32, hipMemcpyDeviceToHost, st));
+    return first_status(c, vb.status_all, n, st);
+}
+
 // Batches longer than one chunk (1024 blobs). All 2n points are validated ONCE up front (two launches side by side; the kernel is a 2 ms
 // latency chain whatever n is), and the blobs then go through in slices that alternate between the two halves of the
 // workspace and two streams: while the GPU parses / evaluates one slice, this thread is already inside the (blocking,
@@ -1589,6 +1699,8 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             hipStreamSynchronize(c->vstream);
             hipStreamSynchronize(c->aux[0]);
             hipStreamSynchronize(c->aux[1]);
+            hipStreamSynchronize(c->aux[knobs().stage_streams[0]]);   // (the copy stream of verify_prepare_staged)
+            hipStreamSynchronize(c->aux[knobs().stage_streams[1]]);
         }
     } drain{c};
     if (vb.owned) {
@@ -1601,8 +1713,15 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
         if (rcv != C_KZG_OK) return rcv;
         verify_buffers_lend(vb, c->vs);
     }
-    if (n > kMaxChunk && proofs48 && !trusted_canon_c)  // up to one chunk the single pass below is ~1 ms shorter
+    if (n > kMaxChunk && proofs48 && !trusted_canon_c) {  // up to one chunk the single pass below is ~1 ms shorter
+        bool taken = false;
+        C_KZG_RET rcs = verify_prepare_staged(c, blobs, comm48, proofs48, n, mode, z32, y32, canon_c, canon_p, vb, taken);
+        if (taken || rcs != C_KZG_OK) {
+            if (rcs == C_KZG_OK) drain.armed = false;   // every side stream was joined into the main stream
+            return rcs;
+        }
         return verify_prepare_long(c, blobs, comm48, proofs48, n, mode, z32, y32, canon_c, canon_p, vb);
+    }
     std::vector<uint8_t> dig(32 * (n < kMaxChunk ? n : kMaxChunk));
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;

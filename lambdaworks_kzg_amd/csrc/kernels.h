@@ -192,6 +192,7 @@ void launch_challenge_finish(const uint8_t *blobs, const uint8_t *canon48, const
 void sha256_host(uint8_t out[32], const uint8_t *msg, size_t len);
 // sha256_host.hip: digests[i] = SHA-256("FSBLOBVERIFY_V1_" | le64(4096) | le64(0) | blobs[i] | comms[i]) on host threads
 void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n);
+double host_hash_rate();   // bytes per second the host threads hashed in their recent long jobs (sha256_host.hip)
 void challenge_midstates_host(uint32_t *mid, const uint8_t *blobs, size_t n);   // 8 words per blob: the hash state k_challenge_finish continues from
 void sha256_blocks_portable(uint32_t h[8], const uint8_t *blocks, size_t n_blocks);
 

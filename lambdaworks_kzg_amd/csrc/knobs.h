@@ -23,6 +23,7 @@ struct Knobs {
     bool twin = true;                // LWKZG_TWIN: a second context for a second caller stream
     size_t small_proof_host = 64;    // LWKZG_SMALL_PROOF_HOST: device-resident proof calls up to this many blobs hash + validate on host threads
     size_t mid_proof_host = 384;     // LWKZG_MID_PROOF_HOST: ... up to this many hash on host threads, pipelined (0 = GPU hash always)
+    int host_threads = 0;            // LWKZG_HOST_THREADS: upper bound on the host threads the library uses (0 = 32; the hardware and a cgroup quota bound it as well)
     int host_warm_ms = 2000;         // LWKZG_HOST_WARM_MS: host-assisted paths only while the host threads ran a job this recently
     size_t host_finish = 8;          // LWKZG_HOST_FINISH: host-pointer calls of up to this many results invert + compress on the calling thread
     bool timing = false;             // LWKZG_TIMING: phase wall clock of verification / proof slices to stderr
@@ -54,6 +55,8 @@ struct Knobs {
     size_t slice0 = 0;               // LWKZG_SLICE0: first slice of a long host-pointer batch
     bool set_mode_in_place = true;   // LWKZG_SET_MODE_IN_PLACE=0
     int host_fp_portable = 0;        // LWKZG_HOST_FP_PORTABLE: 1 = the C products of hostfp.h on a core that has MULX/ADX, 2 = only the Fp2 product in C (the A/B arms)
+    int host_hash_grain = 4;         // LWKZG_HOST_HASH_GRAIN: blobs per thread woken for a host hashing job (1 = wake every parked thread, as before r06)
+    int stage_streams[2] = {1, 0};   // LWKZG_STAGE_STREAMS=c,h: which side streams (aux index) carry the uploads / the head's hashes of a staged verification
     int side_workers = 1;            // LWKZG_SIDE_WORKERS: 0 = a std::thread per SideTask, as before r06 (the A/B arm)
     bool pairing_generic_sqr = false, pairing_naive = false, pairing_no_precomp = false, pairing_one_thread = false;  // LWKZG_PAIRING_*
     // r06, batch verification

@@ -60,6 +60,7 @@ Knobs read_env() {
     r.flag(k.twin, "LWKZG_TWIN", OP);
     r.num(k.small_proof_host, "LWKZG_SMALL_PROOF_HOST", OP);
     r.num(k.mid_proof_host, "LWKZG_MID_PROOF_HOST", OP);
+    r.num(k.host_threads, "LWKZG_HOST_THREADS", OP);
     r.num(k.host_warm_ms, "LWKZG_HOST_WARM_MS", OP);
     r.num(k.host_finish, "LWKZG_HOST_FINISH", OP);
     r.present(k.timing, "LWKZG_TIMING", OP);
@@ -92,6 +93,7 @@ Knobs read_env() {
     r.flag(k.set_mode_in_place, "LWKZG_SET_MODE_IN_PLACE", EXP);
     r.num(k.host_fp_portable, "LWKZG_HOST_FP_PORTABLE", EXP);
     r.num(k.side_workers, "LWKZG_SIDE_WORKERS", EXP);
+    r.num(k.host_hash_grain, "LWKZG_HOST_HASH_GRAIN", EXP);
     r.present(k.pairing_generic_sqr, "LWKZG_PAIRING_GENERIC_SQR", EXP);
     r.present(k.pairing_naive, "LWKZG_PAIRING_NAIVE", EXP);
     r.present(k.pairing_no_precomp, "LWKZG_PAIRING_NO_PRECOMP", EXP);
@@ -111,6 +113,13 @@ Knobs read_env() {
     r.num(k.vmsm_list_cap, "LWKZG_VMSM_LIST_CAP", EXP);
     r.flag(k.zero_copy, "LWKZG_ZERO_COPY", EXP);
     r.flag(k.host_stage, "LWKZG_HOST_STAGE", EXP);
+    if (const char *e = r.get("LWKZG_STAGE_STREAMS", EXP)) {
+        int a = 1, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 8 && b >= 0 && b < 8 && a != b) {
+            k.stage_streams[0] = a;
+            k.stage_streams[1] = b;
+        }
+    }
     return k;
 }
 
@@ -123,7 +132,7 @@ const Knobs &knobs() {
 
 const char *knob_names_operational() {
     return "LWKZG_MODE LWKZG_DIRECT_BITS LWKZG_DIRECT_ROW LWKZG_COALESCE LWKZG_TWIN LWKZG_SMALL_PROOF_HOST LWKZG_MID_PROOF_HOST "
-           "LWKZG_HOST_WARM_MS LWKZG_HOST_FINISH LWKZG_TIMING LWKZG_VERBOSE LWKZG_EXPERIMENTAL";
+           "LWKZG_HOST_THREADS LWKZG_HOST_WARM_MS LWKZG_HOST_FINISH LWKZG_TIMING LWKZG_VERBOSE LWKZG_EXPERIMENTAL";
 }
 
 const char *knob_names_experimental() {
@@ -132,7 +141,7 @@ const char *knob_names_experimental() {
            "LWKZG_MID_PROOF_PIPE LWKZG_MID_PROOF_PIPE_MIN LWKZG_MID_PROOF_PARTS LWKZG_MID_PROOF_CHUNKS LWKZG_HEAVY_SERIAL LWKZG_PROOF_SCHEDULE LWKZG_SPLIT "
            "LWKZG_SLICE0 LWKZG_SET_MODE_IN_PLACE LWKZG_PAIRING_GENERIC_SQR LWKZG_PAIRING_NAIVE LWKZG_PAIRING_NO_PRECOMP "
            "LWKZG_PAIRING_ONE_THREAD LWKZG_VERIFY_MSM LWKZG_VERIFY_FUSED LWKZG_VERIFY_PAD_KB LWKZG_VERIFY_ORDER LWKZG_VERIFY_CU_MASK LWKZG_VMSM_LIST_CAP "
-           "LWKZG_HOST_STAGE LWKZG_ZERO_COPY LWKZG_HOST_FP_PORTABLE LWKZG_SIDE_WORKERS";
+           "LWKZG_HOST_STAGE LWKZG_ZERO_COPY LWKZG_HOST_FP_PORTABLE LWKZG_SIDE_WORKERS LWKZG_HOST_HASH_GRAIN LWKZG_STAGE_STREAMS";
 }
 
 }  // namespace lwk
@@ -143,13 +152,13 @@ extern "C" __attribute__((visibility("default"))) size_t lwkzg_knob_report(char 
     const int n = snprintf(
         tmp, sizeof tmp,
         "{\"experimental\": %s, \"mode\": %d, \"direct_bits\": %s%d, \"direct_row\": %d, \"coalesce\": %d, \"twin\": %d, "
-        "\"small_proof_host\": %zu, \"mid_proof_host\": %zu, \"host_warm_ms\": %d, \"host_finish\": %zu, "
+        "\"small_proof_host\": %zu, \"mid_proof_host\": %zu, \"host_threads\": %d, \"host_warm_ms\": %d, \"host_finish\": %zu, "
         "\"timing\": %d, \"verbose\": %d, \"direct_asm\": %d, \"fold_asm\": %d, \"bucket_asm\": %d, \"coop\": %d, \"coop_max\": %d, "
         "\"hash_pairs\": %d, \"hash_prio\": %d, \"validate_coop\": %d, \"ckzg_eval_proofs\": %d, \"mid_proof_pipe\": %d, "
         "\"verify_msm\": %d, \"verify_fused\": %d, \"verify_pad_kb\": [%d, %d, %d], \"verify_order\": %d, \"vmsm_list_cap\": %d, "
         "\"host_stage\": %d, \"operational\": \"%s\", \"experimental_names\": \"%s\"}",
         k.experimental ? "true" : "false", k.mode, k.has_direct_bits ? "" : "null, \"direct_bits_unset_default\": ", k.direct_bits, k.direct_row,
-        (int)k.coalesce, (int)k.twin, k.small_proof_host, k.mid_proof_host, k.host_warm_ms, k.host_finish, (int)k.timing,
+        (int)k.coalesce, (int)k.twin, k.small_proof_host, k.mid_proof_host, k.host_threads, k.host_warm_ms, k.host_finish, (int)k.timing,
         (int)k.verbose, (int)k.direct_asm, (int)k.fold_asm, (int)k.bucket_asm, k.coop, k.coop_max, (int)k.hash_pairs, k.hash_prio,
         (int)k.validate_coop, (int)k.ckzg_eval_proofs, (int)k.mid_proof_pipe, k.verify_msm, k.verify_fused, k.verify_pad_kb[0],
         k.verify_pad_kb[1], k.verify_pad_kb[2], k.verify_order, k.vmsm_list_cap, (int)k.host_stage, lwk::knob_names_operational(),

@@ -218,7 +218,10 @@ static unsigned probe_host_threads() {
         }
         fclose(f);
     }
-    return n > 32 ? 32 : n;
+    // and a bound of the library's own: 32 unless LWKZG_HOST_THREADS says otherwise (64 and 128 measured the same or worse on a
+    // 256-thread box whose container does not get them all: profiles/r06_experiments.md section 9)
+    const unsigned cap = knobs().host_threads > 0 ? (unsigned)knobs().host_threads : 32u;
+    return n > cap ? cap : n;
 }
 
 unsigned host_threads() {
@@ -245,6 +248,7 @@ class HostPool {
         for (unsigned k = 0; k < workers; k++) {
             try {
                 std::thread([this]() { worker(); }).detach();
+                workers_++;
             } catch (...) {
                 break;  // fewer workers (none: the caller does everything itself); nothing unwinds across the C ABI
             }
@@ -252,8 +256,14 @@ class HostPool {
     }
     pid_t pid() const { return pid_; }
 
-    void run(size_t n, const std::function<void(size_t)> &fn) {
+    // `grain`: indices a woken worker should find for itself. Waking is not free -- 255 parked threads woken at once re-acquire one mutex
+    // in turn, and a 512-blob slice of a long verification (70 us of SHA-256 per blob) spent 1.7 ms per job that way, more than its
+    // 1.2 ms upload (profiles/r06_experiments.md section 8) -- so a job wakes ceil(n / grain) workers, one notification each, and the
+    // others sleep through it (they skip finished generations when they next wake).
+    void run(size_t n, const std::function<void(size_t)> &fn, size_t grain) {
         std::lock_guard<std::mutex> one_at_a_time(run_mu_);
+        size_t wake = grain <= 1 ? n : (n + grain - 1) / grain;
+        if (wake > workers_) wake = workers_;
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = &fn;
@@ -261,7 +271,9 @@ class HostPool {
             next_.store(0, std::memory_order_relaxed);
             gen_++;
         }
-        cv_work_.notify_all();
+        if (wake >= workers_) cv_work_.notify_all();
+        else
+            for (size_t k = 0; k < wake; k++) cv_work_.notify_one();
         claim_loop(fn, n);
         std::unique_lock<std::mutex> lk(mu_);
         done_gen_ = gen_;  // workers that wake up from here on skip this round
@@ -295,6 +307,7 @@ class HostPool {
     }
 
     const pid_t pid_;
+    size_t workers_ = 0;
     std::mutex run_mu_, mu_;
     std::condition_variable cv_work_, cv_done_;
     const std::function<void(size_t)> *fn_ = nullptr;
@@ -393,13 +406,20 @@ void side_worker_wait(SideWorker *w) {
 }
 
 namespace {
+std::atomic<double> g_host_hash_rate{0.0};
 std::atomic<int64_t> g_host_last_active_ns{0};
 int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
 // fn(0) .. fn(n - 1), each exactly once, on the host threads (the caller works too); returns when all are done.
 // Calls from different threads take turns. fn must not call host_parallel_for itself.
-void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+void host_parallel_for_grain(size_t n, const std::function<void(size_t)> &fn, size_t grain);
+void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) { host_parallel_for_grain(n, fn, 1); }
+// blobs a thread woken for a hashing job should find (70 us each): LWKZG_HOST_HASH_GRAIN (experiment; 1 = every parked thread, as before r06)
+static size_t host_hash_grain() { return knobs().host_hash_grain < 1 ? 1 : (size_t)knobs().host_hash_grain; }
+
+// the same with `grain` indices per woken thread (HostPool::run): for jobs of many short pieces
+void host_parallel_for_grain(size_t n, const std::function<void(size_t)> &fn, size_t grain) {
     const unsigned nt = host_threads();
     if (n <= 1 || nt <= 1) {
         for (size_t i = 0; i < n; i++) fn(i);
@@ -413,7 +433,7 @@ void host_parallel_for(size_t n, const std::function<void(size_t)> &fn) {
         if (!pool || pool->pid() != getpid()) pool = new HostPool(nt - 1);
         p = pool;
     }
-    p->run(n, fn);
+    p->run(n, fn, grain);
     g_host_last_active_ns.store(now_ns(), std::memory_order_release);
 }
 
@@ -441,7 +461,7 @@ void host_pool_warm() {
 void challenge_midstates_host(uint32_t *mid, const uint8_t *blobs, size_t n) {
     static const uint8_t header[32] = {'F', 'S', 'B', 'L', 'O', 'B', 'V', 'E', 'R', 'I', 'F', 'Y', '_', 'V', '1', '_',
                                        0x00, 0x10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    host_parallel_for(n, [=](size_t i) {
+    host_parallel_for_grain(n, [=](size_t i) {
         const uint8_t *blob = blobs + (size_t)kBlobBytes * i;
         uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
         uint8_t blk[64];
@@ -455,12 +475,28 @@ void challenge_midstates_host(uint32_t *mid, const uint8_t *blobs, size_t n) {
             sha256_blocks_portable(h, blob + 32, (kBlobBytes - 64) / 64);
         }
         for (int k = 0; k < 8; k++) mid[8 * i + k] = h[k];
-    });
+    }, host_hash_grain());
 }
 
 // digests[i] = SHA-256(header | blobs[i] | comms[i]) for i < n, spread over the host threads
 void challenge_digests_host(uint8_t *digests32, const uint8_t *blobs, const uint8_t *comms48, size_t n) {
-    host_parallel_for(n, [=](size_t i) { challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i); });
+    const int64_t t0 = now_ns();
+    host_parallel_for_grain(n, [=](size_t i) { challenge_digest(digests32 + 32 * i, blobs + (size_t)kBlobBytes * i, comms48 + 48 * i); }, host_hash_grain());
+    const int64_t dt = now_ns() - t0;
+    if (n >= 256 && dt > 0) {   // what this host's threads really hash per second (a cgroup quota, SMT siblings and the caller's memory all show here)
+        const double rate = (double)n * kBlobBytes / ((double)dt * 1e-9);
+        const double old = g_host_hash_rate.load(std::memory_order_relaxed);
+        g_host_hash_rate.store(old > 0 ? 0.5 * old + 0.5 * rate : rate, std::memory_order_relaxed);
+    }
+}
+
+// bytes per second the host threads hashed in their recent jobs of 256 blobs and more; before the first such job an estimate from the thread
+// count (1.1 GB/s per thread beside its SMT sibling, on at most 32 of them: what an EPYC 9575F box measured, profiles/r06_experiments.md section 9)
+double host_hash_rate() {
+    const double r = g_host_hash_rate.load(std::memory_order_relaxed);
+    if (r > 0) return r;
+    const unsigned t = host_threads();
+    return 1.1e9 * (t > 32 ? 32 : t);
 }
 
 }  // namespace lwk

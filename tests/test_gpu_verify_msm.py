@@ -1,7 +1,8 @@
 """GPU: the verification's three linear combinations as the latency-shaped bucket MSM of csrc/vmsm.hip (r06; the reference's
 g1_lincomb x 3, /root/reference/src/lib.rs:679-685) against its two other arms, in fresh processes: the scan fallback of a bucket whose
 list overflows (LWKZG_VMSM_LIST_CAP=1: every lane takes it) and r05's per-point multiples + Straus pieces (LWKZG_VERIFY_MSM=0). The
-partial sums are affine points: all arms must agree BYTE FOR BYTE, per shard, in both semantics, host-pointer and device-resident."""
+partial sums are affine points: all arms must agree BYTE FOR BYTE, per shard, in both semantics, host-pointer and device-resident. The
+2600-blob case also holds the two forms of a host-pointer shard longer than one chunk against each other (LWKZG_HOST_STAGE)."""
 import json
 import os
 import subprocess
@@ -31,6 +32,8 @@ def test_all_arms_of_the_linear_combinations_agree(mode):
     r05 = _run(mode, LWKZG_VERIFY_MSM="0")
     assert scan == shipped
     assert r05 == shipped
+    sliced = _run(mode, LWKZG_HOST_STAGE="0")    # long host-pointer shards: r05's slices (every blob hashed on the host threads) instead of the staged form
+    assert sliced == shipped
 
 
 def test_experiment_knobs_need_the_switch():

@@ -20,7 +20,7 @@ def main():
     be = mode == K.MODE_REFERENCE
     ts = K.TrustedSetup.from_file(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"))
     out = {}
-    for n in (1, 9, 70, 300, 1500):
+    for n in (1, 9, 70, 300, 1500, 2600):
         blobs = [B.synthetic_blob(61000 + 17 * n + i, big_endian=be) for i in range(n)]
         if n > 2:
             blobs[n // 3] = bytes(B.BYTES_PER_BLOB)            # commitment and proof at infinity
@@ -30,8 +30,27 @@ def main():
         data = b"".join(blobs)
         cj = b"".join(K.blob_to_kzg_commitment_batch(data, ts))
         pj = b"".join(K.compute_blob_kzg_proof_batch(data, cj, ts))
-        # host-pointer shards: the whole batch as one, and cut in two uneven shards (the second one's powers start at r^first)
         cut = max(1, (2 * n) // 3)
+        if n == 2600:
+            # a first shard of 2100 blobs through host pointers is LONGER THAN ONE CHUNK: the staged form (engine.hip: verify_prepare_staged --
+            # the head of the batch hashed by the GPU as it lands, the tail by the host threads) against the sliced one (LWKZG_HOST_STAGE=0).
+            # Two all-zero blobs, one in each part, come with their commitment at infinity in a NON-canonical encoding (stray bits behind the
+            # flags, which the reference does not inspect): their challenges must be taken over the canonical bytes on either side
+            cut = 2100
+            stray = bytes([0xc5]) + bytes([7] * 47)
+            cjb = bytearray(cj)
+            for i in (100, 2000):
+                assert data[i * B.BYTES_PER_BLOB:(i + 1) * B.BYTES_PER_BLOB] != bytes(B.BYTES_PER_BLOB)
+            blobs[100] = blobs[2000] = bytes(B.BYTES_PER_BLOB)
+            data = b"".join(blobs)
+            cj = b"".join(K.blob_to_kzg_commitment_batch(data, ts))
+            pj = b"".join(K.compute_blob_kzg_proof_batch(data, cj, ts))
+            cjb = bytearray(cj)
+            for i in (100, 2000):
+                assert cj[48 * i:48 * i + 48] == bytes([0xc0]) + bytes(47)
+                cjb[48 * i:48 * i + 48] = stray
+            cj = bytes(cjb)
+        # host-pointer shards: the whole batch as one, and cut in two uneven shards (the second one's powers start at r^first)
         recs = []
         shards = []
         for lo, hi in ((0, cut), (cut, n)):

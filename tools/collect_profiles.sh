@@ -79,6 +79,25 @@ PK="python3 bench.py --op blob_proof --mode ckzg --batch 1024 --steps 4 --warmup
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_proof_ckzg -o kt -- $PK > $O/kt_proof_ckzg_line.json 2> $O/kt_proof_ckzg_err.txt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_ckzg_sq1 -o sq -- $PK > $O/pmc_ckzg_sq1_line.json 2> $O/pmc_ckzg_sq1_err.txt
 rocprofv3 --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_ckzg_sq2 -o sq -- $PK > $O/pmc_ckzg_sq2_line.json 2> $O/pmc_ckzg_sq2_err.txt
+# r06: BASELINE configs[3] in its device-resident form in a loop of its own (and its kernel timeline), the host-pointer form beside it, 16384 blobs,
+# the arms of the verification (r05's rows, r05's placement), the host field tower on this box's cores, the scaling projection
+python tools/verify_device_loop.py --n 4096 --calls 10 --tag "configs[3] device form" 2>/dev/null | tail -1 > $O/verify_loops.jsonl
+python tools/verify_device_loop.py --n 4096 --calls 10 --host --tag "configs[3] host form" 2>/dev/null | tail -1 >> $O/verify_loops.jsonl
+python tools/verify_device_loop.py --n 16384 --calls 4 --tag "16384 blobs, device form" 2>/dev/null | tail -1 >> $O/verify_loops.jsonl
+LWKZG_VERIFY_MSM=0 LWKZG_VERIFY_FUSED=0 LWKZG_VERIFY_PAD_KB=0,0,0 python tools/verify_device_loop.py --n 4096 --calls 6 --tag "r05 arm: per-point multiples + Straus, two side streams, no footprints" 2>/dev/null | tail -1 >> $O/verify_loops.jsonl
+LWKZG_VERIFY_PAD_KB=0,0,0 python tools/verify_device_loop.py --n 4096 --calls 6 --tag "bucket MSM, no footprints" 2>/dev/null | tail -1 >> $O/verify_loops.jsonl
+LWKZG_HOST_FP_PORTABLE=1 python tools/verify_device_loop.py --n 4096 --calls 6 --tag "host field products in C" 2>/dev/null | tail -1 >> $O/verify_loops.jsonl
+rocprofv3 --kernel-trace --output-format csv -d $O/kt_verify_dev -o kt -- python3 tools/verify_device_loop.py --n 4096 --calls 4 --no-profile > $O/kt_verify_dev_out.txt 2> $O/kt_verify_dev_err.txt
+python tools/timeline.py $(ls $O/kt_verify_dev/*/kt_kernel_trace.csv $O/kt_verify_dev/kt_kernel_trace.csv 2>/dev/null | head -1) 40 > $O/verify_b4096_device_timeline.txt
+rm -f $O/kt_verify_dev/*/kt_kernel_trace.csv $O/kt_verify_dev/kt_kernel_trace.csv
+bash tools/host_field_bench.sh > $O/host_field_bench.txt 2>&1
+LWKZG_HOST_FP_PORTABLE=2 /tmp/host_field_bench > $O/host_field_bench_fp2_in_c.txt 2>&1
+LWKZG_HOST_FP_PORTABLE=1 /tmp/host_field_bench > $O/host_field_bench_all_c.txt 2>&1
+lscpu | grep -E "Model name|^CPU\(s\)|MHz" > $O/lscpu.txt
+LWKZG_TIMING=1 LWKZG_DIRECT=0 python tools/single_blob_timing.py 2>&1 | grep -E "verification:|Miller" | tail -8 > $O/single_blob_phases.txt
+LWKZG_SIDE_WORKERS=0 LWKZG_DIRECT=0 python tools/single_blob_timing.py > $O/single_blob_timing_thread_per_job_arm.txt 2>&1
+LWKZG_ZERO_COPY=0 LWKZG_DIRECT=0 python tools/single_blob_timing.py > $O/single_blob_timing_r05_arm.txt 2>&1
+python tools/scaling_projection.py --out $O/scaling_projection.json 2> $O/scaling_projection_err.txt | grep '^|' > $O/scaling_projection_table.md
 python tools/experiments/r05_host_cold.py > $O/host_cold.txt 2>&1
 tools/ubench_latency_bin > $O/ubench_latency.txt 2>&1
 python tools/host_api_timing.py > $O/host_api_timing.txt 2>&1

@@ -2,7 +2,7 @@
 # Copies what tools/collect_profiles.sh left under gpurun_out/final into profiles/ (tracked), keeping only our kernels' rows.
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/final; P=profiles; TAG=${1:-r05}
+O=gpurun_out/final; P=profiles; TAG=${1:-r06}
 for f in bench_line bench_line_force_dist bench_line_compiler_scheduled_arm bench_line_full_range_scalars bench_line_ckzg_mode bench_line_blob_proof_b256 bench_line_blob_proof_b1024 bench_line_blob_proof_b4096 \
          bench_line_blob_proof_b256_two_streams bench_line_blob_proof_b1024_two_streams bench_line_commit_prove_b256 bench_line_commit_prove_b1024 bench_line_verify_batch_b4096 bench_line_tiled_msm \
          bench_line_bucket bench_line_bucket_compiler_arm bench_line_default_engine bench_line_gpus2_gloo_one_device; do
@@ -23,6 +23,13 @@ for f in setup_load_timing setup_load_timing_16bit; do [ -s $O/$f.txt ] && grep 
 [ -s $O/kt_line.json ] && tail -1 $O/kt_line.json > $P/${TAG}_bench_kernel_stats_run_line.json   # the line the profiled run itself printed
 for f in config_sweep_direct16 config_sweep_default config_sweep_bucket; do [ -s $O/$f.json ] && cp $O/$f.json $P/${TAG}_$f.json; done
 grep -v "amdgpu.ids" $O/host_api_timing.txt > $P/${TAG}_host_api_timing.txt || true
+# r06: the verification in loops of its own, its kernel timeline, the host field tower, one-blob phases and arms, the scaling projection
+for f in verify_loops; do [ -s $O/$f.jsonl ] && cp $O/$f.jsonl $P/${TAG}_$f.jsonl; done
+for f in verify_b4096_device_timeline host_field_bench host_field_bench_fp2_in_c host_field_bench_all_c lscpu single_blob_phases single_blob_timing_thread_per_job_arm single_blob_timing_r05_arm; do
+  [ -s $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${TAG}_$f.txt
+done
+[ -s $O/scaling_projection.json ] && cp $O/scaling_projection.json $P/${TAG}_scaling_projection.json
+[ -s $O/scaling_projection_table.md ] && cp $O/scaling_projection_table.md $P/${TAG}_scaling_projection_table.md
 python3 - "$TAG" <<'PY'
 import csv, glob, os, sys
 tag = sys.argv[1]
@@ -68,5 +75,5 @@ ls $P | grep $TAG | wc -l
 [ -s $O/kt_two_streams_untuned/kt_kernel_trace.csv ] && python3 tools/timeline.py $O/kt_two_streams_untuned/kt_kernel_trace.csv 66 > $P/${TAG}_proof_two_streams_untuned_timeline.txt
 true
 [ -s $O/gpu_test_log.txt ] && grep -v "amdgpu.ids" $O/gpu_test_log.txt > $P/${TAG}_gpu_test_log.txt
-[ -s $O/soak.json ] && cat $O/soak.json $O/soak_ckzg.json $O/soak_small.json $O/soak_verify_direct16.json $O/soak_verify_default.json >> $P/${TAG}_soak.jsonl
+[ -s $O/soak.json ] && cat $O/soak.json $O/soak_ckzg.json $O/soak_small.json $O/soak_verify_direct16.json $O/soak_verify_default.json > $P/${TAG}_soak_final.jsonl
 true
