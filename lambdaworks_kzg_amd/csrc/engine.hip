@@ -1482,14 +1482,24 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
     // (aux[3] for the uploads shares the validation stream's queue: every upload of the first 3.5 ms waited, 15.9 instead of 13.1 ms.)
     hipStream_t st = c->stream, sv = c->vstream, sc = c->aux[knobs().stage_streams[0]], sh = c->aux[knobs().stage_streams[1]];
     Fr *z = c->ws.z_long;
-    // the host's share of the hashing: whole slices at the END of the batch
+    // The GPU's hash kernel is a 3.1 ms latency chain per launch whatever its size, so its LAST slice has to land that long before the
+    // uploads end: the host threads take what is uploaded in those last 3.4 ms (1536 blobs at 56 GB/s, in whole slices) -- but no more than
+    // they hash in 0.8 of the whole upload at their measured rate, or they would be the tail instead. Whole slices for the GPU; the host
+    // gets the rest, the ragged end included.
     const size_t slice = kMaxChunk / 2;
     const double upload_rate = 56e9;   // pageable memory -> HBM on this platform (profiles/r06_h2d_bench.txt)
-    double f = 0.8 * host_hash_rate() / upload_rate;
-    if (f > 1.0) f = 1.0;
-    size_t n_gpu = (size_t)((1.0 - f) * (double)n) / slice * slice;   // whole slices for the GPU; the host takes the rest, the ragged end included
-    if (n_gpu > n) n_gpu = n;
-    const size_t n_host = n - n_gpu;
+    size_t n_host = ((size_t)(3.4e-3 * upload_rate / (double)kBlobBytes) + slice - 1) / slice * slice;
+    const size_t host_can = (size_t)(0.8 * host_hash_rate() / upload_rate * (double)n);
+    if (n_host > host_can) n_host = host_can / slice * slice;
+    if (n_host > n) n_host = n;
+    const size_t n_gpu = (n - n_host) / slice * slice;
+    n_host = n - n_gpu;
+    // The head's hash launches share ONE stream (hash launches on other side streams held up the uploads: the runtime's hardware queues,
+    // profiles/r06_experiments.md section 9), so they run one after the other, 3.1 ms each: a launch goes out after every third slice
+    // counted back from the head's last one (three slices are 3.6 ms of upload) and takes every slice that has landed since the previous
+    // launch -- the last launch starts the moment the head's last slice is there, on a stream that has just fallen idle.
+    const size_t gpu_slices = n_gpu / slice;
+    const size_t every = 3;
     std::vector<uint8_t> dig(32 * (n_host ? n_host : 1));
     SideTask hasher;   // joined by its destructor on every exit (digests assume canonical commitment bytes; the comparison below confirms or refutes that)
     if (n_host) hasher.start([&, n_gpu, n_host]() { challenge_digests_host(dig.data(), blobs + n_gpu * (size_t)kBlobBytes, comm48 + 48 * n_gpu, n_host); });
@@ -1508,13 +1518,19 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
     launch_verify_rows(vb, n, sv, false);
     LWK_HIP(hipEventRecord(c->ev_join[kMaxSplit - 1], sv));
     // the uploads (this thread is inside a blocking pageable copy most of the time) and, behind each slice of the head, its hash
+    size_t hashed = 0, landed = 0;   // slices
     for (size_t off = 0; off < n; off += slice) {
         const size_t m = n - off < slice ? n - off : slice;
         LWK_HIP(hipMemcpyAsync(d_all + off * (size_t)kBlobBytes, blobs + off * (size_t)kBlobBytes, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, sc));
         if (off < n_gpu) {
-            LWK_HIP(hipEventRecord(c->ev_join[3], sc));
-            LWK_HIP(hipStreamWaitEvent(sh, c->ev_join[3], 0));
-            launch_challenge(d_all + off * (size_t)kBlobBytes, vb.comm_in + 48 * off, z + off, le, m, sh);
+            landed++;
+            if ((gpu_slices - landed) % every == 0) {
+                const size_t lo = hashed * slice, cnt = (landed - hashed) * slice;
+                LWK_HIP(hipEventRecord(c->ev_join[3], sc));
+                LWK_HIP(hipStreamWaitEvent(sh, c->ev_join[3], 0));
+                launch_challenge(d_all + lo * (size_t)kBlobBytes, vb.comm_in + 48 * lo, z + lo, le, cnt, sh);
+                hashed = landed;
+            }
         }
     }
     LWK_HIP(hipEventRecord(c->ev_join[3], sc));
@@ -1699,8 +1715,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             hipStreamSynchronize(c->vstream);
             hipStreamSynchronize(c->aux[0]);
             hipStreamSynchronize(c->aux[1]);
-            hipStreamSynchronize(c->aux[knobs().stage_streams[0]]);   // (the copy stream of verify_prepare_staged)
-            hipStreamSynchronize(c->aux[knobs().stage_streams[1]]);
+            for (int k = 2; k < kMaxSplit; k++) hipStreamSynchronize(c->aux[k]);   // (verify_prepare_staged: its copy and hash streams)
         }
     } drain{c};
     if (vb.owned) {
