@@ -122,7 +122,10 @@ C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commi
                                 const Bytes48 *proof_bytes, const KZGSettings *s);
 
 /* src/lib.rs:525-614. n == 0 -> C_KZG_OK with *ok = false in reference mode (src/lib.rs:538-543) and *ok = true in
- * c-kzg mode (the reference's own vector verify_blob_kzg_proof_batch_case_a271b78b8e869d69). */
+ * c-kzg mode (the reference's own vector verify_blob_kzg_proof_batch_case_a271b78b8e869d69).
+ * Batches of more than 1024 blobs are uploaded into a device buffer of n * 131072 bytes that the settings object keeps (grow-only, freed by
+ * free_trusted_setup): 4096 blobs 12.1 ms, of which 9.6 are the upload; lwkzg_verify_blob_kzg_proof_batch_device takes blobs that are
+ * already in HBM (5.3 ms). */
 C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
                                       const Bytes48 *proofs_bytes, size_t n, const KZGSettings *s);
 

@@ -3050,9 +3050,10 @@ static C_KZG_RET blob_proof_batch_impl(KZGProof *out, const Blob *blobs, const B
 // pinned memory by the MSM's last wave, the redo flag is a pinned word: no copy of a result, no fill, no second-pass launch, no verdict
 // word (a reference-mode parse cannot fail; the validation's verdict is this process's own). Anything irregular -- an invalid or
 // non-canonically encoded commitment, P = +-Q inside a quad, no pinned memory -- returns kOneBlobFallback and the caller takes the
-// general path, which owns the error codes. Caller holds c->mu and the workspace.
-static const C_KZG_RET kOneBlobFallback = (C_KZG_RET)100;   // (not a value of the ABI: internal)
-static C_KZG_RET blob_proof_one_host(Ctx *c, uint8_t *out48, const uint8_t *blob, const uint8_t *comm48, int mode) {
+// general path, which owns the error codes. (An int, not a C_KZG_RET: 100 is not a value of that enumeration, and loading it into one was
+// undefined behaviour that the host-UBSan run of the GPU suite caught.) Caller holds c->mu and the workspace.
+static const int kOneBlobFallback = 100;   // (not a value of the ABI: internal)
+static int blob_proof_one_host(Ctx *c, uint8_t *out48, const uint8_t *blob, const uint8_t *comm48, int mode) {
     if (mode != LWKZG_MODE_REFERENCE || !c->direct_table || !knobs().zero_copy || peer_busy(c)) return kOneBlobFallback;
     const uint32_t ctr_words = direct_one_blob_counter_words(c->direct_bits);
     if (!ctr_words) return kOneBlobFallback;
@@ -3092,8 +3093,8 @@ static C_KZG_RET blob_proof_batch_host(Ctx *c, KZGProof *out, const Blob *blobs,
     if (n >= kMaxChunk / 2)
         return blob_proofs_sliced(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, n, mode, first_bad);
     if (n == 1) {
-        const C_KZG_RET r1 = blob_proof_one_host(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, mode);
-        if (r1 != kOneBlobFallback) return r1;
+        const int r1 = blob_proof_one_host(c, (uint8_t *)out, (const uint8_t *)blobs, (const uint8_t *)commitments, mode);
+        if (r1 != kOneBlobFallback) return (C_KZG_RET)r1;
     }
     for (size_t off = 0; off < n; off += kMaxChunk) {
         size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
