@@ -852,6 +852,24 @@ def test_verify_long_batch_pipelined_path(K, gpu_setup):
     with pytest.raises(K.KzgError) as e:
         K.verify_blob_kzg_proof_batch(data, bytes(badc), proofs, n, gpu_setup)
     assert e.value.rc == K.C_KZG_ERROR
+    # r06: such a batch lands in one device buffer, the head hashed by the GPU and the tail by the host threads (engine.hip:
+    # verify_prepare_staged) -- the same three outcomes with the defect in the HEAD of the batch, and with an invalid proof encoding
+    wrong = bytearray(proofs)
+    wrong[48 * 7:48 * 8] = proofs[48 * 300:48 * 301]
+    assert K.verify_blob_kzg_proof_batch(data, comms, bytes(wrong), n, gpu_setup) is False
+    badc = bytearray(comms)
+    badc[48 * 33] &= 0x7f
+    with pytest.raises(K.KzgError) as e:
+        K.verify_blob_kzg_proof_batch(data, bytes(badc), proofs, n, gpu_setup)
+    assert e.value.rc == K.C_KZG_ERROR
+    badp = bytearray(proofs)
+    badp[48 * 600 + 47] ^= 1                                     # x moves off the curve or out of the subgroup
+    with pytest.raises(K.KzgError) as e:
+        K.verify_blob_kzg_proof_batch(data, comms, bytes(badp), n, gpu_setup)
+    assert e.value.rc == K.C_KZG_ERROR
+    swapped = data[:B.BYTES_PER_BLOB * 5] + data[B.BYTES_PER_BLOB * 6:B.BYTES_PER_BLOB * 7] + data[B.BYTES_PER_BLOB * 5:B.BYTES_PER_BLOB * 6] + data[B.BYTES_PER_BLOB * 7:]
+    assert K.verify_blob_kzg_proof_batch(swapped, comms, proofs, n, gpu_setup) is False
+    assert K.verify_blob_kzg_proof_batch(data, comms, proofs, n, gpu_setup) is True   # and the settings object is none the worse for it
 
 
 def test_direct_table_that_does_not_fit_leaves_the_engine_in_place(K, direct_setup, gpu_setup):

@@ -117,6 +117,12 @@ def test_ckzg_device_batches_evaluate_straight_from_the_blobs(K, gpu_setup, orac
             with pytest.raises(K.KzgError) as e:
                 _verify_dev(K, torch, bad, cj, pj, n, gpu_setup)
             assert e.value.rc == K.C_KZG_BADARGS, (where, e_at)
+            if n > 1024:   # r06: the host-pointer form of a long batch evaluates from its uploaded blobs the same way (verify_prepare_staged)
+                with pytest.raises(K.KzgError) as e:
+                    K.verify_blob_kzg_proof_batch(bad, cj, pj, n, gpu_setup)
+                assert e.value.rc == K.C_KZG_BADARGS, (where, e_at)
+        if n > 1024:
+            assert K.verify_blob_kzg_proof_batch(swapped, cj, pj, n, gpu_setup) is False
     finally:
         K.set_mode(K.MODE_REFERENCE)
 
