@@ -296,6 +296,7 @@ struct Ctx {
     SmallProofHost sph;
     DevStage stage;     // under mu
     uint8_t *one_pin = nullptr;    // 4 KiB of pinned memory for a ONE-blob proof call (r06): XYZZ sum 224 | redo flag 4 | digest 32; under mu
+    hipStream_t prio_copy = nullptr;   // a high-priority stream for the uploads of verify_prepare_staged (created by its first call, under mu)
     uint8_t *vblobs = nullptr;     // ALL blobs of a long host-pointer verification on the device (grow-only, under mu): verify_prepare_staged
     size_t vblobs_cap = 0;         // blobs
     uint8_t *host_res = nullptr;   // results / verdicts / digests of a long host-pointer batch on the device (grow-only, under mu):

@@ -474,6 +474,7 @@ static void ctx_destroy(Ctx *c) {
     if (c->comb.pinned_blobs) hipHostFree(c->comb.pinned_blobs);
     dev_free(c->host_res);
     dev_free(c->vblobs);
+    if (c->prio_copy) hipStreamDestroy(c->prio_copy);
     if (c->one_pin) hipHostFree(c->one_pin);
     for (int k = 0; k < 2; k++) {
         dev_free(c->stage.slot[k]);
@@ -1477,10 +1478,23 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
     if (rc != C_KZG_OK) return rc;
     taken = true;
     const int bad = le ? kStatusBadArgs : kStatusError;
-    // Four streams are at work at once here, and the runtime has four hardware queues that it hands out in creation order: the main
-    // stream, the validation stream, aux[0] and aux[1] are the first four a context creates, so none of them queues behind another.
-    // (aux[3] for the uploads shares the validation stream's queue: every upload of the first 3.5 ms waited, 15.9 instead of 13.1 ms.)
-    hipStream_t st = c->stream, sv = c->vstream, sc = c->aux[knobs().stage_streams[0]], sh = c->aux[knobs().stage_streams[1]];
+    // Four streams are at work at once here, and the runtime multiplexes a process's streams onto four hardware queues: a copy that shares
+    // its queue with the validation kernels or with a 3.1 ms hash launch simply waits for them (uploads on aux[3]: 15.9 instead of 13.1 ms;
+    // which side streams collide depends on what else the process has created). The uploads therefore get a HIGH-PRIORITY stream of their
+    // own -- the runtime keeps a queue per priority level -- and every choice of hash stream then measures the same
+    // (profiles/r06_experiments.md section 9). LWKZG_STAGE_STREAMS=c,h (experiment) puts them on side streams instead.
+    hipStream_t st = c->stream, sv = c->vstream, sc = c->aux[knobs().stage_streams[0] & 7], sh = c->aux[knobs().stage_streams[1]];
+    if (knobs().stage_streams[0] >= 8) {
+        if (!c->prio_copy) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&c->prio_copy, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                c->prio_copy = nullptr;
+            }
+        }
+        if (c->prio_copy) sc = c->prio_copy;
+    }
     Fr *z = c->ws.z_long;
     // The GPU's hash kernel is a 3.1 ms latency chain per launch whatever its size, so its LAST slice has to land that long before the
     // uploads end: the host threads take what is uploaded in those last 3.4 ms (1536 blobs at 56 GB/s, in whole slices) -- but no more than
@@ -1716,6 +1730,7 @@ C_KZG_RET verify_prepare_host(Ctx *c, const uint8_t *blobs, const uint8_t *comm4
             hipStreamSynchronize(c->aux[0]);
             hipStreamSynchronize(c->aux[1]);
             for (int k = 2; k < kMaxSplit; k++) hipStreamSynchronize(c->aux[k]);   // (verify_prepare_staged: its copy and hash streams)
+            if (c->prio_copy) hipStreamSynchronize(c->prio_copy);
         }
     } drain{c};
     if (vb.owned) {

@@ -56,7 +56,7 @@ struct Knobs {
     bool set_mode_in_place = true;   // LWKZG_SET_MODE_IN_PLACE=0
     int host_fp_portable = 0;        // LWKZG_HOST_FP_PORTABLE: 1 = the C products of hostfp.h on a core that has MULX/ADX, 2 = only the Fp2 product in C (the A/B arms)
     int host_hash_grain = 4;         // LWKZG_HOST_HASH_GRAIN: blobs per thread woken for a host hashing job (1 = wake every parked thread, as before r06)
-    int stage_streams[2] = {1, 0};   // LWKZG_STAGE_STREAMS=c,h: which side streams (aux index) carry the uploads / the head's hashes of a staged verification
+    int stage_streams[2] = {8, 0};   // LWKZG_STAGE_STREAMS=c,h: which streams carry the uploads (aux index; 8 = a high-priority stream of their own) / the head's hashes (aux index) of a staged verification
     int side_workers = 1;            // LWKZG_SIDE_WORKERS: 0 = a std::thread per SideTask, as before r06 (the A/B arm)
     bool pairing_generic_sqr = false, pairing_naive = false, pairing_no_precomp = false, pairing_one_thread = false;  // LWKZG_PAIRING_*
     // r06, batch verification

@@ -114,8 +114,8 @@ Knobs read_env() {
     r.flag(k.zero_copy, "LWKZG_ZERO_COPY", EXP);
     r.flag(k.host_stage, "LWKZG_HOST_STAGE", EXP);
     if (const char *e = r.get("LWKZG_STAGE_STREAMS", EXP)) {
-        int a = 1, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 8 && b >= 0 && b < 8 && a != b) {
+        int a = 8, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a <= 8 && b >= 0 && b < 8 && a != b) {   // (8: a high-priority stream for the uploads)
             k.stage_streams[0] = a;
             k.stage_streams[1] = b;
         }
