@@ -1393,6 +1393,21 @@ static uint8_t *host_res_block(Ctx *c, size_t bytes) {
 }
 
 // ---- the device-side double buffer of the long host-pointer batches (engine.h: DevStage). Caller holds c->mu. ---------------------------
+// the stream the long host-pointer batches upload on: a high-priority one of the context's own (the runtime keeps a hardware queue per
+// priority level, so these copies never queue behind a kernel of another stream -- verify_prepare_staged has the measurement); a side
+// stream when it cannot be had or when LWKZG_STAGE_STREAMS (experiment) names one
+static hipStream_t upload_stream(Ctx *c) {
+    if (knobs().stage_streams[0] < 8) return c->aux[knobs().stage_streams[0]];
+    if (!c->prio_copy) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->prio_copy, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            c->prio_copy = nullptr;
+        }
+    }
+    return c->prio_copy ? c->prio_copy : c->aux[3];
+}
 static bool dev_stage_ready(Ctx *c) {
     DevStage &r = c->stage;
     if (r.ready || r.failed || !knobs().host_stage) return r.ready && knobs().host_stage;
@@ -1425,7 +1440,7 @@ static size_t stage_slice_len(size_t k, size_t remaining) {
 static C_KZG_RET stage_upload(Ctx *c, size_t k, const uint8_t *src, size_t cnt, hipStream_t compute, uint8_t **d_blobs) {
     DevStage &r = c->stage;
     const int s = (int)(k & 1);
-    hipStream_t sc = c->aux[3];   // (aux[0..2] are the sub-batch streams of the launch sets)
+    hipStream_t sc = upload_stream(c);   // (aux[0..2] are the sub-batch streams of the launch sets)
     if (k >= 2) LWK_HIP(hipStreamWaitEvent(sc, r.parsed[s], 0));
     LWK_HIP(hipMemcpyAsync(r.slot[s], src, cnt * (size_t)kBlobBytes, hipMemcpyHostToDevice, sc));
     LWK_HIP(hipEventRecord(r.copied[s], sc));
@@ -1483,18 +1498,7 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
     // which side streams collide depends on what else the process has created). The uploads therefore get a HIGH-PRIORITY stream of their
     // own -- the runtime keeps a queue per priority level -- and every choice of hash stream then measures the same
     // (profiles/r06_experiments.md section 9). LWKZG_STAGE_STREAMS=c,h (experiment) puts them on side streams instead.
-    hipStream_t st = c->stream, sv = c->vstream, sc = c->aux[knobs().stage_streams[0] & 7], sh = c->aux[knobs().stage_streams[1]];
-    if (knobs().stage_streams[0] >= 8) {
-        if (!c->prio_copy) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&c->prio_copy, hipStreamNonBlocking, hi) != hipSuccess) {
-                (void)hipGetLastError();
-                c->prio_copy = nullptr;
-            }
-        }
-        if (c->prio_copy) sc = c->prio_copy;
-    }
+    hipStream_t st = c->stream, sv = c->vstream, sc = upload_stream(c), sh = c->aux[knobs().stage_streams[1]];
     Fr *z = c->ws.z_long;
     // The GPU's hash kernel is a 3.1 ms latency chain per launch whatever its size, so its LAST slice has to land that long before the
     // uploads end: the host threads take what is uploaded in those last 3.4 ms (1536 blobs at 56 GB/s, in whole slices) -- but no more than
@@ -2722,7 +2726,7 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
         // r06 (engine.h: DevStage): the slices are uploaded into a device-side double buffer on a copy stream and go through the
         // device-resident pipeline itself -- whole chunks, one compute stream -- while the next one is on its way
         hipStream_t st = c->stream;
-        LWK_HIP(hipStreamWaitEvent(c->aux[3], c->ev_fork, 0));
+        LWK_HIP(hipStreamWaitEvent(upload_stream(c), c->ev_fork, 0));
         size_t k = 0;
         for (size_t off = 0, cnt = 0; off < n; off += cnt, k++) {
             cnt = stage_slice_len(k, n - off);
@@ -2735,7 +2739,7 @@ static C_KZG_RET commitment_batch_impl(KZGCommitment *out, const Blob *blobs, si
             if (rc == C_KZG_OK) rc = commit_batch_device(c, d_out_all + 48 * off, d_blobs, cnt, mode, st, d_status_all + off);
             if (rc == C_KZG_OK) rc = stage_parsed(c, k, st);   // (behind the whole slice: the bucket engine's sub-batches parse on streams of their own)
             if (rc != C_KZG_OK) {
-                hipStreamSynchronize(c->aux[3]);
+                hipStreamSynchronize(upload_stream(c));
                 hipStreamSynchronize(st);
                 return rc;
             }
