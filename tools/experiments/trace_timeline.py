@@ -1,4 +1,5 @@
-"""kernel + memory-copy timeline of the LAST call in a rocprofv3 --kernel-trace --memory-copy-trace directory (calls are separated by gaps > 3 ms)."""
+"""kernel + memory-copy timeline of the LAST call in a rocprofv3 --kernel-trace --memory-copy-trace directory (calls are separated by gaps > 3 ms);
+a third argument N takes the last N events instead (calls that follow each other without a gap)."""
 import csv, glob, sys
 O, out_path = sys.argv[1], sys.argv[2]
 ev = []
@@ -14,6 +15,8 @@ for i in range(1, len(ev)):
     if ev[i][0] - max(e[1] for e in ev[max(0, i - 60):i]) > 3_000_000:
         cut = i
 last = ev[cut:]
+if len(sys.argv) > 3:
+    last = ev[-int(sys.argv[3]):]
 t0 = last[0][0]
 with open(out_path, "w") as out:
     for s, e, n in last:
