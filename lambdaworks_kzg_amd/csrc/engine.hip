@@ -1518,6 +1518,9 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
     // launch -- the last launch starts the moment the head's last slice is there, on a stream that has just fallen idle.
     const size_t gpu_slices = n_gpu / slice;
     const size_t every = 3;
+    if (knobs().timing)
+        fprintf(stderr, "[lambdaworks_kzg_amd] staged verification of %zu blobs: the GPU hashes the first %zu (a launch per %zu slices of %zu), the host threads the last %zu (they hashed %.1f GB/s lately)\n",
+                n, n_gpu, every, slice, n_host, host_hash_rate() * 1e-9);
     std::vector<uint8_t> dig(32 * (n_host ? n_host : 1));
     SideTask hasher;   // joined by its destructor on every exit (digests assume canonical commitment bytes; the comparison below confirms or refutes that)
     if (n_host) hasher.start([&, n_gpu, n_host]() { challenge_digests_host(dig.data(), blobs + n_gpu * (size_t)kBlobBytes, comm48 + 48 * n_gpu, n_host); });
@@ -3316,7 +3319,10 @@ static C_KZG_RET reserve_ctx(Ctx *c, size_t max_batch) {
     }
     // a caller that announces batches of more than a chunk gets the device-side double buffer of the long host-pointer batches now (256 MiB)
     // instead of inside its first long call; the twin context never runs host-pointer batches
-    if (max_batch > kMaxChunk && !c->is_twin) (void)dev_stage_ready(c);
+    if (max_batch > kMaxChunk && !c->is_twin) {
+        (void)dev_stage_ready(c);
+        (void)upload_stream(c);   // (the high-priority stream their uploads run on)
+    }
     return C_KZG_OK;
 }
 
