@@ -8,3 +8,4 @@ timeout 2400 python -m pytest tests -m gpu -q --durations=5 > $O/g33_gpu_test_lo
 tail -4 $O/g33_gpu_test_log.txt
 LWKZG_BENCH_DETAIL=$O/g33_bench_detail.json python bench.py > $O/g33_bench_line.json 2> $O/g33_bench_err.txt
 tail -1 $O/g33_bench_line.json | cut -c1-400
+LWKZG_TIMING=1 python tools/verify_device_loop.py --n 4096 --calls 3 --host 2>&1 | grep "staged verification\|verify batch" | tail -4 | tee $O/g33_staged_split.txt
