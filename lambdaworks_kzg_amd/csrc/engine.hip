@@ -1500,24 +1500,9 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
     // (profiles/r06_experiments.md section 9). LWKZG_STAGE_STREAMS=c,h (experiment) puts them on side streams instead.
     hipStream_t st = c->stream, sv = c->vstream, sc = upload_stream(c), sh = c->aux[knobs().stage_streams[1]];
     Fr *z = c->ws.z_long;
-    // The GPU's hash kernel is a 3.1 ms latency chain per launch whatever its size, so its LAST slice has to land that long before the
-    // uploads end: the host threads take what is uploaded in those last 3.4 ms (1536 blobs at 56 GB/s, in whole slices) -- but no more than
-    // they hash in 0.8 of the whole upload at their measured rate, or they would be the tail instead. Whole slices for the GPU; the host
-    // gets the rest, the ragged end included.
-    const size_t slice = kMaxChunk / 2;
-    const double upload_rate = 56e9;   // pageable memory -> HBM on this platform (profiles/r06_h2d_bench.txt)
-    size_t n_host = ((size_t)(3.4e-3 * upload_rate / (double)kBlobBytes) + slice - 1) / slice * slice;
-    const size_t host_can = (size_t)(0.8 * host_hash_rate() / upload_rate * (double)n);
-    if (n_host > host_can) n_host = host_can / slice * slice;
-    if (n_host > n) n_host = n;
-    const size_t n_gpu = (n - n_host) / slice * slice;
-    n_host = n - n_gpu;
-    // The head's hash launches share ONE stream (hash launches on other side streams held up the uploads: the runtime's hardware queues,
-    // profiles/r06_experiments.md section 9), so they run one after the other, 3.1 ms each: a launch goes out after every third slice
-    // counted back from the head's last one (three slices are 3.6 ms of upload) and takes every slice that has landed since the previous
-    // launch -- the last launch starts the moment the head's last slice is there, on a stream that has just fallen idle.
-    const size_t gpu_slices = n_gpu / slice;
-    const size_t every = 3;
+    // who hashes what, and when the head's launches go out: plan.h: plan_staged_verification (pure; tests/test_plan_cpu.py pins its table)
+    const StagedSplit split = plan_staged_verification(n, host_hash_rate());
+    const size_t slice = split.slice, n_gpu = split.n_gpu, n_host = split.n_host, every = split.every;
     if (knobs().timing)
         fprintf(stderr, "[lambdaworks_kzg_amd] staged verification of %zu blobs: the GPU hashes the first %zu (a launch per %zu slices of %zu), the host threads the last %zu (they hashed %.1f GB/s lately)\n",
                 n, n_gpu, every, slice, n_host, host_hash_rate() * 1e-9);
@@ -1545,7 +1530,7 @@ static C_KZG_RET verify_prepare_staged(Ctx *c, const uint8_t *blobs, const uint8
         LWK_HIP(hipMemcpyAsync(d_all + off * (size_t)kBlobBytes, blobs + off * (size_t)kBlobBytes, m * (size_t)kBlobBytes, hipMemcpyHostToDevice, sc));
         if (off < n_gpu) {
             landed++;
-            if ((gpu_slices - landed) % every == 0) {
+            if (split.launch_after(landed)) {
                 const size_t lo = hashed * slice, cnt = (landed - hashed) * slice;
                 LWK_HIP(hipEventRecord(c->ev_join[3], sc));
                 LWK_HIP(hipStreamWaitEvent(sh, c->ev_join[3], 0));

@@ -87,4 +87,34 @@ constexpr int kStatusOk = 0;
 constexpr int kStatusBadArgs = 1;
 constexpr int kStatusError = 2;
 
+
+// ---- who hashes which blobs of a long host-pointer verification (r06; engine.hip: verify_prepare_staged) ---------------------------------
+// The batch is uploaded in slices; the GPU's hash kernel takes the HEAD (whole slices, as they land), the host threads the TAIL (the rest,
+// the ragged end included). Pure: the batch, the two measured rates, the kernel's latency.
+//   * the GPU's kernel is a latency chain of `hash_launch_s` per launch whatever its size, so the head's LAST slice has to land that long
+//     before the uploads end: the tail is what is uploaded in those last `hash_launch_s` (+ 6 %), in whole slices ...
+//   * ... but no more than the host threads hash in 0.8 of the whole upload at their rate -- or they would be the tail of the call instead;
+//   * the head's launches share one stream and so run one after the other: one goes out after every `every`-th slice counted back from
+//     the head's last (`every` slices take longer to upload than a launch runs), each taking every slice that landed since the previous.
+struct StagedSplit {
+    size_t n_gpu = 0, n_host = 0;   // blobs hashed by the GPU's kernel (the first n_gpu) / by the host threads (the last n_host)
+    size_t slice = 0, every = 0;
+    // does a launch go out once `landed` of the head's slices are on the device?
+    bool launch_after(size_t landed) const { return every != 0 && n_gpu != 0 && landed * slice <= n_gpu && ((n_gpu / slice - landed) % every) == 0; }
+};
+inline StagedSplit plan_staged_verification(size_t n, double host_hash_rate, double upload_rate = 56e9, double hash_launch_s = 3.2e-3,
+                                            size_t slice = kPlanMaxChunk / 2, size_t blob_bytes = 131072) {
+    StagedSplit p;
+    p.slice = slice;
+    size_t n_host = ((size_t)(1.0625 * hash_launch_s * upload_rate / (double)blob_bytes) + slice - 1) / slice * slice;
+    const size_t host_can = (size_t)(0.8 * host_hash_rate / upload_rate * (double)n);
+    if (n_host > host_can) n_host = host_can / slice * slice;
+    if (n_host > n) n_host = n;
+    p.n_gpu = (n - n_host) / slice * slice;
+    p.n_host = n - p.n_gpu;
+    const double slice_s = (double)slice * (double)blob_bytes / upload_rate;
+    p.every = (size_t)(hash_launch_s / slice_s) + 1;
+    return p;
+}
+
 }  // namespace lwk

@@ -1,10 +1,28 @@
 // CPU harness of csrc/plan.h (compiled by tests/test_plan_cpu.py with g++): prints plan_proof_call over a grid of batch sizes, host-thread
 // warmth, peer state, table form, staging availability and three knob sets, one line per point:
 //   n warm busy direct staging knobset -> schedule per_chunk chunks parts heavy_serial
+// With the argument "staged": plan_staged_verification over batch sizes and host hashing rates, one line per point:
+//   n rate_GBps -> n_gpu n_host slice every launches-after-slices...
 #include <stdio.h>
+#include <string.h>
 #include "../lambdaworks_kzg_amd/csrc/plan.h"
 
-int main() {
+static int staged_table() {
+    const size_t ns[] = {1025, 1100, 1536, 2048, 2600, 3000, 4096, 8192, 16384, 65536};
+    const double rates[] = {0.0, 4.0, 18.0, 30.0, 36.0, 70.0, 400.0};
+    for (size_t n : ns)
+        for (double r : rates) {
+            const lwk::StagedSplit p = lwk::plan_staged_verification(n, r * 1e9);
+            printf("%zu %.0f -> %zu %zu %zu %zu", n, r, p.n_gpu, p.n_host, p.slice, p.every);
+            for (size_t landed = 1; landed * p.slice <= p.n_gpu; landed++)
+                if (p.launch_after(landed)) printf(" %zu", landed);
+            printf("\n");
+        }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && strcmp(argv[1], "staged") == 0) return staged_table();
     const size_t ns[] = {1, 2, 8, 63, 64, 65, 100, 128, 191, 192, 193, 255, 256, 257, 300, 319, 320, 383, 384, 385, 512, 513, 1000, 1024, 1025, 2048, 4096};
     lwk::PlanKnobs sets[3];
     sets[1].mid_proof_pipe = false;                              // LWKZG_MID_PROOF_PIPE=0

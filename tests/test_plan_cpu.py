@@ -57,3 +57,33 @@ def test_plan_table(tmp_path):
     for key, val in rows.items():
         if not key[4]:
             assert val[0] in (COLD, GPU), key                                                         # without staging no host-assisted schedule
+
+
+def test_staged_verification_split(tmp_path):
+    """plan.h: plan_staged_verification -- who hashes which blobs of a long host-pointer verification
+    (/root/reference/src/lib.rs:525-614 per blob: compute_challenge), as a pure function of the batch and the host threads' measured hashing
+    rate. Invariants on every row, and the rows the documentation quotes."""
+    exe = str(tmp_path / "plan_table")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "plan_table.cpp"), "-o", exe])
+    rows = {}
+    for line in subprocess.check_output([exe, "staged"], text=True).splitlines():
+        lhs, rhs = line.split(" -> ")
+        n, rate = (int(x) for x in lhs.split())
+        v = [int(x) for x in rhs.split()]
+        rows[(n, rate)] = (v[0], v[1], v[2], v[3], v[4:])
+    assert len(rows) == 70
+    for (n, rate), (n_gpu, n_host, slice_, every, launches) in rows.items():
+        assert n_gpu + n_host == n and n_gpu % slice_ == 0 and slice_ == 512 and every == 3       # whole slices for the GPU; three slices upload in 3.6 ms, a launch runs 3.1
+        head = n_gpu // slice_
+        assert (launches[-1] == head if head else launches == [])                                 # the last launch goes out when the head's last slice has landed
+        assert all(b - a == every for a, b in zip(launches, launches[1:])) and (not launches or launches[0] <= every)
+        assert n_host <= max(0.8 * rate / 56.0 * n, 0) + slice_                                   # never more than the host threads hash beside the upload (+ the ragged end)
+        if rate >= 36 and n >= 4096:
+            assert n_host == 1536 + (n % slice_)                                                  # a fast enough host takes what is uploaded in the last 3.4 ms, no more
+    assert rows[(4096, 36)] == (2560, 1536, 512, 3, [2, 5])     # DESIGN.md section 8 / profiles/r06_experiments.md section 9: two launches, after the 2nd and the 5th slice
+    assert rows[(4096, 30)] == (2560, 1536, 512, 3, [2, 5])
+    assert rows[(4096, 18)] == (3072, 1024, 512, 3, [3, 6])     # a slower host takes less
+    assert rows[(4096, 0)] == (4096, 0, 512, 3, [2, 5, 8])      # no host threads worth the name: everything on the GPU, a 3.2 ms tail
+    assert rows[(1100, 36)] == (512, 588, 512, 3, [1])          # tests/test_gpu_parity.py::test_verify_long_batch_pipelined_path
+    assert rows[(2600, 36)] == (1536, 1064, 512, 3, [3])        # tests/verify_arm_worker.py's long shard is 2100 blobs of such a batch; the whole batch: this row
+    assert rows[(16384, 36)][:2] == (14848, 1536)
